@@ -1,0 +1,348 @@
+"""ctypes loader for the parity oracle (oracle/liboracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; the product
+package (spiral_amd) never does.  Buffers are numpy uint64 arrays in the reference's layouts.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liboracle.so")
+
+N = 2048
+P = 268369921
+B = 249561089
+Q = P * B
+NTTP = 2 * N  # words per NTT-form polynomial
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("nu1", C.c_uint32),
+        ("nu2", C.c_uint32),
+        ("t_gsw", C.c_uint32),
+        ("t_conv", C.c_uint32),
+        ("t_exp", C.c_uint32),
+        ("t_exp_right", C.c_uint32),
+        ("qprime_bits", C.c_uint32),
+        ("direct_upload", C.c_uint32),
+        ("p_db", C.c_uint64),
+    ]
+
+
+class Shape(C.Structure):
+    _fields_ = [
+        ("dim0", C.c_uint32),
+        ("num_per", C.c_uint32),
+        ("ell", C.c_uint32),
+        ("m2", C.c_uint32),
+        ("g", C.c_uint32),
+        ("stopround", C.c_uint32),
+        ("n_left", C.c_uint32),
+        ("n_right", C.c_uint32),
+        ("n_query_cts", C.c_uint32),
+        ("n_bits", C.c_uint32),
+        ("qprime", C.c_uint64),
+    ]
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(HERE, "spiral_oracle.c")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", HERE, "-s"])
+    return LIB_PATH
+
+
+_lib = None
+_u64p = C.POINTER(C.c_uint64)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = C.CDLL(LIB_PATH)
+        _lib.orc_client_new.restype = C.c_void_p
+        _lib.orc_client_new.argtypes = [C.POINTER(Params), C.c_uint64, C.c_int]
+        _lib.orc_client_free.argtypes = [C.c_void_p]
+        for name in ("orc_words_w_left", "orc_words_w_right", "orc_words_w", "orc_words_v", "orc_words_query"):
+            getattr(_lib, name).restype = C.c_size_t
+            getattr(_lib, name).argtypes = [C.POINTER(Params)]
+        _lib.orc_rescale.restype = C.c_uint64
+        _lib.orc_rescale.argtypes = [C.c_uint64] * 3
+        _lib.orc_crt_compose.restype = C.c_uint64
+        _lib.orc_crt_compose.argtypes = [C.c_uint64] * 2
+        _lib.orc_get_bits_per.restype = C.c_uint32
+        _lib.orc_get_bits_per.argtypes = [C.c_uint32]
+        _lib.orc_db_coeff.restype = C.c_uint64
+        _lib.orc_db_coeff.argtypes = [C.c_uint64] * 4
+    return _lib
+
+
+def _p(a: np.ndarray):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"], (a.dtype, a.flags)
+    return a.ctypes.data_as(_u64p)
+
+
+def u64(*shape) -> np.ndarray:
+    return np.zeros(shape, dtype=np.uint64)
+
+
+def shape_of(p: Params) -> Shape:
+    s = Shape()
+    if lib().orc_get_shape(C.byref(p), C.byref(s)) != 0:
+        raise ValueError("unsupported parameter set")
+    return s
+
+
+def make_params(nu1, nu2, t_gsw=8, t_conv=4, t_exp=8, t_exp_right=56, qprime_bits=20, p_db=256, direct_upload=0) -> Params:
+    return Params(nu1, nu2, t_gsw, t_conv, t_exp, t_exp_right, qprime_bits, direct_upload, p_db)
+
+
+# ---- L1/L2 ----
+def get_tables() -> np.ndarray:
+    out = u64(8, N)
+    lib().orc_get_tables(_p(out))
+    return out
+
+
+def ntt_forward(x: np.ndarray) -> np.ndarray:
+    y = np.ascontiguousarray(x, dtype=np.uint64).copy()
+    flat = y.reshape(-1, NTTP)
+    for k in range(flat.shape[0]):
+        lib().orc_ntt_forward(flat[k].ctypes.data_as(_u64p))
+    return y
+
+
+def ntt_inverse(x: np.ndarray) -> np.ndarray:
+    y = np.ascontiguousarray(x, dtype=np.uint64).copy()
+    flat = y.reshape(-1, NTTP)
+    for k in range(flat.shape[0]):
+        lib().orc_ntt_inverse(flat[k].ctypes.data_as(_u64p))
+    return y
+
+
+def to_ntt(raw: np.ndarray, reduce: bool = True) -> np.ndarray:
+    raw = np.ascontiguousarray(raw, dtype=np.uint64)
+    npolys = raw.size // N
+    out = u64(*raw.shape[:-1], 2, N)
+    (lib().orc_to_ntt if reduce else lib().orc_to_ntt_no_reduce)(_p(out), _p(raw), C.c_size_t(npolys))
+    return out
+
+
+def from_ntt(a: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    npolys = a.size // NTTP
+    out = u64(*a.shape[:-2], N)
+    lib().orc_from_ntt(_p(out), _p(a), C.c_size_t(npolys))
+    return out
+
+
+def multiply(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    rs, ms = a.shape[0], a.shape[1]
+    cs = b.shape[1]
+    assert b.shape[0] == ms
+    out = u64(rs, cs, 2, N)
+    lib().orc_multiply(_p(out), _p(np.ascontiguousarray(a)), _p(np.ascontiguousarray(b)), C.c_size_t(rs), C.c_size_t(ms), C.c_size_t(cs))
+    return out
+
+
+def add(a, b):
+    out = np.zeros_like(a)
+    lib().orc_add(_p(out), _p(np.ascontiguousarray(a)), _p(np.ascontiguousarray(b)), C.c_size_t(a.size // NTTP))
+    return out
+
+
+def mul_by_const(single, a):
+    out = np.zeros_like(a)
+    lib().orc_mul_by_const(_p(out), _p(np.ascontiguousarray(single)), _p(np.ascontiguousarray(a)), C.c_size_t(a.size // NTTP))
+    return out
+
+
+def automorph(raw, t):
+    raw = np.ascontiguousarray(raw, dtype=np.uint64)
+    out = np.zeros_like(raw)
+    lib().orc_automorph(_p(out), _p(raw), C.c_size_t(raw.size // N), C.c_uint64(t))
+    return out
+
+
+def invert(raw):
+    raw = np.ascontiguousarray(raw, dtype=np.uint64)
+    out = np.zeros_like(raw)
+    lib().orc_invert(_p(out), _p(raw), C.c_size_t(raw.size // N))
+    return out
+
+
+def gadget_invert(raw, mx, rdim):
+    """raw: [rdim][cols][N] -> [mx][cols][N]"""
+    raw = np.ascontiguousarray(raw, dtype=np.uint64)
+    cols = raw.shape[1]
+    out = u64(mx, cols, N)
+    lib().orc_gadget_invert(_p(out), _p(raw), C.c_size_t(mx), C.c_size_t(rdim), C.c_size_t(cols))
+    return out
+
+
+def build_gadget(rows, cols):
+    out = u64(rows, cols, N)
+    lib().orc_build_gadget(_p(out), C.c_size_t(rows), C.c_size_t(cols))
+    return out
+
+
+def rescale(a, inp_mod, out_mod):
+    return lib().orc_rescale(int(a), int(inp_mod), int(out_mod))
+
+
+# ---- L5 ----
+def split_and_crt(raw_cts, t_gsw):
+    raw_cts = np.ascontiguousarray(raw_cts, dtype=np.uint64)
+    num_per = raw_cts.shape[0]
+    out = u64(num_per, 3 * t_gsw, 2, 2, N)
+    lib().orc_split_and_crt(_p(out), _p(raw_cts), C.c_size_t(num_per), C.c_uint32(t_gsw))
+    return out
+
+
+def reorient_ciphertexts(cts):
+    cts = np.ascontiguousarray(cts, dtype=np.uint64)
+    dim0 = cts.shape[0]
+    out = u64(N, dim0, 2, 4)
+    lib().orc_reorient_ciphertexts(_p(out), _p(cts), C.c_size_t(dim0))
+    return out
+
+
+def multiply_query_by_database(reoriented, db, dim0, num_per):
+    out = u64(num_per, 3, 2, 2, N)
+    lib().orc_multiply_query_by_database(_p(out), _p(reoriented), _p(db), C.c_size_t(dim0), C.c_size_t(num_per))
+    return out
+
+
+def expand_improved(cv, g, t_exp, w_left, t_exp_right, w_right, n_right, max_bits_right, stopround):
+    cv = np.ascontiguousarray(cv, dtype=np.uint64).copy()
+    lib().orc_expand_improved(_p(cv), C.c_uint32(g), C.c_uint32(t_exp), _p(w_left), C.c_uint32(t_exp_right), _p(w_right),
+                              C.c_uint32(n_right), C.c_uint32(max_bits_right), C.c_uint32(stopround))
+    return cv
+
+
+def scal_to_mat(cv, w, t_conv):
+    out = u64(3, 2, 2, N)
+    lib().orc_scal_to_mat(_p(out), _p(np.ascontiguousarray(cv)), _p(np.ascontiguousarray(w)), C.c_uint32(t_conv))
+    return out
+
+
+def regev_to_gsw(cv_v, w, v, t_conv, ell):
+    out = u64(3, 3 * ell, 2, N)
+    lib().orc_regev_to_gsw(_p(out), _p(np.ascontiguousarray(cv_v)), _p(np.ascontiguousarray(w)), _p(np.ascontiguousarray(v)),
+                           C.c_uint32(t_conv), C.c_uint32(ell))
+    return out
+
+
+# ---- stages ----
+def stage_expand(p, query, w_left, w_right):
+    s = shape_of(p)
+    out = u64(s.n_bits, 2, 2, N)
+    rc = lib().orc_stage_expand(C.byref(p), _p(query), _p(w_left), _p(w_right), _p(out))
+    assert rc == 0
+    return out
+
+
+def stage_convert(p, cv, w, v):
+    s = shape_of(p)
+    cts = u64(s.dim0, 3, 2, 2, N)
+    gsw = u64(max(p.nu2, 1), 3, s.m2, 2, N)
+    rc = lib().orc_stage_convert(C.byref(p), _p(cv), _p(w), _p(v), _p(cts), _p(gsw))
+    assert rc == 0
+    return cts, gsw[: p.nu2]
+
+
+def stage_first_dim(p, cts, db):
+    s = shape_of(p)
+    out = u64(s.num_per, 3, 2, N)
+    rc = lib().orc_stage_first_dim(C.byref(p), _p(cts), _p(db), _p(out))
+    assert rc == 0
+    return out
+
+
+def stage_fold(p, raw_cts, gsw):
+    raw = np.ascontiguousarray(raw_cts, dtype=np.uint64).copy()
+    out = u64(3, 2, N)
+    gsw = np.ascontiguousarray(gsw) if gsw.size else u64(1)
+    rc = lib().orc_stage_fold(C.byref(p), _p(raw), _p(gsw), _p(out))
+    assert rc == 0
+    return out
+
+
+def stage_rescale(p, final_ct):
+    out = u64(3, 2, N)
+    rc = lib().orc_stage_rescale(C.byref(p), _p(np.ascontiguousarray(final_ct)), _p(out))
+    assert rc == 0
+    return out
+
+
+def answer(p, query, w_left, w_right, w, v, db):
+    out = u64(3, 2, N)
+    rc = lib().orc_answer(C.byref(p), _p(query), _p(w_left), _p(w_right), _p(w), _p(v), _p(db), _p(out))
+    assert rc == 0
+    return out
+
+
+# ---- DB ----
+def db_words(p):
+    s = shape_of(p)
+    return s.dim0 * s.num_per * 4 * N
+
+
+def gen_db(p, seed):
+    db = u64(db_words(p))
+    lib().orc_gen_db(C.byref(p), C.c_uint64(seed), _p(db))
+    return db
+
+
+def db_item(p, seed, item):
+    out = u64(2, 2, N)
+    lib().orc_db_item(C.byref(p), C.c_uint64(seed), C.c_uint64(item), _p(out))
+    return out
+
+
+def fill_db_random(seed, nwords):
+    db = u64(nwords)
+    lib().orc_fill_db_random(C.c_uint64(seed), _p(db), C.c_size_t(nwords))
+    return db
+
+
+# ---- client ----
+class Client:
+    def __init__(self, p: Params, seed: int = 1, nonoise: bool = False):
+        self.p = p
+        self.h = lib().orc_client_new(C.byref(p), C.c_uint64(seed), C.c_int(1 if nonoise else 0))
+        if not self.h:
+            raise ValueError("unsupported parameter set")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_client_free(C.c_void_p(self.h))
+            self.h = None
+
+    def pub_params(self):
+        L = lib()
+        p = self.p
+        wl = u64(max(L.orc_words_w_left(C.byref(p)), 1))
+        wr = u64(max(L.orc_words_w_right(C.byref(p)), 1))
+        w = u64(L.orc_words_w(C.byref(p)))
+        v = u64(L.orc_words_v(C.byref(p)))
+        L.orc_client_pub_params(C.c_void_p(self.h), _p(wl), _p(wr), _p(w), _p(v))
+        return wl, wr, w, v
+
+    def query(self, idx):
+        q = u64(lib().orc_words_query(C.byref(self.p)))
+        lib().orc_client_query(C.c_void_p(self.h), C.c_uint64(idx), _p(q))
+        return q
+
+    def decode(self, resp):
+        out = u64(2, 2, N)
+        lib().orc_client_decode(C.c_void_p(self.h), _p(np.ascontiguousarray(resp)), _p(out))
+        return out

@@ -1,0 +1,180 @@
+"""CPU tests of the parity oracle itself: the reference's own self-checks restated
+(do_MatPol_test src/spiral.cpp:1181, "Is correct?" src/spiral.cpp:1412-1494) plus algebraic
+properties that pin each restated function independently of the others."""
+import numpy as np
+import pytest
+
+N = 2048
+
+
+def br(i):
+    return int(format(i, "011b")[::-1], 2)
+
+
+def test_ntt_is_the_negacyclic_evaluation_map(oracle):
+    """forward output slot k (bit-reversed order) = a(psi^(2*bitrev(k)+1)) for the minimal 4096-th roots"""
+    O = oracle
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, O.Q, size=N, dtype=np.uint64)
+    f = O.to_ntt(a)
+    for n, (m, psi) in enumerate(((O.P, 66687), (O.B, 158221))):
+        am = [int(x) % m for x in a]
+        for k in [0, 1, 2, 1023, 1024, 2047]:
+            e = pow(psi, 2 * br(k) + 1, m)
+            s, x = 0, 1
+            for j in range(N):
+                s = (s + am[j] * x) % m
+                x = x * e % m
+            assert s == int(f[n, k])
+
+
+def test_matpoly_roundtrip(oracle):
+    """do_MatPol_test: from_ntt(to_ntt(A)) == A for a random 3x6 matrix mod Q"""
+    O = oracle
+    rng = np.random.default_rng(2)
+    A = rng.integers(0, O.Q, size=(3, 6, N), dtype=np.uint64)
+    assert (O.from_ntt(O.to_ntt(A)) == A).all()
+    # edge values: 0, 1, Q-1, Q (a lazy "Q" must come back as 0)
+    e = np.zeros(N, dtype=np.uint64)
+    e[0], e[1], e[2], e[3] = 0, 1, O.Q - 1, O.Q
+    back = O.from_ntt(O.to_ntt(e))
+    assert list(back[:4]) == [0, 1, O.Q - 1, 0]
+
+
+def test_multiply_is_negacyclic_convolution(oracle):
+    O = oracle
+    rng = np.random.default_rng(3)
+    a = np.zeros(N, dtype=np.uint64)
+    b = np.zeros(N, dtype=np.uint64)
+    ia = rng.choice(N, 5, replace=False)
+    ib = rng.choice(N, 5, replace=False)
+    a[ia] = rng.integers(0, O.Q, 5, dtype=np.uint64)
+    b[ib] = rng.integers(0, O.Q, 5, dtype=np.uint64)
+    got = O.from_ntt(O.multiply(O.to_ntt(a).reshape(1, 1, 2, N), O.to_ntt(b).reshape(1, 1, 2, N)))[0, 0]
+    exp = [0] * N
+    for i in ia:
+        for j in ib:
+            pr = int(a[i]) * int(b[j]) % O.Q
+            k = int(i + j)
+            if k < N:
+                exp[k] = (exp[k] + pr) % O.Q
+            else:
+                exp[k - N] = (exp[k - N] - pr) % O.Q
+    assert [int(x) for x in got] == exp
+
+
+def test_automorph_and_invert_edge_semantics(oracle):
+    O = oracle
+    a = np.arange(N, dtype=np.uint64) + 5
+    a[7] = 0
+    t = N // 4 + 1
+    out = O.automorph(a, t)
+    for i in [0, 1, 7, 100, 2047]:
+        pos, wraps = (i * t) % N, (i * t) // N
+        assert int(out[pos]) == (O.Q - int(a[i]) if wraps & 1 else int(a[i]))
+    assert int(O.invert(np.zeros(N, dtype=np.uint64))[0]) == O.Q  # 0 -> Q, poly.cpp:279
+
+
+def test_gadget_invert_recomposes(oracle):
+    O = oracle
+    rng = np.random.default_rng(4)
+    for t in (2, 4, 5, 8, 10, 16, 56):
+        bits = O.lib().orc_get_bits_per(t)
+        assert bits == (1 if t == 56 else 56 // t + 1)
+        v = rng.integers(0, O.Q, size=(1, 1, N), dtype=np.uint64)
+        v[0, 0, 0] = O.Q  # the Q - 0 case
+        d = O.gadget_invert(v, t, 1)
+        assert d.max() < (1 << bits)
+        rec = sum(d[k, 0].astype(object) << (bits * k) for k in range(t))
+        assert (rec == v[0, 0].astype(object)).all()
+
+
+def test_split_and_crt_is_a_signed_decomposition(oracle):
+    O = oracle
+    rng = np.random.default_rng(5)
+    for t in (4, 5, 8, 10):
+        bits = O.lib().orc_get_bits_per(t)
+        raw = rng.integers(0, O.Q, size=(2, 3, 2, N), dtype=np.uint64)
+        raw[0, 0, 0, :4] = [0, 1, O.Q - 1, (1 << (bits - 1))]
+        dig = O.from_ntt(O.split_and_crt(raw, t))  # [2][3t][2][N] digits mod Q
+        for r in range(3):
+            rec = np.zeros((2, 2, N), dtype=object)
+            for k in range(t):
+                rec = (rec + (dig[:, r + 3 * k].astype(object) << (bits * k))) % O.Q
+            assert (rec == raw[:, r].astype(object) % O.Q).all()
+        cent = np.where(dig.astype(object) > O.Q // 2, dig.astype(object) - O.Q, dig.astype(object))
+        assert abs(cent).max() <= (1 << bits)
+
+
+def test_rescale_edges(oracle):
+    O = oracle
+    qp, q1 = 786433, 1024
+    for a in [0, 1, O.Q // 2 - 1, O.Q // 2, O.Q // 2 + 1, O.Q - 1, 12345678901234567]:
+        for out_mod in (qp, q1):
+            c = a - O.Q if a >= O.Q // 2 else a
+            num = c * out_mod
+            sign = 1 if c >= 0 else -1
+            val = num + sign * (O.Q // 2)
+            res = abs(val) // O.Q * (1 if val >= 0 else -1)  # C truncating division
+            assert O.rescale(a, O.Q, out_mod) == res % out_mod
+
+
+def test_sweep_matches_matrix_product(oracle):
+    """first-dimension sweep == sum_j ct_j * pt_{i,j} computed with multiply() on the unpacked operands"""
+    O = oracle
+    p = O.make_params(2, 1)
+    s = O.shape_of(p)
+    rng = np.random.default_rng(6)
+    cts = np.stack([rng.integers(0, m, size=(s.dim0, 3, 2, N), dtype=np.uint64) for m in (O.P, O.B)], axis=3)
+    db = O.gen_db(p, 99)
+    got = O.multiply_query_by_database(O.reorient_ciphertexts(cts), db, s.dim0, s.num_per)
+    dbv = db.reshape(N, s.num_per, 2, s.dim0, 2)  # z, ii, c, j, m
+    for ii in range(s.num_per):
+        acc = np.zeros((3, 2, 2, N), dtype=object)
+        for j in range(s.dim0):
+            pt = np.zeros((2, 2, 2, N), dtype=np.uint64)  # m, c, limb, z
+            w = dbv[:, ii, :, j, :]  # z, c, m
+            pt[:, :, 0, :] = (w & 0xFFFFFFFF).transpose(2, 1, 0)
+            pt[:, :, 1, :] = (w >> 32).transpose(2, 1, 0)
+            acc = acc + O.multiply(cts[j], pt).astype(object)
+        acc[:, :, 0] %= O.P
+        acc[:, :, 1] %= O.B
+        assert (acc == got[ii].astype(object)).all()
+
+
+@pytest.mark.parametrize(
+    "nu1,nu2,kw",
+    [
+        (2, 1, {}),  # stopround == 0 branch
+        (4, 2, dict(t_gsw=4)),  # stopround > 0 branch
+        (3, 3, dict(t_gsw=8)),
+        (2, 2, dict(t_gsw=5, t_exp=2, qprime_bits=19, direct_upload=1)),  # SpiralStream-style direct upload
+    ],
+)
+def test_end_to_end_is_correct(oracle, nu1, nu2, kw):
+    """the reference's only functional oracle: decode(answer(query(idx))) == DB[idx]"""
+    O = oracle
+    p = O.make_params(nu1, nu2, **kw)
+    s = O.shape_of(p)
+    db = O.gen_db(p, 1234)
+    c = O.Client(p, seed=11)
+    wl, wr, w, v = c.pub_params()
+    total = s.dim0 * s.num_per
+    for idx in {0, total - 1, 1234 % total}:
+        fin = O.answer(p, c.query(idx), wl, wr, w, v, db)
+        pt = c.decode(O.stage_rescale(p, fin))
+        assert (pt == O.db_item(p, 1234, idx)).all(), idx
+
+
+def test_staged_pipeline_equals_answer(oracle):
+    O = oracle
+    p = O.make_params(3, 2, t_gsw=4)
+    db = O.gen_db(p, 5)
+    c = O.Client(p, seed=3)
+    wl, wr, w, v = c.pub_params()
+    q = c.query(9)
+    cv = O.stage_expand(p, q, wl, wr)
+    cts, gsw = O.stage_convert(p, cv, w, v)
+    raw = O.stage_first_dim(p, cts, db)
+    fin = O.stage_fold(p, raw, gsw)
+    assert (fin == O.answer(p, q, wl, wr, w, v, db)).all()
