@@ -1,0 +1,195 @@
+/*
+ * spiral_gpu.h -- C ABI of libspiral_gpu.so: the MI355X (gfx950) implementation of the Spiral
+ * server-answer path.
+ *
+ * The reference (menonsamir/spiral) has no FFI or plugin interface: it is one C++ executable whose
+ * server hot path is a set of free functions over caller-owned uint64_t buffers.
+ * This header declares exactly those seams, so that a maintainer can replace the reference function
+ * bodies with calls into this library (INTEGRATION.md shows the stubs).  Each entry point cites the
+ * reference function it replaces.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns 0 on success and a negative code on error
+ *     (spiral_gpu_last_error() gives the message); the reference's error behaviour is assert/exit(1).
+ *   - buffers use the REFERENCE layouts:
+ *       NTT form : [rows][cols][2 limbs][2048] uint64_t residues (limb 0 mod p, limb 1 mod b), NTT slots
+ *                  in the order produced by the reference's ntt_forward          (include/poly.h:24-64)
+ *       raw form : [rows][cols][2048] uint64_t in [0, Q]
+ *     any re-layout (packed u32 limb pairs, lane-major database) is internal to the library.
+ *   - "host" entry points take host pointers and copy; the *_server_* stage entry points keep all
+ *     state resident in HBM and are asynchronous on the server's HIP stream.
+ *   - there is no CPU fallback: without a usable gfx950 device every compute entry point fails.
+ */
+#ifndef SPIRAL_GPU_H
+#define SPIRAL_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPIRAL_GPU_ABI_VERSION 1
+
+/* Scheme parameters = the reference's compile-time -D values (include/values.h:78-93,
+ * select_params.py:337) plus argv[1], argv[2] (src/spiral.cpp:1243-1244). */
+typedef struct spiral_gpu_params {
+    uint32_t nu1;           /* num_expansions: first dimension is 2^nu1                          */
+    uint32_t nu2;           /* further_dims:   2^nu2 plaintexts per first-dimension index        */
+    uint32_t t_gsw;         /* TGSW   */
+    uint32_t t_conv;        /* TCONV  */
+    uint32_t t_exp;         /* TEXP   */
+    uint32_t t_exp_right;   /* TEXPRIGHT */
+    uint32_t qprime_bits;   /* QPBITS */
+    uint32_t direct_upload; /* 0: QNUMFIRST=1, QNUMREST=0;  1: QNUMFIRST=2^nu1, QNUMREST=t_gsw*nu2 */
+    uint64_t p_db;          /* PVALUE */
+} spiral_gpu_params;
+
+/* sizes derived from the parameters (src/spiral.cpp:2046-2085) */
+typedef struct spiral_gpu_shape {
+    uint32_t dim0, num_per, ell, m2, g, stopround;
+    uint32_t n_left;      /* W_exp_left matrices  (n0 x t_exp each)       */
+    uint32_t n_right;     /* W_exp_right matrices (n0 x t_exp_right each) */
+    uint32_t n_query_cts; /* Regev ciphertexts (n0 x 1) in the query       */
+    uint32_t n_bits;      /* dim0 + ell*nu2 expanded ciphertexts           */
+    uint64_t qprime;
+} spiral_gpu_shape;
+
+typedef struct spiral_gpu_server spiral_gpu_server;
+
+int spiral_gpu_abi_version(void);
+const char *spiral_gpu_last_error(void);
+int spiral_gpu_device_count(void);
+int spiral_gpu_get_shape(const spiral_gpu_params *p, spiral_gpu_shape *out);
+
+/* ------------------------------------------------------------------------------------------------
+ * L1/L2 seams: NTT core and polynomial algebra (host buffers)
+ * ------------------------------------------------------------------------------------------------ */
+/* the 8 x 2048 twiddle rows in the order of `tables[]`, src/constants.cpp:16 (host only, no GPU) */
+int spiral_gpu_get_tables(uint64_t *out);
+/* void ntt_forward(uint64_t*) / ntt_inverse(uint64_t*), src/core.cpp:247,419; batched over npolys */
+int spiral_gpu_ntt_forward(uint64_t *operand, size_t npolys);
+int spiral_gpu_ntt_inverse(uint64_t *operand, size_t npolys);
+/* to_ntt / to_ntt_no_reduce, src/poly.cpp:311,291 : raw [npolys][N] -> NTT [npolys][2][N] */
+int spiral_gpu_to_ntt(uint64_t *out, const uint64_t *in, size_t npolys, int reduce);
+/* from_ntt, src/poly.cpp:357 : NTT -> raw in [0, Q) */
+int spiral_gpu_from_ntt(uint64_t *out, const uint64_t *in, size_t npolys);
+/* multiply, src/poly.cpp:34 : out(rs x cs) = a(rs x ms) * b(ms x cs), NTT form */
+int spiral_gpu_multiply(uint64_t *out, const uint64_t *a, const uint64_t *b, size_t rs, size_t ms, size_t cs);
+/* add, mul_by_const, src/poly.cpp:138,190 */
+int spiral_gpu_add(uint64_t *out, const uint64_t *a, const uint64_t *b, size_t npolys);
+int spiral_gpu_mul_by_const(uint64_t *out, const uint64_t *single_poly, const uint64_t *a, size_t npolys);
+/* automorph, invert, src/poly.cpp:240,269 (raw form; negation is Q - a) */
+int spiral_gpu_automorph(uint64_t *out, const uint64_t *in, size_t npolys, uint64_t t);
+int spiral_gpu_invert(uint64_t *out, const uint64_t *in, size_t npolys);
+/* gadget_invert, src/util.cpp:114 : raw [rdim][cols][N] -> raw [mx][cols][N] */
+int spiral_gpu_gadget_invert(uint64_t *out, const uint64_t *in, size_t mx, size_t rdim, size_t cols);
+/* getRescaled, src/poly.cpp:593 : element-wise rescale(a % Q, inp_mod, out_mod) */
+int spiral_gpu_get_rescaled(uint64_t *out, const uint64_t *in, size_t n, uint64_t inp_mod, uint64_t out_mod);
+
+/* ------------------------------------------------------------------------------------------------
+ * L5 seams: the server hot-path functions (host buffers, reference layouts)
+ * ------------------------------------------------------------------------------------------------ */
+/* multiplyQueryByDatabase, src/spiral.cpp:628.  reorientedCts: (z, j, m, r_pad4) packed words
+ * (reorientCiphertexts, :410); database: load_db's layout (:1139-1153); output: NTT form
+ * [num_per][n1][n2][2][N]. */
+int spiral_gpu_multiply_query_by_database(uint64_t *output, const uint64_t *reorientedCiphertexts,
+                                          const uint64_t *database, size_t dim0, size_t num_per);
+/* split_and_crt, src/spiral.cpp:270 : raw [num_per][n1][n2][N] -> NTT [num_per][m2][n2][2][N] */
+int spiral_gpu_split_and_crt(uint64_t *out, const uint64_t *in, size_t num_per, uint32_t t_gsw);
+/* foldOneFurtherDimension, src/spiral.cpp:1349.  cts: raw [2*num_per][n1][n2][N], the first num_per
+ * are overwritten; query_ct / query_ct_neg: ONE dimension's reoriented (z, r, m) packed GSW matrices
+ * (reorient_Q, :388). */
+int spiral_gpu_fold_one_further_dimension(uint64_t *cts, size_t num_per, const uint64_t *query_ct,
+                                          const uint64_t *query_ct_neg, uint32_t t_gsw);
+/* expandImproved, src/spiral.cpp:1664.  cv_v: 2^g ciphertexts (n0 x 1, NTT form), element 0 is the
+ * query, updated in place; W_left: g matrices n0 x t_exp; W_right: n_right matrices n0 x t_exp_right. */
+int spiral_gpu_expand_improved(uint64_t *cv_v, uint32_t g, uint32_t t_exp, const uint64_t *w_left,
+                               uint32_t t_exp_right, const uint64_t *w_right, uint32_t n_right,
+                               uint32_t max_bits_to_gen_right, uint32_t stopround);
+/* scalToMat, src/spiral.cpp:1918 : out n1 x n0 from cv n0 x 1 and W n1 x (n0*t_conv) */
+int spiral_gpu_scal_to_mat(uint64_t *out, const uint64_t *cv, const uint64_t *w, uint32_t t_conv);
+/* regevToGSW, src/spiral.cpp:1985 : out n1 x (n1*ell) from ell ciphertexts, W and V */
+int spiral_gpu_regev_to_gsw(uint64_t *out, const uint64_t *cv_v, const uint64_t *w, const uint64_t *v,
+                            uint32_t t_conv, uint32_t ell);
+
+/* ------------------------------------------------------------------------------------------------
+ * Resident server: do_test's server half (src/spiral.cpp:2337-2406, 1584-1629) with the database,
+ * public parameters and all intermediates in HBM.
+ * ------------------------------------------------------------------------------------------------ */
+/* The server holds first-dimension indices j in [j_begin, j_end) of the database (the whole range
+ * for a single GPU).  Shards are summed by the caller between first_dim and lift (see
+ * spiral_gpu_server_acc). */
+int spiral_gpu_server_create(const spiral_gpu_params *p, int device, uint32_t j_begin, uint32_t j_end,
+                             spiral_gpu_server **out);
+void spiral_gpu_server_destroy(spiral_gpu_server *s);
+/* use an external HIP stream (hipStream_t as void*); NULL = the server's own stream */
+int spiral_gpu_server_set_stream(spiral_gpu_server *s, void *hip_stream);
+
+/* database producers: load_db, src/spiral.cpp:1028-1172 */
+int spiral_gpu_server_load_db(spiral_gpu_server *s, const uint64_t *database /* full, reference layout */);
+/* explicit DB generated on the device: plaintext coefficient k of item i is
+ * splitmix64(seed ^ (i*4N + k)) % p_db (the rand() % p_db of :25-29 with a counter-based generator) */
+int spiral_gpu_server_gen_db(spiral_gpu_server *s, uint64_t seed);
+/* --random-data analogue: arbitrary valid NTT-form words, timing only */
+int spiral_gpu_server_fill_db_random(spiral_gpu_server *s, uint64_t seed);
+
+/* public parameters (NTT form): W_exp_left g x (n0 x t_exp), W_exp_right n_right x (n0 x t_exp_right),
+ * W n1 x (n0*t_conv), V n1 x (2*t_conv)   (src/spiral.cpp:2091-2092, 2216-2227, 2279-2296) */
+int spiral_gpu_server_set_pub_params(spiral_gpu_server *s, const uint64_t *w_left, const uint64_t *w_right,
+                                     const uint64_t *w, const uint64_t *v);
+/* query: n_query_cts Regev ciphertexts, n0 x 1 NTT form */
+int spiral_gpu_server_set_query(spiral_gpu_server *s, const uint64_t *query);
+
+/* stages, asynchronous on the server stream */
+int spiral_gpu_server_expand(spiral_gpu_server *s);    /* expandImproved + reorderFromStopround      */
+int spiral_gpu_server_convert(spiral_gpu_server *s);   /* scalToMat x dim0, regevToGSW x nu2, Q_neg   */
+int spiral_gpu_server_first_dim(spiral_gpu_server *s); /* multiplyQueryByDatabase on this shard       */
+int spiral_gpu_server_lift(spiral_gpu_server *s, int reduce_first); /* nttInvAndCrtLiftCiphertexts     */
+int spiral_gpu_server_fold(spiral_gpu_server *s);      /* foldOneFurtherDimension x nu2               */
+int spiral_gpu_server_finish(spiral_gpu_server *s);    /* response modulus switch, :1441-1447         */
+int spiral_gpu_server_sync(spiral_gpu_server *s);
+/* per-shard first-dimension accumulators: num_per*n1*n2*2048 packed words (p-limb | b-limb << 32, each
+ * field < 2^28).  Summing the shards' buffers as uint64 (one RCCL reduce) and calling lift with
+ * reduce_first = 1 gives the unsharded result.  Returns a device pointer. */
+void *spiral_gpu_server_acc(spiral_gpu_server *s, size_t *bytes);
+/* make the sweep write into caller-owned device memory (e.g. a torch tensor) */
+int spiral_gpu_server_set_acc(spiral_gpu_server *s, void *device_ptr);
+
+/* whole path for one query: set_query, expand, convert, first_dim, lift, fold, finish, sync.
+ * final_ct: raw n1 x n2 (may be NULL); response: rescaled n1 x n2 (may be NULL).
+ * stage_us (may be NULL): [0] expansion [1] conversion [2] first-dimension multiply (sweep + lift)
+ * [3] folding [4] response switch [5] sweep kernel alone [6] total device time [7] reserved,
+ * the reference's buckets of src/spiral.cpp:246-257, measured with HIP events on the server stream. */
+int spiral_gpu_server_answer(spiral_gpu_server *s, const uint64_t *query, uint64_t *final_ct,
+                             uint64_t *response, double stage_us[8]);
+/* the same without touching host memory: the query must have been set; results stay on the device */
+int spiral_gpu_server_answer_resident(spiral_gpu_server *s, double stage_us[8]);
+
+/* read back intermediates in reference layouts (stage parity tests) */
+enum spiral_gpu_buffer {
+    SPIRAL_GPU_BUF_EXPANDED = 0, /* n_bits cts n0 x 1 NTT, in the order scalToMat/regevToGSW consume them */
+    SPIRAL_GPU_BUF_CTS = 1,      /* (j_end-j_begin) cts n1 x n0 NTT = expansionLocals.cts (needs keep_cts)  */
+    SPIRAL_GPU_BUF_GSW = 2,      /* nu2 matrices n1 x m2 NTT, reference's reversed order (:2324)           */
+    SPIRAL_GPU_BUF_ACC = 3,      /* num_per cts n1 x n2 NTT: the sweep output                              */
+    SPIRAL_GPU_BUF_RAW = 4,      /* num_per cts n1 x n2 raw: after lift / after folding rounds             */
+    SPIRAL_GPU_BUF_FINAL = 5,    /* n1 x n2 raw                                                            */
+    SPIRAL_GPU_BUF_RESPONSE = 6  /* n1 x n2 rescaled                                                       */
+};
+int spiral_gpu_server_keep_cts(spiral_gpu_server *s, int on);
+size_t spiral_gpu_server_buffer_words(spiral_gpu_server *s, int which);
+int spiral_gpu_server_read(spiral_gpu_server *s, int which, uint64_t *out);
+/* overwrite the lifted ciphertexts (raw [num_per][n1][n2][N]) -- lets a test drive fold() alone */
+int spiral_gpu_server_write_raw(spiral_gpu_server *s, const uint64_t *raw_cts);
+
+/* measurement helper: average duration (ms) of the sweep kernel alone over `iters` launches, timed
+ * with HIP events on the server stream */
+int spiral_gpu_server_time_sweep(spiral_gpu_server *s, int iters, float *avg_ms);
+/* algorithmic bytes of one sweep on this shard: DB + query records + accumulators */
+uint64_t spiral_gpu_server_sweep_bytes(spiral_gpu_server *s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

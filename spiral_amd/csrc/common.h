@@ -1,0 +1,45 @@
+// Shared constants and device arithmetic for the Spiral server-answer kernels (gfx950).
+//
+// Internal data formats (device side):
+//   PK  "packed NTT form": one u64 per NTT slot, low 32 bits = residue mod p, high 32 bits = residue
+//       mod b (the reference packs the same way for its hot loops, src/spiral.cpp:345-433).  A
+//       polynomial is 2048 u64 = 16 KiB.  Slot order is the reference's (bit-reversed) order.
+//   RAW one u64 per coefficient, value in [0, Q] (reference raw form, include/poly.h:24-64).
+// Residues are < 2^28, so every product fits u64 (< 2^56) and lazy butterflies fit u32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace spiral {
+
+constexpr uint32_t kN = 2048;
+constexpr uint32_t kLogN = 11;
+constexpr uint32_t kP = 268369921u;  // include/values.h:13
+constexpr uint32_t kB = 249561089u;  // include/values.h:21
+constexpr uint64_t kQ = (uint64_t)kP * kB;
+constexpr uint32_t kPinvB = 97389680u;  // p^-1 mod b, include/values.h:24
+constexpr uint32_t kN0 = 2, kN1 = 3, kN2 = 2;
+
+__device__ __forceinline__ uint32_t lo32(uint64_t x) { return (uint32_t)x; }
+__device__ __forceinline__ uint32_t hi32(uint64_t x) { return (uint32_t)(x >> 32); }
+__device__ __forceinline__ uint64_t pack(uint32_t lo, uint32_t hi) { return (uint64_t)lo | ((uint64_t)hi << 32); }
+
+// exact reductions of a u64 (include/poly.h:137-153 computes the same function with Barrett)
+__device__ __forceinline__ uint32_t mod_p(uint64_t x) { return (uint32_t)(x % kP); }
+__device__ __forceinline__ uint32_t mod_b(uint64_t x) { return (uint32_t)(x % kB); }
+// reduce a u32 known to be < 4m / < 2m
+__device__ __forceinline__ uint32_t csub(uint32_t x, uint32_t m) { return x >= m ? x - m : x; }
+
+// CRT lift of (x mod p, y mod b) to the canonical value in [0, Q): Garner form of
+// src/poly.cpp:344-353 (same unique result, no 128-bit arithmetic)
+__device__ __forceinline__ uint64_t crt_compose(uint32_t x, uint32_t y) {
+    uint32_t xb = csub(x, kB);                       // x < p < 2b
+    uint32_t d = y >= xb ? y - xb : y + kB - xb;     // (y - x) mod b
+    uint32_t k = mod_b((uint64_t)d * kPinvB);
+    return (uint64_t)x + (uint64_t)kP * k;
+}
+
+// include/util.h:34-38
+__host__ __device__ inline uint32_t get_bits_per(uint32_t dim) { return dim == 56 ? 1u : 56u / dim + 1u; }
+
+}  // namespace spiral

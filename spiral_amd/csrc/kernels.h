@@ -1,0 +1,141 @@
+// Host-callable launchers for the HIP kernels (internal interface between server.cpp and *.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace spiral {
+
+// block/poly index map: idx(b) = (b / inner) * outer_stride + (b % inner) + off
+struct IndexMap {
+    uint32_t inner, outer_stride, off;
+    __host__ __device__ uint32_t operator()(uint32_t b) const { return (b / inner) * outer_stride + (b % inner) + off; }
+};
+inline IndexMap identity_map() { return IndexMap{1u, 1u, 0u}; }
+
+struct DeviceTables {
+    uint4* fwd = nullptr;      // [2048] forward twiddles {W_p, W'_p, W_b, W'_b}
+    uint4* inv = nullptr;      // [2048] inverse twiddles (1/2 folded in)
+    uint64_t* neg1 = nullptr;  // [11][2048] PK: NTT(-x^(N-2^r))   (src/spiral.cpp:171-190)
+};
+// builds the tables on `device` (host computes psi powers, tables.cpp); idempotent per device
+int tables_get(int device, DeviceTables* out);
+// host copy of the reference-ordered rows (for the C-ABI's spiral_gpu_get_tables)
+void tables_host_rows(uint64_t* out8x2048);
+
+// ---- forward NTT ---------------------------------------------------------------------------------
+enum FwdLoad : uint32_t {
+    LD_RAW = 0,     // raw u64 coefficient, reduced mod p / mod b        (to_ntt, src/poly.cpp:311)
+    LD_DIGIT = 1,   // unsigned gadget digit k of a raw coefficient      (gadget_invert + to_ntt_no_reduce)
+    LD_SDIGIT = 2,  // balanced digit with the fold's carry rules        (split_and_crt, src/spiral.cpp:270)
+    LD_LIMBS = 3,   // reference NTT layout [2][N] u64 taken as per-limb coefficient arrays (ntt_forward)
+    LD_DBGEN = 4,   // seeded plaintext coefficient, centred lift        (load_db, src/spiral.cpp:1116-1127)
+};
+enum FwdStore : uint32_t {
+    ST_PK = 0,      // packed slot words
+    ST_REF = 1,     // reference layout [2][N] u64
+    ST_DB = 2,      // scatter into the device DB layout (see sweep)
+};
+struct FwdParams {
+    const uint64_t* src;
+    uint64_t* dst;
+    IndexMap src_map;   // s -> source polynomial index
+    IndexMap dst_map;   // b -> destination polynomial index (ST_PK / ST_REF)
+    uint32_t n_digits;  // b -> (s = b / n_digits, k = b % n_digits)
+    uint32_t bits;      // digit width
+    uint32_t ell;       // LD_SDIGIT: digits per value (t_GSW)
+    uint32_t tinv;      // automorphism gather x -> x^t folded into the load: t^-1 mod 2N, 0 = none
+    uint32_t fold_np;   // LD_SDIGIT: num_per' (destination is the fold operand layout)
+    // LD_DBGEN / ST_DB
+    uint64_t seed, p_db;
+    uint64_t item_base;                 // first item handled by this launch
+    uint32_t num_per, dim0_shard, j0;   // DB geometry of this shard
+};
+void launch_ntt_forward(const DeviceTables& t, const FwdParams& p, uint32_t load, uint32_t store, uint32_t nblocks, hipStream_t s);
+
+// ---- inverse NTT ---------------------------------------------------------------------------------
+enum InvStore : uint32_t {
+    IST_CRT = 0,    // CRT-lifted raw coefficient in [0, Q)   (from_ntt, src/poly.cpp:357)
+    IST_LIMBS = 1,  // reference layout [2][N] u64 residues   (ntt_inverse)
+};
+struct InvParams {
+    const uint64_t* src;
+    uint64_t* dst;
+    IndexMap src_map, dst_map;
+    uint32_t pre_reduce;  // 1: fields are lazy sums (< 2^32), reduce mod m first
+    uint32_t src_ref;     // 1: source is reference layout [2][N] u64 instead of PK
+};
+void launch_ntt_inverse(const DeviceTables& t, const InvParams& p, uint32_t store, uint32_t nblocks, hipStream_t s);
+
+// ---- layout conversion at the C-ABI boundary -------------------------------------------------------
+// reference polynomial b <-> packed polynomial pk_map(b)
+void launch_ref_to_pk(const uint64_t* ref, uint64_t* pk, uint32_t npolys, IndexMap pk_map, hipStream_t s);
+void launch_pk_to_ref(const uint64_t* pk, uint64_t* ref, uint32_t npolys, IndexMap pk_map, hipStream_t s);
+
+// ---- pointwise polynomial kernels (poly.hip) -------------------------------------------------------
+// out[b][r][c] = sum_m A[r][m] * B[b][m][c]  (+ addend), all PK; generic MatPoly multiply (src/poly.cpp:34)
+struct MatmulParams {
+    const uint64_t* a;  // [rs][ms] polys, stride a_batch polys between batches (0 = shared)
+    const uint64_t* b;  // [ms][cs] polys
+    uint64_t* out;      // [rs][cs] polys
+    uint32_t rs, ms, cs;
+    uint32_t a_batch, b_batch, out_batch;  // strides in polynomials
+};
+void launch_matmul(const MatmulParams& p, uint32_t batch, hipStream_t s);
+// out = (a + b) mod m ; out = single * a (src/poly.cpp:138,190)
+void launch_add(const uint64_t* a, const uint64_t* b, uint64_t* out, uint32_t npolys, hipStream_t s);
+void launch_mul_by_const(const uint64_t* single, const uint64_t* a, uint64_t* out, uint32_t npolys, hipStream_t s);
+// raw-domain automorphism / negation (src/poly.cpp:240,269)
+void launch_automorph(const uint64_t* in, uint64_t* out, uint32_t npolys, uint32_t t, hipStream_t s);
+void launch_invert(const uint64_t* in, uint64_t* out, uint32_t npolys, hipStream_t s);
+// unsigned gadget digits in the raw domain (src/util.cpp:114)
+void launch_gadget_invert(const uint64_t* in, uint64_t* out, uint32_t mx, uint32_t rdim, uint32_t cols, hipStream_t s);
+// response modulus switch (src/poly.cpp:578-601, src/spiral.cpp:1441-1447)
+void launch_rescale(const uint64_t* in, uint64_t* out, uint32_t n, uint64_t inp_mod, uint64_t out_mod, hipStream_t s);
+
+// ---- expansion / conversion / fold specials ----------------------------------------------------------
+// cv[dst0 + step*a] = neg1[r] * cv[src0 + step*a], both rows (src/spiral.cpp:1709)
+void launch_mul_neg1(uint64_t* cv, const uint64_t* neg1_r, uint32_t src0, uint32_t dst0, uint32_t step, uint32_t count, hipStream_t s);
+// cv[i][j] = cv[i][j] + sum_k W[j][k] * G[a][k] + j * A1[a],  i = i0 + step*a   (src/spiral.cpp:1722-1733)
+void launch_expand_mac(uint64_t* cv, const uint64_t* w, const uint64_t* g, const uint64_t* a1, uint32_t t_dim, uint32_t i0, uint32_t step,
+                       uint32_t count, hipStream_t s);
+// scalToMat product: out[a][r][c] = sum_k W[r][2k+c] * G[a][k] + pad(cv[pos(a)][1])   (src/spiral.cpp:1850-1885)
+// qs != null: also (or instead, out may be null) write the sweep's query records (see sweep)
+struct Scal2MatParams {
+    const uint64_t* w;    // [3][2*t_conv] PK
+    const uint64_t* g;    // [count][t_conv] PK digits of cv row 0
+    const uint64_t* cv;   // expanded cts
+    IndexMap cv_pos;      // a -> ct index in cv
+    uint64_t* out;        // [count][3][2] PK or null
+    uint32_t* qs;         // sweep query records [N][jm_total/2][12] u32 or null
+    uint32_t t_conv, count, jm_total, j_base;
+};
+void launch_scal2mat(const Scal2MatParams& p, hipStream_t s);
+// regevToGSW assembly for one dimension: gsw[r][3i] = sum_k V[r][k] * chat[i][k], gsw[r][3i+1+c] = scalToMat(cv_i)[r][c]
+struct GswParams {
+    const uint64_t* w;     // [3][2*t_conv]
+    const uint64_t* v;     // [3][2*t_conv]
+    const uint64_t* chat;  // [dims*ell][2*t_conv] PK digits (cv row 0 digits, then row 1 digits)
+    const uint64_t* cv;
+    IndexMap cv_pos;       // i (over dims*ell) -> ct index
+    uint64_t* gsw;         // [dims][3][3*ell] PK, dimension d stored at index (dims-1-d)  (src/spiral.cpp:2324)
+    uint32_t t_conv, ell, dims;
+};
+void launch_regev_to_gsw(const GswParams& p, hipStream_t s);
+// fold key: key[d][r][0..m2) = G2 - gsw (= Q_neg, src/spiral.cpp:2361-2379), key[d][r][m2..2*m2) = gsw
+void launch_fold_key(const uint64_t* gsw, uint64_t* key, uint32_t dims, uint32_t ell, hipStream_t s);
+// the same key from the reference's reoriented (z, r, m) packed matrices (reorient_Q, src/spiral.cpp:388)
+void launch_fold_key_from_reoriented(const uint64_t* q_re, const uint64_t* qneg_re, uint64_t* key, uint32_t m2, hipStream_t s);
+
+// ---- first-dimension sweep (sweep.hip) -----------------------------------------------------------------
+// device DB layout: word(z, jm, ic) at ((z * (JM/2) + jm/2) * nic + ic) * 2 + (jm & 1), jm = (j - j0)*2 + m,
+// ic = ii*2 + c, nic = 2*num_per.  acc[ii][r][c][z] PK (fields < m).
+void launch_sweep(const uint64_t* db, const uint32_t* qs, uint64_t* acc, uint32_t num_per, uint32_t jm_total, hipStream_t s);
+// reference DB layout (src/spiral.cpp:1139-1153) -> device layout, for the j-range [j0, j0 + dim0_shard) and
+// nz consecutive z slabs starting at the given pointers
+void launch_db_relayout(const uint64_t* db_ref, uint64_t* db_dev, uint32_t num_per, uint32_t dim0, uint32_t j0, uint32_t dim0_shard, uint32_t nz,
+                        hipStream_t s);
+// reference reorientCiphertexts layout (z, j, m, r_pad4) u64 -> sweep query records
+void launch_qs_from_reoriented(const uint64_t* reoriented, uint32_t* qs, uint32_t jm_total, hipStream_t s);
+void launch_fill_db_random(uint64_t* db_dev, uint64_t nwords, uint64_t seed, hipStream_t s);
+
+}  // namespace spiral

@@ -1,0 +1,173 @@
+// Negacyclic NTT / INTT over Z[x]/(x^2048+1) for the two 28-bit CRT primes, one 256-thread workgroup
+// per polynomial, both limbs processed side by side (PK format, see common.h).
+//
+// Replaces ntt_forward / ntt_inverse (reference src/core.cpp:247-514).  Same transform and slot
+// order (natural in -> bit-reversed out for the forward, the converse for the inverse) and the same
+// twiddle table (regenerated from psi, see tables.cpp), but organised for CDNA4: every thread keeps
+// 8 coefficients x 2 limbs in VGPRs and runs three radix-2 stages per pass with lazy u32 Harvey
+// butterflies; passes exchange data through a 16 KiB LDS tile (3 exchanges for 11 stages).
+// Outputs are canonical residues in [0, m).
+#pragma once
+#include "common.h"
+
+namespace spiral {
+
+struct Tables {
+    const uint4* fwd;  // [2048] {W_p, W'_p, W_b, W'_b} indexed like the reference's forward rows (m + i)
+    const uint4* inv;  // [2048] same for the inverse rows (h + i), 1/2 folded in
+};
+
+// ---- butterflies --------------------------------------------------------------------------------
+// forward (Cooley-Tukey, Harvey lazy): x, y in [0, 4m) -> [0, 4m)      (src/core.cpp:274-290)
+__device__ __forceinline__ void ct_bfly(uint32_t& x, uint32_t& y, uint32_t w, uint32_t ws, uint32_t m) {
+    const uint32_t m2 = 2 * m;
+    uint32_t cx = x >= m2 ? x - m2 : x;
+    uint32_t q = __umulhi(y, ws);
+    uint32_t t = w * y - q * m;  // [0, 2m)
+    x = cx + t;
+    y = cx + (m2 - t);
+}
+// inverse (Gentleman-Sande, 1/2 per stage): u, v in [0, 2m) -> [0, 2m)  (src/core.cpp:445-472)
+__device__ __forceinline__ void gs_bfly(uint32_t& u, uint32_t& v, uint32_t w, uint32_t ws, uint32_t m) {
+    const uint32_t m2 = 2 * m;
+    uint32_t t = m2 - v + u;
+    uint32_t s = u + v;
+    s = s >= m2 ? s - m2 : s;
+    u = (s + ((t & 1u) ? m : 0u)) >> 1;
+    uint32_t q = __umulhi(t, ws);
+    v = w * t - q * m;
+}
+
+__device__ __forceinline__ void ct2(uint32_t* lo, uint32_t* hi, int a, int b, uint4 tw) {
+    ct_bfly(lo[a], lo[b], tw.x, tw.y, kP);
+    ct_bfly(hi[a], hi[b], tw.z, tw.w, kB);
+}
+__device__ __forceinline__ void gs2(uint32_t* lo, uint32_t* hi, int a, int b, uint4 tw) {
+    gs_bfly(lo[a], lo[b], tw.x, tw.y, kP);
+    gs_bfly(hi[a], hi[b], tw.z, tw.w, kB);
+}
+
+// three forward stages on 8 register-resident coefficients whose indices differ in the 3 bits the
+// stages consume: distance 4, then 2, then 1 in register numbering
+__device__ __forceinline__ void ct_radix8(uint32_t* lo, uint32_t* hi, const uint4* tw, uint32_t b0, uint32_t b1, uint32_t b2) {
+    uint4 t0 = tw[b0];
+#pragma unroll
+    for (int k = 0; k < 4; k++) ct2(lo, hi, k, k + 4, t0);
+    uint4 t1a = tw[b1], t1b = tw[b1 + 1];
+    ct2(lo, hi, 0, 2, t1a);
+    ct2(lo, hi, 1, 3, t1a);
+    ct2(lo, hi, 4, 6, t1b);
+    ct2(lo, hi, 5, 7, t1b);
+#pragma unroll
+    for (int q = 0; q < 4; q++) ct2(lo, hi, 2 * q, 2 * q + 1, tw[b2 + q]);
+}
+__device__ __forceinline__ void ct_radix4x2(uint32_t* lo, uint32_t* hi, const uint4* tw, uint32_t b1, uint32_t b2) {
+    uint4 t1a = tw[b1], t1b = tw[b1 + 1];
+    ct2(lo, hi, 0, 2, t1a);
+    ct2(lo, hi, 1, 3, t1a);
+    ct2(lo, hi, 4, 6, t1b);
+    ct2(lo, hi, 5, 7, t1b);
+#pragma unroll
+    for (int q = 0; q < 4; q++) ct2(lo, hi, 2 * q, 2 * q + 1, tw[b2 + q]);
+}
+// inverse order: distance 1, 2, 4
+__device__ __forceinline__ void gs_radix8(uint32_t* lo, uint32_t* hi, const uint4* tw, uint32_t b0, uint32_t b1, uint32_t b2) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) gs2(lo, hi, 2 * q, 2 * q + 1, tw[b2 + q]);
+    uint4 t1a = tw[b1], t1b = tw[b1 + 1];
+    gs2(lo, hi, 0, 2, t1a);
+    gs2(lo, hi, 1, 3, t1a);
+    gs2(lo, hi, 4, 6, t1b);
+    gs2(lo, hi, 5, 7, t1b);
+    uint4 t0 = tw[b0];
+#pragma unroll
+    for (int k = 0; k < 4; k++) gs2(lo, hi, k, k + 4, t0);
+}
+__device__ __forceinline__ void gs_radix4x2(uint32_t* lo, uint32_t* hi, const uint4* tw, uint32_t b1, uint32_t b2) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) gs2(lo, hi, 2 * q, 2 * q + 1, tw[b2 + q]);
+    uint4 t1a = tw[b1], t1b = tw[b1 + 1];
+    gs2(lo, hi, 0, 2, t1a);
+    gs2(lo, hi, 1, 3, t1a);
+    gs2(lo, hi, 4, 6, t1b);
+    gs2(lo, hi, 5, 7, t1b);
+}
+
+// ---- LDS tile -----------------------------------------------------------------------------------
+// 2048 packed coefficients; +4 words of padding per 32 keeps the stride-32 and stride-8 access
+// patterns of passes C and D off a single bank
+constexpr uint32_t kLdsWords = kN + (kN >> 5) * 4;
+__device__ __forceinline__ uint32_t lds_ix(uint32_t i) { return i + ((i >> 5) << 2); }
+
+// coefficient index held in register k by thread `tid` in each pass
+__device__ __forceinline__ uint32_t ix_a(uint32_t tid, int k) { return tid + 256u * k; }
+__device__ __forceinline__ uint32_t ix_b(uint32_t tid, int k) { return ((tid >> 5) << 8) + 32u * k + (tid & 31u); }
+__device__ __forceinline__ uint32_t ix_c(uint32_t tid, int k) { return ((tid >> 2) << 5) + 4u * k + (tid & 3u); }
+__device__ __forceinline__ uint32_t ix_d(uint32_t tid, int k) { return 8u * tid + k; }
+
+template <uint32_t (*IX)(uint32_t, int)>
+__device__ __forceinline__ void lds_put(uint64_t* sh, uint32_t tid, const uint32_t* lo, const uint32_t* hi) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) sh[lds_ix(IX(tid, k))] = pack(lo[k], hi[k]);
+}
+template <uint32_t (*IX)(uint32_t, int)>
+__device__ __forceinline__ void lds_get(const uint64_t* sh, uint32_t tid, uint32_t* lo, uint32_t* hi) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        uint64_t v = sh[lds_ix(IX(tid, k))];
+        lo[k] = lo32(v);
+        hi[k] = hi32(v);
+    }
+}
+
+// Forward transform of the 2048 coefficients held as (lo,hi)[k] <-> index ix_a(tid,k), values < 4m.
+// On return (lo,hi)[k] <-> slot ix_d(tid,k) = 8*tid + k, canonical in [0, m).
+__device__ __forceinline__ void ntt_forward_block(uint32_t* lo, uint32_t* hi, uint64_t* sh, const uint4* tw, uint32_t tid) {
+    ct_radix8(lo, hi, tw, 1, 2, 4);
+    lds_put<ix_a>(sh, tid, lo, hi);
+    __syncthreads();
+    lds_get<ix_b>(sh, tid, lo, hi);
+    uint32_t g = tid >> 5;
+    ct_radix8(lo, hi, tw, 8 + g, 16 + 2 * g, 32 + 4 * g);
+    lds_put<ix_b>(sh, tid, lo, hi);
+    __syncthreads();
+    lds_get<ix_c>(sh, tid, lo, hi);
+    g = tid >> 2;
+    ct_radix8(lo, hi, tw, 64 + g, 128 + 2 * g, 256 + 4 * g);
+    lds_put<ix_c>(sh, tid, lo, hi);
+    __syncthreads();
+    lds_get<ix_d>(sh, tid, lo, hi);
+    ct_radix4x2(lo, hi, tw, 512 + 2 * tid, 1024 + 4 * tid);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        lo[k] = csub(csub(lo[k], 2 * kP), kP);
+        hi[k] = csub(csub(hi[k], 2 * kB), kB);
+    }
+}
+
+// Inverse transform: in (lo,hi)[k] <-> slot ix_d(tid,k), values in [0, 2m);
+// out (lo,hi)[k] <-> coefficient ix_a(tid,k) = tid + 256k, canonical in [0, m).
+__device__ __forceinline__ void ntt_inverse_block(uint32_t* lo, uint32_t* hi, uint64_t* sh, const uint4* tw, uint32_t tid) {
+    gs_radix4x2(lo, hi, tw, 512 + 2 * tid, 1024 + 4 * tid);
+    lds_put<ix_d>(sh, tid, lo, hi);
+    __syncthreads();
+    lds_get<ix_c>(sh, tid, lo, hi);
+    uint32_t g = tid >> 2;
+    gs_radix8(lo, hi, tw, 64 + g, 128 + 2 * g, 256 + 4 * g);
+    lds_put<ix_c>(sh, tid, lo, hi);
+    __syncthreads();
+    lds_get<ix_b>(sh, tid, lo, hi);
+    g = tid >> 5;
+    gs_radix8(lo, hi, tw, 8 + g, 16 + 2 * g, 32 + 4 * g);
+    lds_put<ix_b>(sh, tid, lo, hi);
+    __syncthreads();
+    lds_get<ix_a>(sh, tid, lo, hi);
+    gs_radix8(lo, hi, tw, 1, 2, 4);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        lo[k] = csub(lo[k], kP);
+        hi[k] = csub(hi[k], kB);
+    }
+}
+
+}  // namespace spiral

@@ -1,0 +1,237 @@
+// Batched NTT / INTT kernels with fused pre- and post-operations, gfx950.
+// One 256-thread workgroup per output polynomial.  See ntt.cuh for the transform itself.
+#include "kernels.h"
+#include "ntt.cuh"
+
+namespace spiral {
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// raw coefficient `idx` of the automorphed polynomial a(x^t): gather form of src/poly.cpp:240-261.
+// e = idx * t^-1 mod 2N; source index e mod N, negated (as Q - a, so 0 -> Q) when e >= N.
+__device__ __forceinline__ uint64_t load_raw(const uint64_t* src, uint32_t idx, uint32_t tinv) {
+    if (tinv == 0) return src[idx];
+    uint32_t e = (idx * tinv) & (2 * kN - 1);
+    uint64_t v = src[e & (kN - 1)];
+    return (e & kN) ? kQ - v : v;
+}
+
+__device__ __forceinline__ uint64_t digit_of(uint64_t v, uint32_t k, uint32_t bits, uint64_t mask) {
+    uint32_t sh = k * bits;
+    return sh >= 64 ? 0ull : ((v >> sh) & mask);  // a shift count >= 64 is UB in src/util.cpp:136; defined as 0
+}
+
+// balanced digit k of v under split_and_crt's two carry chains (src/spiral.cpp:283-292, 313-322),
+// returned as residues (mod p, mod b); a borrowed digit is piece + Q - 2^bits == piece - 2^bits (mod m)
+__device__ __forceinline__ void sdigit_of(uint64_t v, uint32_t k, uint32_t bits, uint32_t ell, uint32_t& rp, uint32_t& rb) {
+    const uint64_t mask = (1ull << bits) - 1, base = 1ull << bits, thresh = base >> 1;
+    const uint32_t half = ell >> 1;
+    uint32_t kk = k < half ? 0u : half;
+    uint64_t carry = 0, piece = 0;
+    bool borrowed = false;
+    for (; kk <= k; kk++) {
+        piece = digit_of(v, kk, bits, mask) + carry;
+        bool may = (kk < half) ? (kk + 1 < half) : true;
+        borrowed = (piece > thresh) && may;
+        carry = borrowed ? 1 : 0;
+    }
+    if (borrowed) {
+        uint32_t d = (uint32_t)(base - piece);  // in [0, 2^bits/2)
+        rp = kP - d;
+        rb = kB - d;
+    } else {
+        rp = (uint32_t)piece;
+        rb = (uint32_t)piece;
+    }
+}
+
+template <uint32_t LOAD, uint32_t STORE>
+__global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p) {
+    __shared__ uint64_t sh[kLdsWords];
+    const uint32_t tid = threadIdx.x, b = blockIdx.x;
+    const uint32_t s = b / p.n_digits, k = b - s * p.n_digits;
+    uint32_t lo[8], hi[8];
+
+    if constexpr (LOAD == LD_DBGEN) {
+        // block b <-> (item, polynomial mc) ; coefficient index within the item = mc*N + z
+        const uint64_t item = p.item_base + (b >> 2);
+        const uint32_t mc = b & 3u;
+        const uint64_t half_p = p.p_db >> 1;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            uint32_t idx = ix_a(tid, r);
+            uint64_t v = splitmix64(p.seed ^ (item * (4ull * kN) + (uint64_t)mc * kN + idx)) % p.p_db;
+            if (v >= half_p) {  // v - p_db + Q  ==  -(p_db - v) mod m
+                uint64_t d = p.p_db - v;
+                lo[r] = kP - mod_p(d);
+                hi[r] = kB - mod_b(d);
+            } else {
+                lo[r] = mod_p(v);
+                hi[r] = mod_b(v);
+            }
+        }
+    } else if constexpr (LOAD == LD_LIMBS) {
+        const uint64_t* src = p.src + (size_t)p.src_map(s) * (2 * kN);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            uint32_t idx = ix_a(tid, r);
+            lo[r] = (uint32_t)src[idx];
+            hi[r] = (uint32_t)src[kN + idx];
+        }
+    } else {
+        const uint64_t* src = p.src + (size_t)p.src_map(s) * kN;
+        const uint64_t mask = (1ull << p.bits) - 1;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            uint32_t idx = ix_a(tid, r);
+            uint64_t v = load_raw(src, idx, p.tinv);
+            if constexpr (LOAD == LD_RAW) {
+                lo[r] = mod_p(v);
+                hi[r] = mod_b(v);
+            } else if constexpr (LOAD == LD_DIGIT) {
+                uint32_t d = (uint32_t)digit_of(v, k, p.bits, mask);
+                lo[r] = d;
+                hi[r] = d;
+            } else {
+                sdigit_of(v, k, p.bits, p.ell, lo[r], hi[r]);
+            }
+        }
+    }
+
+    ntt_forward_block(lo, hi, sh, t.fwd, tid);
+
+    if constexpr (STORE == ST_PK) {
+        uint32_t di;
+        if constexpr (LOAD == LD_SDIGIT) {
+            // source s = (ct i', r, c) over [2*np][3][2]; operand layout D[i' % np][(i' / np)*m2 + r + 3k][c]
+            const uint32_t ct = s / 6u, rc = s - ct * 6u, r = rc >> 1, c = rc & 1u;
+            const uint32_t m2 = 3u * p.ell, hi_half = ct / p.fold_np, i = ct - hi_half * p.fold_np;
+            di = ((i * 2u + hi_half) * m2 + r + 3u * k) * 2u + c;
+        } else {
+            di = p.dst_map(b);
+        }
+        uint64_t* dst = p.dst + (size_t)di * kN + 8u * tid;
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) {
+            ulonglong2 v2 = make_ulonglong2(pack(lo[r], hi[r]), pack(lo[r + 1], hi[r + 1]));
+            *reinterpret_cast<ulonglong2*>(dst + r) = v2;
+        }
+    } else if constexpr (STORE == ST_REF) {
+        uint64_t* dst = p.dst + (size_t)p.dst_map(b) * (2 * kN) + 8u * tid;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            dst[r] = lo[r];
+            dst[kN + r] = hi[r];
+        }
+    } else {  // ST_DB: scatter into the sweep layout
+        const uint64_t item = p.item_base + (b >> 2);
+        const uint32_t mc = b & 3u, m = mc >> 1, c = mc & 1u;
+        const uint32_t ii = (uint32_t)(item % p.num_per), j = (uint32_t)(item / p.num_per);
+        const uint32_t jm = (j - p.j0) * 2u + m, ic = ii * 2u + c, nic = 2u * p.num_per;
+        const size_t zstride = (size_t)p.dim0_shard * nic * 2u;  // words per z slab = (JM/2) * nic * 2
+        uint64_t* dst = p.dst + ((size_t)(jm >> 1) * nic + ic) * 2u + (jm & 1u);
+#pragma unroll
+        for (int r = 0; r < 8; r++) dst[(size_t)(8u * tid + r) * zstride] = pack(lo[r], hi[r]);
+    }
+}
+
+template <uint32_t STORE>
+__global__ __launch_bounds__(256) void ntt_inverse_kernel(Tables t, InvParams p) {
+    __shared__ uint64_t sh[kLdsWords];
+    const uint32_t tid = threadIdx.x, b = blockIdx.x;
+    uint32_t lo[8], hi[8];
+    if (p.src_ref) {
+        const uint64_t* src = p.src + (size_t)p.src_map(b) * (2 * kN) + 8u * tid;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            lo[r] = (uint32_t)src[r];
+            hi[r] = (uint32_t)src[kN + r];
+        }
+    } else {
+        const uint64_t* src = p.src + (size_t)p.src_map(b) * kN + 8u * tid;
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) {
+            ulonglong2 v2 = *reinterpret_cast<const ulonglong2*>(src + r);
+            lo[r] = lo32(v2.x);
+            hi[r] = hi32(v2.x);
+            lo[r + 1] = lo32(v2.y);
+            hi[r + 1] = hi32(v2.y);
+        }
+    }
+    if (p.pre_reduce) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            lo[r] %= kP;
+            hi[r] %= kB;
+        }
+    }
+    ntt_inverse_block(lo, hi, sh, t.inv, tid);
+    if constexpr (STORE == IST_CRT) {
+        uint64_t* dst = p.dst + (size_t)p.dst_map(b) * kN;
+#pragma unroll
+        for (int r = 0; r < 8; r++) dst[ix_a(tid, r)] = crt_compose(lo[r], hi[r]);
+    } else {
+        uint64_t* dst = p.dst + (size_t)p.dst_map(b) * (2 * kN);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            dst[ix_a(tid, r)] = lo[r];
+            dst[kN + ix_a(tid, r)] = hi[r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ref_to_pk_kernel(const uint64_t* ref, uint64_t* pk, IndexMap pk_map) {
+    const size_t poly = blockIdx.y;
+    const uint32_t z = blockIdx.x * 256u + threadIdx.x;
+    const uint64_t* r = ref + poly * (2 * kN);
+    pk[(size_t)pk_map((uint32_t)poly) * kN + z] = pack((uint32_t)(r[z] % kP), (uint32_t)(r[kN + z] % kB));
+}
+__global__ __launch_bounds__(256) void pk_to_ref_kernel(const uint64_t* pk, uint64_t* ref, IndexMap pk_map) {
+    const size_t poly = blockIdx.y;
+    const uint32_t z = blockIdx.x * 256u + threadIdx.x;
+    uint64_t v = pk[(size_t)pk_map((uint32_t)poly) * kN + z];
+    ref[poly * (2 * kN) + z] = lo32(v);
+    ref[poly * (2 * kN) + kN + z] = hi32(v);
+}
+
+#define FWD_CASE(L, S)                                                                                  \
+    if (load == L && store == S) {                                                                      \
+        hipLaunchKernelGGL((ntt_forward_kernel<L, S>), dim3(nblocks), dim3(256), 0, s, tb, p);          \
+        return;                                                                                         \
+    }
+
+void launch_ntt_forward(const DeviceTables& t, const FwdParams& p, uint32_t load, uint32_t store, uint32_t nblocks, hipStream_t s) {
+    if (nblocks == 0) return;
+    Tables tb{t.fwd, t.inv};
+    FWD_CASE(LD_RAW, ST_PK)
+    FWD_CASE(LD_RAW, ST_REF)
+    FWD_CASE(LD_DIGIT, ST_PK)
+    FWD_CASE(LD_SDIGIT, ST_PK)
+    FWD_CASE(LD_LIMBS, ST_REF)
+    FWD_CASE(LD_LIMBS, ST_PK)
+    FWD_CASE(LD_DBGEN, ST_DB)
+    abort();
+}
+
+void launch_ntt_inverse(const DeviceTables& t, const InvParams& p, uint32_t store, uint32_t nblocks, hipStream_t s) {
+    if (nblocks == 0) return;
+    Tables tb{t.fwd, t.inv};
+    if (store == IST_CRT)
+        hipLaunchKernelGGL((ntt_inverse_kernel<IST_CRT>), dim3(nblocks), dim3(256), 0, s, tb, p);
+    else
+        hipLaunchKernelGGL((ntt_inverse_kernel<IST_LIMBS>), dim3(nblocks), dim3(256), 0, s, tb, p);
+}
+
+void launch_ref_to_pk(const uint64_t* ref, uint64_t* pk, uint32_t npolys, IndexMap pk_map, hipStream_t s) {
+    if (npolys) hipLaunchKernelGGL(ref_to_pk_kernel, dim3(kN / 256, npolys), dim3(256), 0, s, ref, pk, pk_map);
+}
+void launch_pk_to_ref(const uint64_t* pk, uint64_t* ref, uint32_t npolys, IndexMap pk_map, hipStream_t s) {
+    if (npolys) hipLaunchKernelGGL(pk_to_ref_kernel, dim3(kN / 256, npolys), dim3(256), 0, s, pk, ref, pk_map);
+}
+
+}  // namespace spiral

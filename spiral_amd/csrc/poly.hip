@@ -1,0 +1,267 @@
+// Pointwise polynomial kernels on PK (packed NTT) and RAW buffers, gfx950.
+// One thread per NTT slot / coefficient, 256-thread workgroups, 8 workgroups per polynomial.
+// All NTT-domain outputs are canonical residues in [0, m).
+#include "common.h"
+#include "kernels.h"
+
+namespace spiral {
+
+constexpr uint32_t kTpb = 256;
+constexpr uint32_t kBpp = kN / kTpb;  // blocks per polynomial
+
+struct Acc2 {
+    uint64_t lo = 0, hi = 0;
+    __device__ __forceinline__ void mac(uint64_t a, uint64_t b) {
+        lo += (uint64_t)lo32(a) * lo32(b);  // u64 accumulation without intermediate reduce,
+        hi += (uint64_t)hi32(a) * hi32(b);  // as src/poly.cpp:62 (<= 256 terms of < 2^56)
+    }
+    __device__ __forceinline__ uint64_t reduced() const { return pack(mod_p(lo), mod_b(hi)); }
+};
+__device__ __forceinline__ uint64_t add_pk(uint64_t a, uint64_t b) {  // canonical operands
+    return pack(csub(lo32(a) + lo32(b), kP), csub(hi32(a) + hi32(b), kB));
+}
+
+// ---- generic MatPoly multiply (src/poly.cpp:34-78) ---------------------------------------------------
+__global__ __launch_bounds__(kTpb) void matmul_kernel(MatmulParams p) {
+    const uint32_t z = blockIdx.x * kTpb + threadIdx.x;
+    const uint32_t rc = blockIdx.y, r = rc / p.cs, c = rc - r * p.cs, bt = blockIdx.z;
+    const uint64_t* a = p.a + ((size_t)bt * p.a_batch + (size_t)r * p.ms) * kN + z;
+    const uint64_t* b = p.b + ((size_t)bt * p.b_batch + c) * kN + z;
+    Acc2 acc;
+    for (uint32_t m = 0; m < p.ms; m++) acc.mac(a[(size_t)m * kN], b[(size_t)m * p.cs * kN]);
+    p.out[((size_t)bt * p.out_batch + rc) * kN + z] = acc.reduced();
+}
+void launch_matmul(const MatmulParams& p, uint32_t batch, hipStream_t s) {
+    if (batch == 0) return;
+    hipLaunchKernelGGL(matmul_kernel, dim3(kBpp, p.rs * p.cs, batch), dim3(kTpb), 0, s, p);
+}
+
+// ---- add / mul_by_const (src/poly.cpp:138-155, 190-211) ----------------------------------------------
+__global__ __launch_bounds__(kTpb) void add_kernel(const uint64_t* a, const uint64_t* b, uint64_t* out) {
+    const size_t i = (size_t)blockIdx.x * kTpb + threadIdx.x;
+    uint64_t x = a[i], y = b[i];
+    out[i] = pack(mod_p((uint64_t)lo32(x) + lo32(y)), mod_b((uint64_t)hi32(x) + hi32(y)));
+}
+void launch_add(const uint64_t* a, const uint64_t* b, uint64_t* out, uint32_t npolys, hipStream_t s) {
+    if (npolys) hipLaunchKernelGGL(add_kernel, dim3(npolys * kBpp), dim3(kTpb), 0, s, a, b, out);
+}
+__global__ __launch_bounds__(kTpb) void mul_by_const_kernel(const uint64_t* single, const uint64_t* a, uint64_t* out) {
+    const uint32_t z = blockIdx.x * kTpb + threadIdx.x;
+    const size_t i = (size_t)blockIdx.y * kN + z;
+    uint64_t x = a[i], w = single[z];
+    out[i] = pack(mod_p((uint64_t)lo32(x) * lo32(w)), mod_b((uint64_t)hi32(x) * hi32(w)));
+}
+void launch_mul_by_const(const uint64_t* single, const uint64_t* a, uint64_t* out, uint32_t npolys, hipStream_t s) {
+    if (npolys) hipLaunchKernelGGL(mul_by_const_kernel, dim3(kBpp, npolys), dim3(kTpb), 0, s, single, a, out);
+}
+
+// ---- raw-domain helpers (src/poly.cpp:240-283, src/util.cpp:114-144) ------------------------------------
+__global__ __launch_bounds__(kTpb) void automorph_kernel(const uint64_t* in, uint64_t* out, uint32_t t) {
+    const uint32_t i = blockIdx.x * kTpb + threadIdx.x;
+    const size_t base = (size_t)blockIdx.y * kN;
+    const uint64_t prod = (uint64_t)i * t;
+    const uint32_t pos = (uint32_t)(prod & (kN - 1));
+    const uint64_t v = in[base + i];
+    out[base + pos] = ((prod >> kLogN) & 1ull) ? kQ - v : v;  // Q - a: 0 -> Q
+}
+void launch_automorph(const uint64_t* in, uint64_t* out, uint32_t npolys, uint32_t t, hipStream_t s) {
+    if (npolys) hipLaunchKernelGGL(automorph_kernel, dim3(kBpp, npolys), dim3(kTpb), 0, s, in, out, t);
+}
+__global__ __launch_bounds__(kTpb) void invert_kernel(const uint64_t* in, uint64_t* out) {
+    const size_t i = (size_t)blockIdx.x * kTpb + threadIdx.x;
+    out[i] = kQ - in[i];
+}
+void launch_invert(const uint64_t* in, uint64_t* out, uint32_t npolys, hipStream_t s) {
+    if (npolys) hipLaunchKernelGGL(invert_kernel, dim3(npolys * kBpp), dim3(kTpb), 0, s, in, out);
+}
+// in raw [rdim][cols][N] -> out raw [mx][cols][N], row = j + k*rdim
+__global__ __launch_bounds__(kTpb) void gadget_invert_kernel(const uint64_t* in, uint64_t* out, uint32_t mx, uint32_t rdim, uint32_t cols) {
+    const uint32_t z = blockIdx.x * kTpb + threadIdx.x;
+    const uint32_t jc = blockIdx.y, j = jc / cols, c = jc - j * cols;
+    const uint32_t ne = mx / rdim, bits = get_bits_per(ne);
+    const uint64_t mask = (1ull << bits) - 1;
+    const uint64_t v = in[((size_t)j * cols + c) * kN + z];
+    for (uint32_t k = 0; k < ne; k++) {
+        uint32_t sh = k * bits;
+        out[((size_t)(j + k * rdim) * cols + c) * kN + z] = sh >= 64 ? 0ull : ((v >> sh) & mask);
+    }
+}
+void launch_gadget_invert(const uint64_t* in, uint64_t* out, uint32_t mx, uint32_t rdim, uint32_t cols, hipStream_t s) {
+    hipLaunchKernelGGL(gadget_invert_kernel, dim3(kBpp, rdim * cols), dim3(kTpb), 0, s, in, out, mx, rdim, cols);
+}
+
+// ---- response modulus switch (src/poly.cpp:578-601) ------------------------------------------------------
+// round(centre(a) * out_mod / inp_mod) mod out_mod with the reference's round-half-away-from-zero and
+// truncating division; the 128-bit quotient is a double estimate corrected exactly.
+__device__ __forceinline__ uint64_t rescale_dev(uint64_t a, uint64_t inp_mod, uint64_t out_mod) {
+    a %= inp_mod;
+    const bool neg = a >= inp_mod / 2;
+    const uint64_t mag = neg ? inp_mod - a : a;
+    const unsigned __int128 x = (unsigned __int128)mag * out_mod + inp_mod / 2;
+    const double xd = (double)(uint64_t)(x >> 64) * 18446744073709551616.0 + (double)(uint64_t)x;
+    uint64_t q = (uint64_t)(xd / (double)inp_mod);
+    __int128 r = (__int128)x - (__int128)((unsigned __int128)q * inp_mod);
+    while (r < 0) {
+        q--;
+        r += inp_mod;
+    }
+    while (r >= (__int128)inp_mod) {
+        q++;
+        r -= inp_mod;
+    }
+    uint64_t res = q % out_mod;
+    return (neg && res != 0) ? out_mod - res : res;
+}
+__global__ __launch_bounds__(kTpb) void rescale_kernel(const uint64_t* in, uint64_t* out, uint32_t n, uint64_t inp_mod, uint64_t out_mod) {
+    const uint32_t i = blockIdx.x * kTpb + threadIdx.x;
+    if (i < n) out[i] = rescale_dev(in[i] % kQ, inp_mod, out_mod);
+}
+void launch_rescale(const uint64_t* in, uint64_t* out, uint32_t n, uint64_t inp_mod, uint64_t out_mod, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(rescale_kernel, dim3((n + kTpb - 1) / kTpb), dim3(kTpb), 0, s, in, out, n, inp_mod, out_mod);
+}
+
+// ---- coefficient expansion (src/spiral.cpp:1664-1743) -------------------------------------------------------
+// cv[dst0 + step*a][j] = neg1_r * cv[src0 + step*a][j]
+__global__ __launch_bounds__(kTpb) void mul_neg1_kernel(uint64_t* cv, const uint64_t* neg1_r, uint32_t src0, uint32_t dst0, uint32_t step) {
+    const uint32_t z = blockIdx.x * kTpb + threadIdx.x, a = blockIdx.y;
+    const uint64_t w = neg1_r[z];
+    const size_t si = (size_t)(src0 + step * a) * 2 * kN + z, di = (size_t)(dst0 + step * a) * 2 * kN + z;
+#pragma unroll
+    for (uint32_t j = 0; j < 2; j++) {
+        uint64_t x = cv[si + (size_t)j * kN];
+        cv[di + (size_t)j * kN] = pack(mod_p((uint64_t)lo32(x) * lo32(w)), mod_b((uint64_t)hi32(x) * hi32(w)));
+    }
+}
+void launch_mul_neg1(uint64_t* cv, const uint64_t* neg1_r, uint32_t src0, uint32_t dst0, uint32_t step, uint32_t count, hipStream_t s) {
+    if (count) hipLaunchKernelGGL(mul_neg1_kernel, dim3(kBpp, count), dim3(kTpb), 0, s, cv, neg1_r, src0, dst0, step);
+}
+
+// cv[i][j] = cv[i][j] + (W * G^-1(c'_0))[j] + j * NTT(c'_1),  i = i0 + step*a
+__global__ __launch_bounds__(kTpb) void expand_mac_kernel(uint64_t* cv, const uint64_t* w, const uint64_t* g, const uint64_t* a1, uint32_t t_dim,
+                                                          uint32_t i0, uint32_t step) {
+    const uint32_t z = blockIdx.x * kTpb + threadIdx.x, a = blockIdx.y;
+    const uint64_t* gp = g + (size_t)a * t_dim * kN + z;
+    Acc2 acc0, acc1;
+    for (uint32_t k = 0; k < t_dim; k++) {
+        uint64_t gv = gp[(size_t)k * kN];
+        acc0.mac(w[(size_t)k * kN + z], gv);
+        acc1.mac(w[(size_t)(t_dim + k) * kN + z], gv);
+    }
+    uint64_t* c = cv + (size_t)(i0 + step * a) * 2 * kN + z;
+    c[0] = add_pk(c[0], acc0.reduced());
+    c[kN] = add_pk(add_pk(c[kN], acc1.reduced()), a1[(size_t)a * kN + z]);
+}
+void launch_expand_mac(uint64_t* cv, const uint64_t* w, const uint64_t* g, const uint64_t* a1, uint32_t t_dim, uint32_t i0, uint32_t step,
+                       uint32_t count, hipStream_t s) {
+    if (count) hipLaunchKernelGGL(expand_mac_kernel, dim3(kBpp, count), dim3(kTpb), 0, s, cv, w, g, a1, t_dim, i0, step);
+}
+
+// ---- scalToMat (src/spiral.cpp:1834-1885) ----------------------------------------------------------------------
+// prod[r][c] = sum_k W[r][2k + c] * g[k]  (special_distribute makes column c see only W's columns 2k+c),
+// out = prod + pad(cv row 1) at (1,0) and (2,1)
+__device__ __forceinline__ void scal2mat_slot(const uint64_t* w, const uint64_t* g, uint32_t t_conv, uint64_t cv1, uint32_t z, uint64_t out[3][2]) {
+    Acc2 acc[3][2];
+    for (uint32_t k = 0; k < t_conv; k++) {
+        uint64_t gv = g[(size_t)k * kN];
+#pragma unroll
+        for (uint32_t r = 0; r < 3; r++) {
+            const uint64_t* wr = w + ((size_t)r * 2 * t_conv + 2 * k) * kN + z;
+            acc[r][0].mac(wr[0], gv);
+            acc[r][1].mac(wr[kN], gv);
+        }
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < 3; r++)
+#pragma unroll
+        for (uint32_t c = 0; c < 2; c++) {
+            uint64_t v = acc[r][c].reduced();
+            if ((r == 1 && c == 0) || (r == 2 && c == 1)) v = add_pk(v, cv1);
+            out[r][c] = v;
+        }
+}
+__global__ __launch_bounds__(kTpb) void scal2mat_kernel(Scal2MatParams p) {
+    const uint32_t z = blockIdx.x * kTpb + threadIdx.x, a = blockIdx.y;
+    const uint64_t cv1 = p.cv[((size_t)p.cv_pos(a) * 2 + 1) * kN + z];
+    uint64_t out[3][2];
+    scal2mat_slot(p.w, p.g + (size_t)a * p.t_conv * kN + z, p.t_conv, cv1, z, out);
+    if (p.out) {
+#pragma unroll
+        for (uint32_t r = 0; r < 3; r++)
+#pragma unroll
+            for (uint32_t c = 0; c < 2; c++) p.out[(((size_t)a * 3 + r) * 2 + c) * kN + z] = out[r][c];
+    }
+    if (p.qs) {  // sweep query record of (z, j): {p rows 0..2 | b rows 0..2} for m = 0, then m = 1
+        uint4* rec = reinterpret_cast<uint4*>(p.qs + ((size_t)z * (p.jm_total / 2) + p.j_base + a) * 12);
+        rec[0] = make_uint4(lo32(out[0][0]), lo32(out[1][0]), lo32(out[2][0]), hi32(out[0][0]));
+        rec[1] = make_uint4(hi32(out[1][0]), hi32(out[2][0]), lo32(out[0][1]), lo32(out[1][1]));
+        rec[2] = make_uint4(lo32(out[2][1]), hi32(out[0][1]), hi32(out[1][1]), hi32(out[2][1]));
+    }
+}
+void launch_scal2mat(const Scal2MatParams& p, hipStream_t s) {
+    if (p.count) hipLaunchKernelGGL(scal2mat_kernel, dim3(kBpp, p.count), dim3(kTpb), 0, s, p);
+}
+
+// ---- regevToGSW (src/spiral.cpp:1985-2025) ------------------------------------------------------------------------
+__global__ __launch_bounds__(kTpb) void regev_to_gsw_kernel(GswParams p) {
+    const uint32_t z = blockIdx.x * kTpb + threadIdx.x, di = blockIdx.y;  // di = d*ell + i
+    const uint32_t d = di / p.ell, i = di - d * p.ell, tc = p.t_conv;
+    const uint64_t* chat = p.chat + (size_t)di * 2 * tc * kN + z;
+    const uint64_t cv1 = p.cv[((size_t)p.cv_pos(di) * 2 + 1) * kN + z];
+    uint64_t s2m[3][2];
+    scal2mat_slot(p.w, chat, tc, cv1, z, s2m);
+    Acc2 accv[3];
+    for (uint32_t k = 0; k < 2 * tc; k++) {
+        uint64_t cvv = chat[(size_t)k * kN];
+#pragma unroll
+        for (uint32_t r = 0; r < 3; r++) accv[r].mac(p.v[((size_t)r * 2 * tc + k) * kN + z], cvv);
+    }
+    const uint32_t cols = 3 * p.ell;
+    uint64_t* g = p.gsw + (size_t)(p.dims - 1 - d) * 3 * cols * kN + z;
+#pragma unroll
+    for (uint32_t r = 0; r < 3; r++) {
+        g[((size_t)r * cols + 3 * i) * kN] = accv[r].reduced();
+        g[((size_t)r * cols + 3 * i + 1) * kN] = s2m[r][0];
+        g[((size_t)r * cols + 3 * i + 2) * kN] = s2m[r][1];
+    }
+}
+void launch_regev_to_gsw(const GswParams& p, hipStream_t s) {
+    if (p.dims) hipLaunchKernelGGL(regev_to_gsw_kernel, dim3(kBpp, p.dims * p.ell), dim3(kTpb), 0, s, p);
+}
+
+// ---- fold key (src/spiral.cpp:2361-2386) ------------------------------------------------------------------------------
+// Q_neg = NTT(G2 - INTT(Q)) = NTT(G2) - Q slot-wise (the NTT is linear and a constant polynomial c has
+// NTT c in every slot); G2[r][mm] = 2^(bits*j) when mm == r + 3j (src/util.cpp:89-106)
+__global__ __launch_bounds__(kTpb) void fold_key_kernel(const uint64_t* gsw, uint64_t* key, uint32_t ell) {
+    const uint32_t z = blockIdx.x * kTpb + threadIdx.x;
+    const uint32_t m2 = 3 * ell, rm = blockIdx.y, r = rm / m2, mm = rm - r * m2, d = blockIdx.z;
+    const uint64_t q = gsw[((size_t)d * 3 * m2 + rm) * kN + z];
+    uint32_t gp = 0, gb = 0;
+    if (mm % 3 == r) {
+        const uint32_t j = mm / 3, sh = get_bits_per(ell) * j;
+        if (sh < 64) {
+            gp = mod_p(1ull << sh);
+            gb = mod_b(1ull << sh);
+        }
+    }
+    const uint32_t np = csub(gp + kP - lo32(q), kP), nb = csub(gb + kB - hi32(q), kB);
+    uint64_t* k = key + ((size_t)d * 3 + r) * (2 * m2) * kN + z;
+    k[(size_t)mm * kN] = pack(np, nb);
+    k[(size_t)(m2 + mm) * kN] = q;
+}
+void launch_fold_key(const uint64_t* gsw, uint64_t* key, uint32_t dims, uint32_t ell, hipStream_t s) {
+    if (dims) hipLaunchKernelGGL(fold_key_kernel, dim3(kBpp, 9 * ell, dims), dim3(kTpb), 0, s, gsw, key, ell);
+}
+
+__global__ __launch_bounds__(kTpb) void fold_key_from_reoriented_kernel(const uint64_t* q_re, const uint64_t* qneg_re, uint64_t* key, uint32_t m2) {
+    const uint32_t z = blockIdx.x * kTpb + threadIdx.x, rm = blockIdx.y, r = rm / m2, mm = rm - r * m2;
+    const size_t src = (size_t)z * (3 * m2) + rm;
+    const uint64_t q = q_re[src], qn = qneg_re[src];
+    uint64_t* k = key + (size_t)r * (2 * m2) * kN + z;
+    k[(size_t)mm * kN] = pack(lo32(qn) % kP, hi32(qn) % kB);
+    k[(size_t)(m2 + mm) * kN] = pack(lo32(q) % kP, hi32(q) % kB);
+}
+void launch_fold_key_from_reoriented(const uint64_t* q_re, const uint64_t* qneg_re, uint64_t* key, uint32_t m2, hipStream_t s) {
+    hipLaunchKernelGGL(fold_key_from_reoriented_kernel, dim3(kBpp, 3 * m2), dim3(kTpb), 0, s, q_re, qneg_re, key, m2);
+}
+
+}  // namespace spiral

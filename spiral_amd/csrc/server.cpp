@@ -1,0 +1,1066 @@
+// Host side of libspiral_gpu.so: the C ABI of include/spiral_gpu.h and the orchestration of the server
+// answer path (server halves of runConversionImproved / process_crtd_query / process_query_fast,
+// reference src/spiral.cpp:2040-2406, 1584-1629).  Everything is kernel launches on one HIP stream;
+// there is no CPU arithmetic path -- without a device every compute entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/spiral_gpu.h"
+#include "common.h"
+#include "kernels.h"
+
+using namespace spiral;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return -1;
+}
+
+#define HIP_OK(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+constexpr size_t kPolyBytes = (size_t)kN * sizeof(uint64_t);  // PK or RAW polynomial
+constexpr size_t kRefNtt = 2 * (size_t)kN;                     // words of a reference NTT-form polynomial
+constexpr uint64_t kQprimeMods[37] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 12289, 12289, 61441, 65537, 65537, 520193, 786433, 786433,
+                                      3604481, 7340033, 16515073, 33292289, 67043329, 132120577, 268369921, 469762049, 1073479681,
+                                      2013265921, 4293918721ull, 8588886017ull, 17175674881ull, 34359214081ull, 68718428161ull};  // values.h:74-76
+
+uint32_t ceil_log2(uint64_t x) {
+    uint32_t r = 0;
+    while ((1ull << r) < x) r++;
+    return r;
+}
+
+int shape_of(const spiral_gpu_params* p, spiral_gpu_shape* s) {
+    if (!p || !s) return fail("null argument");
+    if (p->nu1 > 16 || p->nu2 > 16) return fail("nu1/nu2 out of range");
+    if (p->t_gsw < 2 || p->t_gsw > 28 || p->t_conv < 1 || p->t_conv > 56 || p->t_exp < 1 || p->t_exp > 56 || p->t_exp_right < 1 ||
+        p->t_exp_right > 56)
+        return fail("gadget dimension out of range");
+    if (p->qprime_bits >= 37 || kQprimeMods[p->qprime_bits] == 0) return fail("unsupported q' bit width %u", p->qprime_bits);
+    if (p->p_db < 2 || p->p_db > (1ull << 40)) return fail("unsupported plaintext modulus");
+    s->dim0 = 1u << p->nu1;
+    s->num_per = 1u << p->nu2;
+    s->ell = p->t_gsw;
+    s->m2 = 3 * p->t_gsw;
+    s->n_bits = s->dim0 + s->ell * p->nu2;
+    s->qprime = kQprimeMods[p->qprime_bits];
+    if (p->direct_upload) {
+        s->g = s->stopround = s->n_left = s->n_right = 0;
+        s->n_query_cts = s->n_bits;
+    } else {
+        s->g = ceil_log2(s->n_bits);
+        s->stopround = p->nu2 ? ceil_log2((uint64_t)s->ell * p->nu2) : 0;
+        if (s->ell * p->nu2 > s->dim0) s->stopround = 0;  // src/spiral.cpp:2083
+        s->n_left = s->g;
+        s->n_right = s->stopround ? s->stopround + 1 : s->g;
+        s->n_query_cts = 1;
+        if (s->g > kLogN) return fail("query does not fit one polynomial (g = %u)", s->g);
+    }
+    return 0;
+}
+
+uint32_t inv_mod_2n(uint32_t t) {  // t odd, inverse modulo 2N = 4096
+    uint32_t x = 1;
+    for (int i = 0; i < 12; i++) x = x * (2 - t * x);  // Newton, doubles the valid bits
+    return x & (2 * kN - 1);
+}
+
+struct DevBuf {
+    uint64_t* p = nullptr;
+    size_t words = 0;
+    int alloc(size_t w) {
+        words = w ? w : 1;
+        HIP_OK(hipMalloc(&p, words * sizeof(uint64_t)));
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
+};
+
+// scoped device scratch for the host-buffer seams
+struct Scratch {
+    std::vector<void*> ptrs;
+    ~Scratch() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+    uint64_t* get(size_t words) {
+        void* p = nullptr;
+        if (hipMalloc(&p, (words ? words : 1) * sizeof(uint64_t)) != hipSuccess) return nullptr;
+        ptrs.push_back(p);
+        return (uint64_t*)p;
+    }
+    uint64_t* upload(const uint64_t* host, size_t words) {
+        uint64_t* d = get(words);
+        if (d && hipMemcpy(d, host, words * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        return d;
+    }
+};
+
+int current_tables(DeviceTables* t) {
+    int dev = 0;
+    HIP_OK(hipGetDevice(&dev));
+    if (tables_get(dev, t) != 0) return fail("twiddle table setup failed on device %d", dev);
+    return 0;
+}
+
+// ---- expansion on PK buffers, shared by the seam and the resident server ---------------------------------
+struct ExpandWork {
+    uint64_t* raw;  // [2^g][2] RAW
+    uint64_t* g;    // digit polynomials
+    uint64_t* a1;   // [2^g] PK
+};
+size_t expand_g_polys(uint32_t g, uint32_t t_exp, uint32_t t_exp_right) {
+    size_t half = (size_t)1 << (g ? g - 1 : 0);
+    return half * (t_exp > t_exp_right ? t_exp : t_exp_right);
+}
+
+// src/spiral.cpp:1664-1743.  cv: 2^g cts (2 PK polys each).
+void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_t t_exp, const uint64_t* w_left, uint32_t t_exp_right,
+                const uint64_t* w_right, uint32_t max_bits_right, uint32_t stopround, const ExpandWork& wk, hipStream_t st) {
+    for (uint32_t r = 0; r < g; r++) {
+        const uint32_t num_in = 1u << r;
+        const uint32_t t = (kN >> r) + 1, tinv = inv_mod_2n(t);
+        // active ciphertexts of this round, by parity (:1701-1702)
+        uint32_t cnt_even = num_in, cnt_odd = num_in;
+        if (stopround > 0 && r > stopround) cnt_odd = 0;
+        if (stopround > 0 && r == stopround) cnt_odd = std::min(num_in, max_bits_right + 1);
+        // cv[num_in + i] = neg1 * cv[i] for the active i < num_in (:1709), before cv[i] is updated
+        const uint64_t* neg1 = tb.neg1 + (size_t)r * kN;
+        if (r == 0) {
+            launch_mul_neg1(cv, neg1, 0, 1, 1, 1, st);
+        } else {
+            launch_mul_neg1(cv, neg1, 0, num_in, 2, num_in / 2, st);
+            launch_mul_neg1(cv, neg1, 1, num_in + 1, 2, std::min(num_in / 2, cnt_odd), st);
+        }
+        for (int parity = 0; parity < 2; parity++) {
+            const uint32_t cnt = parity ? cnt_odd : cnt_even;
+            if (cnt == 0) continue;
+            const uint32_t tdim = parity ? t_exp_right : t_exp;
+            const uint64_t* w = (parity ? w_right : w_left) + (size_t)r * 2 * tdim * kN;
+            // c = from_ntt(cv[i]) for i = parity + 2a
+            InvParams ip{};
+            ip.src = cv;
+            ip.dst = wk.raw;
+            ip.src_map = IndexMap{2, 4, 2u * parity};
+            ip.dst_map = identity_map();
+            launch_ntt_inverse(tb, ip, IST_CRT, 2 * cnt, st);
+            // G^-1(automorph(c)[0]) -> tdim digit polynomials per ct, NTT'd without reduction
+            FwdParams fp{};
+            fp.src = wk.raw;
+            fp.dst = wk.g;
+            fp.src_map = IndexMap{1, 2, 0};
+            fp.dst_map = identity_map();
+            fp.n_digits = tdim;
+            fp.bits = get_bits_per(tdim);
+            fp.tinv = tinv;
+            launch_ntt_forward(tb, fp, LD_DIGIT, ST_PK, cnt * tdim, st);
+            // NTT(automorph(c)[1])
+            FwdParams fa{};
+            fa.src = wk.raw;
+            fa.dst = wk.a1;
+            fa.src_map = IndexMap{1, 2, 1};
+            fa.dst_map = identity_map();
+            fa.n_digits = 1;
+            fa.tinv = tinv;
+            launch_ntt_forward(tb, fa, LD_RAW, ST_PK, cnt, st);
+            launch_expand_mac(cv, w, wk.g, wk.a1, tdim, parity, 2, cnt, st);
+        }
+    }
+}
+
+}  // namespace
+
+// =================================================================================================
+// resident server
+// =================================================================================================
+struct spiral_gpu_server {
+    spiral_gpu_params p;
+    spiral_gpu_shape s;
+    int device = 0;
+    uint32_t j0 = 0, j1 = 0, dim0_shard = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    DeviceTables tb;
+    bool keep_cts = false, have_db = false, have_pp = false, have_query = false;
+    // expanded-ciphertext positions inside cv: first-dim j at j*pos_stride + pos_first, rest i at i*pos_stride + pos_rest
+    uint32_t pos_stride = 1, pos_first = 0, pos_rest = 0, n_cv = 0;
+
+    DevBuf db, w_left, w_right, w, v, query, cv, ex_raw, ex_g, ex_a1;
+    DevBuf cv_raw, cv_g, gs_raw, gs_chat, gsw, key, cts_keep;
+    DevBuf qs, acc_own, raw, fold_d, fold_c, resp, stage;
+    uint64_t* acc = nullptr;
+    hipEvent_t ev[8] = {};
+};
+
+namespace {
+
+int srv_alloc(spiral_gpu_server* S) {
+    const spiral_gpu_params& p = S->p;
+    const spiral_gpu_shape& s = S->s;
+    const size_t nic = 2 * (size_t)s.num_per;
+    if (S->db.alloc((size_t)kN * S->dim0_shard * nic * 2)) return -1;
+    if (S->w_left.alloc((size_t)s.n_left * 2 * p.t_exp * kN)) return -1;
+    if (S->w_right.alloc((size_t)s.n_right * 2 * p.t_exp_right * kN)) return -1;
+    if (S->w.alloc((size_t)3 * 2 * p.t_conv * kN)) return -1;
+    if (S->v.alloc((size_t)3 * 2 * p.t_conv * kN)) return -1;
+    if (S->query.alloc((size_t)s.n_query_cts * 2 * kN)) return -1;
+    S->n_cv = p.direct_upload ? s.n_bits : (1u << s.g);
+    if (S->cv.alloc((size_t)S->n_cv * 2 * kN)) return -1;
+    HIP_OK(hipMemset(S->cv.p, 0, S->cv.words * sizeof(uint64_t)));
+    if (!p.direct_upload) {
+        if (S->ex_raw.alloc((size_t)S->n_cv * 2 * kN)) return -1;
+        if (S->ex_g.alloc(expand_g_polys(s.g, p.t_exp, p.t_exp_right) * kN)) return -1;
+        if (S->ex_a1.alloc((size_t)S->n_cv * kN)) return -1;
+    }
+    if (S->cv_raw.alloc((size_t)S->dim0_shard * kN)) return -1;
+    if (S->cv_g.alloc((size_t)S->dim0_shard * p.t_conv * kN)) return -1;
+    const size_t ngs = (size_t)p.nu2 * s.ell;
+    if (S->gs_raw.alloc(ngs * 2 * kN)) return -1;
+    if (S->gs_chat.alloc(ngs * 2 * p.t_conv * kN)) return -1;
+    if (S->gsw.alloc((size_t)p.nu2 * 3 * s.m2 * kN)) return -1;
+    if (S->key.alloc((size_t)p.nu2 * 3 * 2 * s.m2 * kN)) return -1;
+    if (S->qs.alloc((size_t)kN * S->dim0_shard * 6)) return -1;  // 12 u32 per (z, j)
+    if (S->acc_own.alloc((size_t)s.num_per * 6 * kN)) return -1;
+    S->acc = S->acc_own.p;
+    if (S->raw.alloc((size_t)s.num_per * 6 * kN)) return -1;
+    const size_t half = s.num_per > 1 ? s.num_per / 2 : 1;
+    if (S->fold_d.alloc(half * 2 * s.m2 * 2 * kN)) return -1;
+    if (S->fold_c.alloc(half * 6 * kN)) return -1;
+    if (S->resp.alloc((size_t)6 * kN)) return -1;
+    return 0;
+}
+
+void srv_free(spiral_gpu_server* S) {
+    DevBuf* all[] = {&S->db, &S->w_left, &S->w_right, &S->w, &S->v, &S->query, &S->cv, &S->ex_raw, &S->ex_g, &S->ex_a1, &S->cv_raw,
+                     &S->cv_g, &S->gs_raw, &S->gs_chat, &S->gsw, &S->key, &S->cts_keep, &S->qs, &S->acc_own, &S->raw, &S->fold_d, &S->fold_c,
+                     &S->resp, &S->stage};
+    for (DevBuf* b : all) b->release();
+    for (auto& e : S->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (S->own_stream) (void)hipStreamDestroy(S->own_stream);
+}
+
+// stage a host buffer through a device staging area and convert reference NTT layout -> PK
+int upload_ref_ntt(spiral_gpu_server* S, const uint64_t* host, uint64_t* pk, size_t npolys) {
+    if (npolys == 0) return 0;
+    if (!host) return fail("null host buffer");
+    const size_t chunk = 4096;  // polynomials per staging pass (128 MiB)
+    if (S->stage.words < std::min(npolys, chunk) * kRefNtt) {
+        S->stage.release();
+        if (S->stage.alloc(std::min(npolys, chunk) * kRefNtt)) return -1;
+    }
+    for (size_t done = 0; done < npolys; done += chunk) {
+        const size_t n = std::min(chunk, npolys - done);
+        HIP_OK(hipMemcpyAsync(S->stage.p, host + done * kRefNtt, n * kRefNtt * sizeof(uint64_t), hipMemcpyHostToDevice, S->stream));
+        launch_ref_to_pk(S->stage.p, pk + done * kN, (uint32_t)n, identity_map(), S->stream);
+        HIP_OK(hipStreamSynchronize(S->stream));
+    }
+    return 0;
+}
+
+int download_pk_as_ref(spiral_gpu_server* S, const uint64_t* pk, IndexMap map, uint64_t* host, size_t npolys) {
+    if (npolys == 0) return 0;
+    const size_t chunk = 4096;
+    if (S->stage.words < std::min(npolys, chunk) * kRefNtt) {
+        S->stage.release();
+        if (S->stage.alloc(std::min(npolys, chunk) * kRefNtt)) return -1;
+    }
+    for (size_t done = 0; done < npolys; done += chunk) {
+        const size_t n = std::min(chunk, npolys - done);
+        IndexMap m = map;
+        // shift the map by `done` polynomials: valid because chunk is a multiple of every inner we use
+        m.off += (uint32_t)(done / map.inner) * map.outer_stride;
+        launch_pk_to_ref(pk, S->stage.p, (uint32_t)n, m, S->stream);
+        HIP_OK(hipMemcpyAsync(host + done * kRefNtt, S->stage.p, n * kRefNtt * sizeof(uint64_t), hipMemcpyDeviceToHost, S->stream));
+        HIP_OK(hipStreamSynchronize(S->stream));
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int spiral_gpu_abi_version(void) { return SPIRAL_GPU_ABI_VERSION; }
+const char* spiral_gpu_last_error(void) { return g_err.c_str(); }
+int spiral_gpu_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int spiral_gpu_get_shape(const spiral_gpu_params* p, spiral_gpu_shape* out) { return shape_of(p, out); }
+int spiral_gpu_get_tables(uint64_t* out) {
+    if (!out) return fail("null argument");
+    tables_host_rows(out);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-buffer seams
+// ------------------------------------------------------------------------------------------------
+int spiral_gpu_ntt_forward(uint64_t* operand, size_t npolys) {
+    DeviceTables tb;
+    if (current_tables(&tb)) return -1;
+    Scratch sc;
+    uint64_t* d = sc.upload(operand, npolys * kRefNtt);
+    if (!d) return fail("device allocation/upload failed");
+    FwdParams fp{};
+    fp.src = d;
+    fp.dst = d;
+    fp.src_map = fp.dst_map = identity_map();
+    fp.n_digits = 1;
+    launch_ntt_forward(tb, fp, LD_LIMBS, ST_REF, (uint32_t)npolys, 0);
+    HIP_OK(hipMemcpy(operand, d, npolys * kRefNtt * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int spiral_gpu_ntt_inverse(uint64_t* operand, size_t npolys) {
+    DeviceTables tb;
+    if (current_tables(&tb)) return -1;
+    Scratch sc;
+    uint64_t* d = sc.upload(operand, npolys * kRefNtt);
+    if (!d) return fail("device allocation/upload failed");
+    InvParams ip{};
+    ip.src = d;
+    ip.dst = d;
+    ip.src_map = ip.dst_map = identity_map();
+    ip.src_ref = 1;
+    ip.pre_reduce = 1;
+    launch_ntt_inverse(tb, ip, IST_LIMBS, (uint32_t)npolys, 0);
+    HIP_OK(hipMemcpy(operand, d, npolys * kRefNtt * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int spiral_gpu_to_ntt(uint64_t* out, const uint64_t* in, size_t npolys, int reduce) {
+    DeviceTables tb;
+    if (current_tables(&tb)) return -1;
+    Scratch sc;
+    uint64_t* d_in = sc.upload(in, npolys * kN);
+    uint64_t* d_out = sc.get(npolys * kRefNtt);
+    if (!d_in || !d_out) return fail("device allocation/upload failed");
+    FwdParams fp{};
+    fp.src = d_in;
+    fp.dst = d_out;
+    fp.src_map = fp.dst_map = identity_map();
+    fp.n_digits = 1;
+    if (reduce) {
+        launch_ntt_forward(tb, fp, LD_RAW, ST_REF, (uint32_t)npolys, 0);
+    } else {
+        // to_ntt_no_reduce copies the raw value into both limbs (src/poly.cpp:291-309): it is digit 0 of width 32
+        uint64_t* d_pk = sc.get(npolys * kN);
+        if (!d_pk) return fail("device allocation failed");
+        fp.dst = d_pk;
+        fp.bits = 32;
+        launch_ntt_forward(tb, fp, LD_DIGIT, ST_PK, (uint32_t)npolys, 0);
+        launch_pk_to_ref(d_pk, d_out, (uint32_t)npolys, identity_map(), 0);
+    }
+    HIP_OK(hipMemcpy(out, d_out, npolys * kRefNtt * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int spiral_gpu_from_ntt(uint64_t* out, const uint64_t* in, size_t npolys) {
+    DeviceTables tb;
+    if (current_tables(&tb)) return -1;
+    Scratch sc;
+    uint64_t* d_in = sc.upload(in, npolys * kRefNtt);
+    uint64_t* d_out = sc.get(npolys * kN);
+    if (!d_in || !d_out) return fail("device allocation/upload failed");
+    InvParams ip{};
+    ip.src = d_in;
+    ip.dst = d_out;
+    ip.src_map = ip.dst_map = identity_map();
+    ip.src_ref = 1;
+    ip.pre_reduce = 1;
+    launch_ntt_inverse(tb, ip, IST_CRT, (uint32_t)npolys, 0);
+    HIP_OK(hipMemcpy(out, d_out, npolys * kN * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+namespace {
+// upload reference NTT-form polynomials and convert to PK
+uint64_t* upload_pk(Scratch& sc, const uint64_t* host_ref, size_t npolys) {
+    uint64_t* d_ref = sc.upload(host_ref, npolys * kRefNtt);
+    uint64_t* d_pk = sc.get(npolys * kN);
+    if (!d_ref || !d_pk) return nullptr;
+    launch_ref_to_pk(d_ref, d_pk, (uint32_t)npolys, identity_map(), 0);
+    return d_pk;
+}
+int download_pk(Scratch& sc, const uint64_t* d_pk, IndexMap map, uint64_t* host_ref, size_t npolys) {
+    uint64_t* d_ref = sc.get(npolys * kRefNtt);
+    if (!d_ref) return fail("device allocation failed");
+    launch_pk_to_ref(d_pk, d_ref, (uint32_t)npolys, map, 0);
+    HIP_OK(hipMemcpy(host_ref, d_ref, npolys * kRefNtt * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+}  // namespace
+
+int spiral_gpu_multiply(uint64_t* out, const uint64_t* a, const uint64_t* b, size_t rs, size_t ms, size_t cs) {
+    Scratch sc;
+    uint64_t* da = upload_pk(sc, a, rs * ms);
+    uint64_t* db = upload_pk(sc, b, ms * cs);
+    uint64_t* dout = sc.get(rs * cs * kN);
+    if (!da || !db || !dout) return fail("device allocation/upload failed");
+    MatmulParams mp{da, db, dout, (uint32_t)rs, (uint32_t)ms, (uint32_t)cs, 0, 0, 0};
+    launch_matmul(mp, 1, 0);
+    return download_pk(sc, dout, identity_map(), out, rs * cs);
+}
+
+int spiral_gpu_add(uint64_t* out, const uint64_t* a, const uint64_t* b, size_t npolys) {
+    Scratch sc;
+    uint64_t* da = upload_pk(sc, a, npolys);
+    uint64_t* db = upload_pk(sc, b, npolys);
+    if (!da || !db) return fail("device allocation/upload failed");
+    launch_add(da, db, da, (uint32_t)npolys, 0);
+    return download_pk(sc, da, identity_map(), out, npolys);
+}
+
+int spiral_gpu_mul_by_const(uint64_t* out, const uint64_t* single_poly, const uint64_t* a, size_t npolys) {
+    Scratch sc;
+    uint64_t* ds = upload_pk(sc, single_poly, 1);
+    uint64_t* da = upload_pk(sc, a, npolys);
+    if (!ds || !da) return fail("device allocation/upload failed");
+    launch_mul_by_const(ds, da, da, (uint32_t)npolys, 0);
+    return download_pk(sc, da, identity_map(), out, npolys);
+}
+
+int spiral_gpu_automorph(uint64_t* out, const uint64_t* in, size_t npolys, uint64_t t) {
+    if ((t & 1) == 0) return fail("automorphism exponent must be odd");
+    Scratch sc;
+    uint64_t* di = sc.upload(in, npolys * kN);
+    uint64_t* dout = sc.get(npolys * kN);
+    if (!di || !dout) return fail("device allocation/upload failed");
+    launch_automorph(di, dout, (uint32_t)npolys, (uint32_t)t, 0);
+    HIP_OK(hipMemcpy(out, dout, npolys * kN * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int spiral_gpu_invert(uint64_t* out, const uint64_t* in, size_t npolys) {
+    Scratch sc;
+    uint64_t* di = sc.upload(in, npolys * kN);
+    if (!di) return fail("device allocation/upload failed");
+    launch_invert(di, di, (uint32_t)npolys, 0);
+    HIP_OK(hipMemcpy(out, di, npolys * kN * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int spiral_gpu_gadget_invert(uint64_t* out, const uint64_t* in, size_t mx, size_t rdim, size_t cols) {
+    if (rdim == 0 || mx % rdim) return fail("mx must be a multiple of rdim");
+    Scratch sc;
+    uint64_t* di = sc.upload(in, rdim * cols * kN);
+    uint64_t* dout = sc.get(mx * cols * kN);
+    if (!di || !dout) return fail("device allocation/upload failed");
+    launch_gadget_invert(di, dout, (uint32_t)mx, (uint32_t)rdim, (uint32_t)cols, 0);
+    HIP_OK(hipMemcpy(out, dout, mx * cols * kN * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int spiral_gpu_get_rescaled(uint64_t* out, const uint64_t* in, size_t n, uint64_t inp_mod, uint64_t out_mod) {
+    Scratch sc;
+    uint64_t* di = sc.upload(in, n);
+    if (!di) return fail("device allocation/upload failed");
+    launch_rescale(di, di, (uint32_t)n, inp_mod, out_mod, 0);
+    HIP_OK(hipMemcpy(out, di, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int spiral_gpu_multiply_query_by_database(uint64_t* output, const uint64_t* reorientedCiphertexts, const uint64_t* database, size_t dim0,
+                                          size_t num_per) {
+    if (dim0 == 0 || num_per == 0) return fail("empty geometry");
+    Scratch sc;
+    const size_t db_words = (size_t)kN * dim0 * num_per * 4;
+    uint64_t* d_ref = sc.upload(database, db_words);
+    uint64_t* d_db = sc.get(db_words);
+    uint64_t* d_re = sc.upload(reorientedCiphertexts, (size_t)kN * dim0 * 8);
+    uint64_t* d_qs = sc.get((size_t)kN * dim0 * 6);
+    uint64_t* d_acc = sc.get(num_per * 6 * kN);
+    if (!d_ref || !d_db || !d_re || !d_qs || !d_acc) return fail("device allocation/upload failed");
+    launch_db_relayout(d_ref, d_db, (uint32_t)num_per, (uint32_t)dim0, 0, (uint32_t)dim0, kN, 0);
+    launch_qs_from_reoriented(d_re, (uint32_t*)d_qs, (uint32_t)(2 * dim0), 0);
+    launch_sweep(d_db, (const uint32_t*)d_qs, d_acc, (uint32_t)num_per, (uint32_t)(2 * dim0), 0);
+    return download_pk(sc, d_acc, identity_map(), output, num_per * 6);
+}
+
+int spiral_gpu_split_and_crt(uint64_t* out, const uint64_t* in, size_t num_per, uint32_t t_gsw) {
+    DeviceTables tb;
+    if (current_tables(&tb)) return -1;
+    Scratch sc;
+    const uint32_t m2 = 3 * t_gsw;
+    uint64_t* di = sc.upload(in, num_per * 6 * kN);
+    uint64_t* dd = sc.get(num_per * 2 * m2 * 2 * kN);  // fold operand layout, only the low halves are filled
+    if (!di || !dd) return fail("device allocation/upload failed");
+    FwdParams fp{};
+    fp.src = di;
+    fp.dst = dd;
+    fp.src_map = identity_map();
+    fp.n_digits = t_gsw;
+    fp.bits = get_bits_per(t_gsw);
+    fp.ell = t_gsw;
+    fp.fold_np = (uint32_t)num_per;  // every ct index < num_per -> low half
+    launch_ntt_forward(tb, fp, LD_SDIGIT, ST_PK, (uint32_t)(num_per * 6 * t_gsw), 0);
+    // D[i][row][c] at (i*2*m2 + row)*2 + c  ->  reference [i][row][c]
+    return download_pk(sc, dd, IndexMap{2 * m2, 4 * m2, 0}, out, num_per * m2 * 2);
+}
+
+int spiral_gpu_fold_one_further_dimension(uint64_t* cts, size_t num_per, const uint64_t* query_ct, const uint64_t* query_ct_neg,
+                                          uint32_t t_gsw) {
+    DeviceTables tb;
+    if (current_tables(&tb)) return -1;
+    Scratch sc;
+    const uint32_t m2 = 3 * t_gsw;
+    uint64_t* d_cts = sc.upload(cts, 2 * num_per * 6 * kN);
+    uint64_t* d_q = sc.upload(query_ct, (size_t)kN * 3 * m2);
+    uint64_t* d_qn = sc.upload(query_ct_neg, (size_t)kN * 3 * m2);
+    uint64_t* d_key = sc.get((size_t)3 * 2 * m2 * kN);
+    uint64_t* d_d = sc.get(num_per * 2 * m2 * 2 * kN);
+    uint64_t* d_c = sc.get(num_per * 6 * kN);
+    if (!d_cts || !d_q || !d_qn || !d_key || !d_d || !d_c) return fail("device allocation/upload failed");
+    launch_fold_key_from_reoriented(d_q, d_qn, d_key, m2, 0);
+    FwdParams fp{};
+    fp.src = d_cts;
+    fp.dst = d_d;
+    fp.src_map = identity_map();
+    fp.n_digits = t_gsw;
+    fp.bits = get_bits_per(t_gsw);
+    fp.ell = t_gsw;
+    fp.fold_np = (uint32_t)num_per;
+    launch_ntt_forward(tb, fp, LD_SDIGIT, ST_PK, (uint32_t)(2 * num_per * 6 * t_gsw), 0);
+    MatmulParams mp{d_key, d_d, d_c, 3, 2 * m2, 2, 0, 2 * m2 * 2, 6};
+    launch_matmul(mp, (uint32_t)num_per, 0);
+    InvParams ip{};
+    ip.src = d_c;
+    ip.dst = d_cts;
+    ip.src_map = ip.dst_map = identity_map();
+    launch_ntt_inverse(tb, ip, IST_CRT, (uint32_t)(num_per * 6), 0);
+    HIP_OK(hipMemcpy(cts, d_cts, num_per * 6 * kN * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int spiral_gpu_expand_improved(uint64_t* cv_v, uint32_t g, uint32_t t_exp, const uint64_t* w_left, uint32_t t_exp_right,
+                               const uint64_t* w_right, uint32_t n_right, uint32_t max_bits_to_gen_right, uint32_t stopround) {
+    DeviceTables tb;
+    if (current_tables(&tb)) return -1;
+    if (g == 0 || g > kLogN) return fail("g out of range");
+    const uint32_t need_right = stopround ? stopround + 1 : g;
+    if (n_right < need_right) return fail("W_exp_right has %u matrices, %u needed", n_right, need_right);
+    Scratch sc;
+    const size_t ncv = (size_t)1 << g;
+    uint64_t* d_cv = upload_pk(sc, cv_v, ncv * 2);
+    uint64_t* d_wl = upload_pk(sc, w_left, (size_t)g * 2 * t_exp);
+    uint64_t* d_wr = upload_pk(sc, w_right, (size_t)n_right * 2 * t_exp_right);
+    ExpandWork wk{sc.get(ncv * 2 * kN), sc.get(expand_g_polys(g, t_exp, t_exp_right) * kN), sc.get(ncv * kN)};
+    if (!d_cv || !d_wl || !d_wr || !wk.raw || !wk.g || !wk.a1) return fail("device allocation/upload failed");
+    run_expand(tb, d_cv, g, t_exp, d_wl, t_exp_right, d_wr, max_bits_to_gen_right, stopround, wk, 0);
+    return download_pk(sc, d_cv, identity_map(), cv_v, ncv * 2);
+}
+
+int spiral_gpu_scal_to_mat(uint64_t* out, const uint64_t* cv, const uint64_t* w, uint32_t t_conv) {
+    DeviceTables tb;
+    if (current_tables(&tb)) return -1;
+    Scratch sc;
+    uint64_t* d_cv = upload_pk(sc, cv, 2);
+    uint64_t* d_w = upload_pk(sc, w, (size_t)3 * 2 * t_conv);
+    uint64_t* d_raw = sc.get(kN);
+    uint64_t* d_g = sc.get((size_t)t_conv * kN);
+    uint64_t* d_out = sc.get((size_t)6 * kN);
+    if (!d_cv || !d_w || !d_raw || !d_g || !d_out) return fail("device allocation/upload failed");
+    InvParams ip{};
+    ip.src = d_cv;
+    ip.dst = d_raw;
+    ip.src_map = ip.dst_map = identity_map();
+    launch_ntt_inverse(tb, ip, IST_CRT, 1, 0);
+    FwdParams fp{};
+    fp.src = d_raw;
+    fp.dst = d_g;
+    fp.src_map = fp.dst_map = identity_map();
+    fp.n_digits = t_conv;
+    fp.bits = get_bits_per(t_conv);
+    launch_ntt_forward(tb, fp, LD_DIGIT, ST_PK, t_conv, 0);
+    Scal2MatParams sp{};
+    sp.w = d_w;
+    sp.g = d_g;
+    sp.cv = d_cv;
+    sp.cv_pos = identity_map();
+    sp.out = d_out;
+    sp.t_conv = t_conv;
+    sp.count = 1;
+    launch_scal2mat(sp, 0);
+    return download_pk(sc, d_out, identity_map(), out, 6);
+}
+
+int spiral_gpu_regev_to_gsw(uint64_t* out, const uint64_t* cv_v, const uint64_t* w, const uint64_t* v, uint32_t t_conv, uint32_t ell) {
+    DeviceTables tb;
+    if (current_tables(&tb)) return -1;
+    Scratch sc;
+    uint64_t* d_cv = upload_pk(sc, cv_v, (size_t)ell * 2);
+    uint64_t* d_w = upload_pk(sc, w, (size_t)3 * 2 * t_conv);
+    uint64_t* d_v = upload_pk(sc, v, (size_t)3 * 2 * t_conv);
+    uint64_t* d_raw = sc.get((size_t)ell * 2 * kN);
+    uint64_t* d_chat = sc.get((size_t)ell * 2 * t_conv * kN);
+    uint64_t* d_gsw = sc.get((size_t)3 * 3 * ell * kN);
+    if (!d_cv || !d_w || !d_v || !d_raw || !d_chat || !d_gsw) return fail("device allocation/upload failed");
+    InvParams ip{};
+    ip.src = d_cv;
+    ip.dst = d_raw;
+    ip.src_map = ip.dst_map = identity_map();
+    launch_ntt_inverse(tb, ip, IST_CRT, 2 * ell, 0);
+    FwdParams fp{};
+    fp.src = d_raw;
+    fp.dst = d_chat;
+    fp.src_map = fp.dst_map = identity_map();
+    fp.n_digits = t_conv;
+    fp.bits = get_bits_per(t_conv);
+    launch_ntt_forward(tb, fp, LD_DIGIT, ST_PK, 2 * ell * t_conv, 0);
+    GswParams gp{};
+    gp.w = d_w;
+    gp.v = d_v;
+    gp.chat = d_chat;
+    gp.cv = d_cv;
+    gp.cv_pos = identity_map();
+    gp.gsw = d_gsw;
+    gp.t_conv = t_conv;
+    gp.ell = ell;
+    gp.dims = 1;
+    launch_regev_to_gsw(gp, 0);
+    return download_pk(sc, d_gsw, identity_map(), out, (size_t)9 * ell);
+}
+
+// ------------------------------------------------------------------------------------------------
+// resident server
+// ------------------------------------------------------------------------------------------------
+int spiral_gpu_server_create(const spiral_gpu_params* p, int device, uint32_t j_begin, uint32_t j_end, spiral_gpu_server** out) {
+    if (!p || !out) return fail("null argument");
+    spiral_gpu_shape s;
+    if (shape_of(p, &s)) return -1;
+    if (j_end == 0 && j_begin == 0) j_end = s.dim0;
+    if (j_begin >= j_end || j_end > s.dim0) return fail("bad first-dimension shard [%u, %u) of %u", j_begin, j_end, s.dim0);
+    HIP_OK(hipSetDevice(device));
+    spiral_gpu_server* S = new spiral_gpu_server();
+    S->p = *p;
+    S->s = s;
+    S->device = device;
+    S->j0 = j_begin;
+    S->j1 = j_end;
+    S->dim0_shard = j_end - j_begin;
+    if (p->direct_upload || s.stopround == 0) {
+        S->pos_stride = 1;
+        S->pos_first = 0;
+        S->pos_rest = s.dim0;
+    } else {  // reorderFromStopround (src/spiral.cpp:2027-2036): even slots, then odd slots
+        S->pos_stride = 2;
+        S->pos_first = 0;
+        S->pos_rest = 1;
+    }
+    if (tables_get(device, &S->tb) != 0) {
+        delete S;
+        return fail("twiddle table setup failed on device %d", device);
+    }
+    if (hipStreamCreate(&S->own_stream) != hipSuccess) {
+        delete S;
+        return fail("hipStreamCreate failed");
+    }
+    S->stream = S->own_stream;
+    for (auto& e : S->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            srv_free(S);
+            delete S;
+            return fail("hipEventCreate failed");
+        }
+    if (srv_alloc(S)) {
+        srv_free(S);
+        delete S;
+        return -1;
+    }
+    *out = S;
+    return 0;
+}
+
+void spiral_gpu_server_destroy(spiral_gpu_server* S) {
+    if (!S) return;
+    (void)hipSetDevice(S->device);
+    (void)hipDeviceSynchronize();
+    srv_free(S);
+    delete S;
+}
+
+int spiral_gpu_server_set_stream(spiral_gpu_server* S, void* hip_stream) {
+    if (!S) return fail("null server");
+    S->stream = hip_stream ? (hipStream_t)hip_stream : S->own_stream;
+    return 0;
+}
+
+int spiral_gpu_server_load_db(spiral_gpu_server* S, const uint64_t* database) {
+    if (!S || !database) return fail("null argument");
+    HIP_OK(hipSetDevice(S->device));
+    // stage the reference-layout database one z-slab group at a time and re-lay the shard
+    const size_t per_z_ref = (size_t)S->s.num_per * 2 * S->s.dim0 * 2;
+    const size_t per_z_dev = (size_t)S->dim0_shard * 2 * S->s.num_per * 2;
+    const uint32_t zchunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(kN, ((size_t)64 << 20) / per_z_ref));
+    DevBuf st;
+    if (st.alloc(per_z_ref * zchunk)) return -1;
+    for (uint32_t z = 0; z < kN; z += zchunk) {
+        const uint32_t nz = std::min(zchunk, kN - z);
+        if (hipMemcpyAsync(st.p, database + (size_t)z * per_z_ref, (size_t)nz * per_z_ref * sizeof(uint64_t), hipMemcpyHostToDevice, S->stream) !=
+            hipSuccess) {
+            st.release();
+            return fail("database upload failed");
+        }
+        launch_db_relayout(st.p, S->db.p + (size_t)z * per_z_dev, S->s.num_per, S->s.dim0, S->j0, S->dim0_shard, nz, S->stream);
+        if (hipStreamSynchronize(S->stream) != hipSuccess) {
+            st.release();
+            return fail("database relayout failed");
+        }
+    }
+    st.release();
+    S->have_db = true;
+    return 0;
+}
+
+int spiral_gpu_server_gen_db(spiral_gpu_server* S, uint64_t seed) {
+    if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
+    FwdParams fp{};
+    fp.dst = S->db.p;
+    fp.src_map = fp.dst_map = identity_map();
+    fp.n_digits = 1;
+    fp.seed = seed;
+    fp.p_db = S->p.p_db;
+    fp.num_per = S->s.num_per;
+    fp.dim0_shard = S->dim0_shard;
+    fp.j0 = S->j0;
+    const uint64_t items = (uint64_t)S->dim0_shard * S->s.num_per, first = (uint64_t)S->j0 * S->s.num_per;
+    const uint64_t chunk = 1u << 16;  // items per launch (4 polynomials each)
+    for (uint64_t done = 0; done < items; done += chunk) {
+        fp.item_base = first + done;
+        launch_ntt_forward(S->tb, fp, LD_DBGEN, ST_DB, (uint32_t)(std::min(chunk, items - done) * 4), S->stream);
+    }
+    HIP_OK(hipStreamSynchronize(S->stream));
+    S->have_db = true;
+    return 0;
+}
+
+int spiral_gpu_server_fill_db_random(spiral_gpu_server* S, uint64_t seed) {
+    if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
+    launch_fill_db_random(S->db.p, S->db.words, seed, S->stream);
+    HIP_OK(hipStreamSynchronize(S->stream));
+    S->have_db = true;
+    return 0;
+}
+
+int spiral_gpu_server_set_pub_params(spiral_gpu_server* S, const uint64_t* w_left, const uint64_t* w_right, const uint64_t* w,
+                                     const uint64_t* v) {
+    if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
+    const spiral_gpu_params& p = S->p;
+    if (upload_ref_ntt(S, w_left, S->w_left.p, (size_t)S->s.n_left * 2 * p.t_exp)) return -1;
+    if (upload_ref_ntt(S, w_right, S->w_right.p, (size_t)S->s.n_right * 2 * p.t_exp_right)) return -1;
+    if (upload_ref_ntt(S, w, S->w.p, (size_t)3 * 2 * p.t_conv)) return -1;
+    if (upload_ref_ntt(S, v, S->v.p, (size_t)3 * 2 * p.t_conv)) return -1;
+    S->have_pp = true;
+    return 0;
+}
+
+int spiral_gpu_server_set_query(spiral_gpu_server* S, const uint64_t* query) {
+    if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
+    if (upload_ref_ntt(S, query, S->query.p, (size_t)S->s.n_query_cts * 2)) return -1;
+    S->have_query = true;
+    return 0;
+}
+
+int spiral_gpu_server_expand(spiral_gpu_server* S) {
+    if (!S) return fail("null server");
+    if (!S->have_query || !S->have_pp) return fail("query and public parameters must be set before expand");
+    const spiral_gpu_params& p = S->p;
+    if (p.direct_upload) {
+        HIP_OK(hipMemcpyAsync(S->cv.p, S->query.p, (size_t)S->s.n_bits * 2 * kPolyBytes, hipMemcpyDeviceToDevice, S->stream));
+        return 0;
+    }
+    HIP_OK(hipMemcpyAsync(S->cv.p, S->query.p, 2 * kPolyBytes, hipMemcpyDeviceToDevice, S->stream));
+    ExpandWork wk{S->ex_raw.p, S->ex_g.p, S->ex_a1.p};
+    run_expand(S->tb, S->cv.p, S->s.g, p.t_exp, S->w_left.p, p.t_exp_right, S->w_right.p, S->s.ell * p.nu2, S->s.stopround, wk, S->stream);
+    return 0;
+}
+
+int spiral_gpu_server_convert(spiral_gpu_server* S) {
+    if (!S) return fail("null server");
+    const spiral_gpu_params& p = S->p;
+    const spiral_gpu_shape& s = S->s;
+    hipStream_t st = S->stream;
+    const uint32_t ps = S->pos_stride;
+    // ---- scalToMat for this shard's first-dimension ciphertexts (src/spiral.cpp:2230-2253)
+    {
+        InvParams ip{};
+        ip.src = S->cv.p;
+        ip.dst = S->cv_raw.p;
+        ip.src_map = IndexMap{1, 2 * ps, 2 * (S->j0 * ps + S->pos_first)};  // row 0 of ct pos(j0 + a)
+        ip.dst_map = identity_map();
+        launch_ntt_inverse(S->tb, ip, IST_CRT, S->dim0_shard, st);
+        FwdParams fp{};
+        fp.src = S->cv_raw.p;
+        fp.dst = S->cv_g.p;
+        fp.src_map = fp.dst_map = identity_map();
+        fp.n_digits = p.t_conv;
+        fp.bits = get_bits_per(p.t_conv);
+        launch_ntt_forward(S->tb, fp, LD_DIGIT, ST_PK, S->dim0_shard * p.t_conv, st);
+        Scal2MatParams sp{};
+        sp.w = S->w.p;
+        sp.g = S->cv_g.p;
+        sp.cv = S->cv.p;
+        sp.cv_pos = IndexMap{1, ps, S->j0 * ps + S->pos_first};
+        sp.out = S->keep_cts ? S->cts_keep.p : nullptr;
+        sp.qs = (uint32_t*)S->qs.p;
+        sp.t_conv = p.t_conv;
+        sp.count = S->dim0_shard;
+        sp.jm_total = 2 * S->dim0_shard;
+        sp.j_base = 0;
+        launch_scal2mat(sp, st);
+    }
+    // ---- regevToGSW for the nu2 further dimensions + fold keys (src/spiral.cpp:2315-2331, 2361-2386)
+    if (p.nu2) {
+        const uint32_t ngs = p.nu2 * s.ell;
+        InvParams ip{};
+        ip.src = S->cv.p;
+        ip.dst = S->gs_raw.p;
+        ip.src_map = IndexMap{2, 2 * ps, 2 * S->pos_rest};
+        ip.dst_map = identity_map();
+        launch_ntt_inverse(S->tb, ip, IST_CRT, 2 * ngs, st);
+        FwdParams fp{};
+        fp.src = S->gs_raw.p;
+        fp.dst = S->gs_chat.p;
+        fp.src_map = fp.dst_map = identity_map();
+        fp.n_digits = p.t_conv;
+        fp.bits = get_bits_per(p.t_conv);
+        launch_ntt_forward(S->tb, fp, LD_DIGIT, ST_PK, 2 * ngs * p.t_conv, st);
+        GswParams gp{};
+        gp.w = S->w.p;
+        gp.v = S->v.p;
+        gp.chat = S->gs_chat.p;
+        gp.cv = S->cv.p;
+        gp.cv_pos = IndexMap{1, ps, S->pos_rest};
+        gp.gsw = S->gsw.p;
+        gp.t_conv = p.t_conv;
+        gp.ell = s.ell;
+        gp.dims = p.nu2;
+        launch_regev_to_gsw(gp, st);
+        launch_fold_key(S->gsw.p, S->key.p, p.nu2, s.ell, st);
+    }
+    return 0;
+}
+
+int spiral_gpu_server_first_dim(spiral_gpu_server* S) {
+    if (!S) return fail("null server");
+    if (!S->have_db) return fail("no database loaded");
+    launch_sweep(S->db.p, (const uint32_t*)S->qs.p, S->acc, S->s.num_per, 2 * S->dim0_shard, S->stream);
+    return 0;
+}
+
+int spiral_gpu_server_lift(spiral_gpu_server* S, int reduce_first) {
+    if (!S) return fail("null server");
+    InvParams ip{};
+    ip.src = S->acc;
+    ip.dst = S->raw.p;
+    ip.src_map = ip.dst_map = identity_map();
+    ip.pre_reduce = reduce_first ? 1 : 0;
+    launch_ntt_inverse(S->tb, ip, IST_CRT, S->s.num_per * 6, S->stream);
+    return 0;
+}
+
+int spiral_gpu_server_fold(spiral_gpu_server* S) {
+    if (!S) return fail("null server");
+    const spiral_gpu_shape& s = S->s;
+    uint32_t np = s.num_per, d = 0;
+    while (np >= 2) {  // src/spiral.cpp:1622-1626
+        np /= 2;
+        FwdParams fp{};
+        fp.src = S->raw.p;
+        fp.dst = S->fold_d.p;
+        fp.src_map = identity_map();
+        fp.n_digits = s.ell;
+        fp.bits = get_bits_per(s.ell);
+        fp.ell = s.ell;
+        fp.fold_np = np;
+        launch_ntt_forward(S->tb, fp, LD_SDIGIT, ST_PK, 2 * np * 6 * s.ell, S->stream);
+        MatmulParams mp{S->key.p + (size_t)d * 3 * 2 * s.m2 * kN, S->fold_d.p, S->fold_c.p, 3, 2 * s.m2, 2, 0, 2 * s.m2 * 2, 6};
+        launch_matmul(mp, np, S->stream);
+        InvParams ip{};
+        ip.src = S->fold_c.p;
+        ip.dst = S->raw.p;
+        ip.src_map = ip.dst_map = identity_map();
+        launch_ntt_inverse(S->tb, ip, IST_CRT, np * 6, S->stream);
+        d++;
+    }
+    return 0;
+}
+
+int spiral_gpu_server_finish(spiral_gpu_server* S) {
+    if (!S) return fail("null server");
+    // row 0 -> q', rows 1.. -> 4*p_db (src/spiral.cpp:1441-1447)
+    launch_rescale(S->raw.p, S->resp.p, 2 * kN, kQ, S->s.qprime, S->stream);
+    launch_rescale(S->raw.p + 2 * kN, S->resp.p + 2 * kN, 4 * kN, kQ, 4 * S->p.p_db, S->stream);
+    return 0;
+}
+
+int spiral_gpu_server_sync(spiral_gpu_server* S) {
+    if (!S) return fail("null server");
+    HIP_OK(hipStreamSynchronize(S->stream));
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+void* spiral_gpu_server_acc(spiral_gpu_server* S, size_t* bytes) {
+    if (!S) return nullptr;
+    if (bytes) *bytes = (size_t)S->s.num_per * 6 * kPolyBytes;
+    return S->acc;
+}
+
+int spiral_gpu_server_set_acc(spiral_gpu_server* S, void* device_ptr) {
+    if (!S) return fail("null server");
+    S->acc = device_ptr ? (uint64_t*)device_ptr : S->acc_own.p;
+    return 0;
+}
+
+int spiral_gpu_server_answer_resident(spiral_gpu_server* S, double stage_us[8]) {
+    if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
+    hipStream_t st = S->stream;
+    HIP_OK(hipEventRecord(S->ev[0], st));
+    if (spiral_gpu_server_expand(S)) return -1;
+    HIP_OK(hipEventRecord(S->ev[1], st));
+    if (spiral_gpu_server_convert(S)) return -1;
+    HIP_OK(hipEventRecord(S->ev[2], st));
+    if (spiral_gpu_server_first_dim(S)) return -1;
+    HIP_OK(hipEventRecord(S->ev[3], st));
+    if (spiral_gpu_server_lift(S, 0)) return -1;
+    HIP_OK(hipEventRecord(S->ev[4], st));
+    if (spiral_gpu_server_fold(S)) return -1;
+    HIP_OK(hipEventRecord(S->ev[5], st));
+    if (spiral_gpu_server_finish(S)) return -1;
+    HIP_OK(hipEventRecord(S->ev[6], st));
+    HIP_OK(hipStreamSynchronize(st));
+    HIP_OK(hipGetLastError());
+    if (stage_us) {
+        float ms[6];
+        for (int i = 0; i < 6; i++) HIP_OK(hipEventElapsedTime(&ms[i], S->ev[i], S->ev[i + 1]));
+        float total = 0;
+        HIP_OK(hipEventElapsedTime(&total, S->ev[0], S->ev[6]));
+        stage_us[0] = ms[0] * 1e3;
+        stage_us[1] = ms[1] * 1e3;
+        stage_us[2] = (ms[2] + ms[3]) * 1e3;
+        stage_us[3] = ms[4] * 1e3;
+        stage_us[4] = ms[5] * 1e3;
+        stage_us[5] = ms[2] * 1e3;
+        stage_us[6] = total * 1e3;
+        stage_us[7] = 0;
+    }
+    return 0;
+}
+
+int spiral_gpu_server_answer(spiral_gpu_server* S, const uint64_t* query, uint64_t* final_ct, uint64_t* response, double stage_us[8]) {
+    if (!S) return fail("null server");
+    if (spiral_gpu_server_set_query(S, query)) return -1;
+    if (spiral_gpu_server_answer_resident(S, stage_us)) return -1;
+    if (final_ct) HIP_OK(hipMemcpy(final_ct, S->raw.p, 6 * kPolyBytes, hipMemcpyDeviceToHost));
+    if (response) HIP_OK(hipMemcpy(response, S->resp.p, 6 * kPolyBytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int spiral_gpu_server_keep_cts(spiral_gpu_server* S, int on) {
+    if (!S) return fail("null server");
+    if (on && !S->cts_keep.p) {
+        HIP_OK(hipSetDevice(S->device));
+        if (S->cts_keep.alloc((size_t)S->dim0_shard * 6 * kN)) return -1;
+    }
+    S->keep_cts = on != 0;
+    return 0;
+}
+
+size_t spiral_gpu_server_buffer_words(spiral_gpu_server* S, int which) {
+    if (!S) return 0;
+    const spiral_gpu_shape& s = S->s;
+    switch (which) {
+        case SPIRAL_GPU_BUF_EXPANDED: return (size_t)s.n_bits * 2 * kRefNtt;
+        case SPIRAL_GPU_BUF_CTS: return (size_t)S->dim0_shard * 6 * kRefNtt;
+        case SPIRAL_GPU_BUF_GSW: return (size_t)S->p.nu2 * 3 * s.m2 * kRefNtt;
+        case SPIRAL_GPU_BUF_ACC: return (size_t)s.num_per * 6 * kRefNtt;
+        case SPIRAL_GPU_BUF_RAW: return (size_t)s.num_per * 6 * kN;
+        case SPIRAL_GPU_BUF_FINAL: return (size_t)6 * kN;
+        case SPIRAL_GPU_BUF_RESPONSE: return (size_t)6 * kN;
+        default: return 0;
+    }
+}
+
+int spiral_gpu_server_read(spiral_gpu_server* S, int which, uint64_t* out) {
+    if (!S || !out) return fail("null argument");
+    HIP_OK(hipSetDevice(S->device));
+    HIP_OK(hipStreamSynchronize(S->stream));
+    const spiral_gpu_shape& s = S->s;
+    const uint32_t ps = S->pos_stride;
+    switch (which) {
+        case SPIRAL_GPU_BUF_EXPANDED: {
+            // first dim0 cts, then the ell*nu2 conversion inputs, each 2 polys
+            if (download_pk_as_ref(S, S->cv.p, IndexMap{2, 2 * ps, 2 * S->pos_first}, out, (size_t)s.dim0 * 2)) return -1;
+            return download_pk_as_ref(S, S->cv.p, IndexMap{2, 2 * ps, 2 * S->pos_rest}, out + (size_t)s.dim0 * 2 * kRefNtt,
+                                      (size_t)s.ell * S->p.nu2 * 2);
+        }
+        case SPIRAL_GPU_BUF_CTS:
+            if (!S->keep_cts) return fail("keep_cts is off");
+            return download_pk_as_ref(S, S->cts_keep.p, identity_map(), out, (size_t)S->dim0_shard * 6);
+        case SPIRAL_GPU_BUF_GSW: return download_pk_as_ref(S, S->gsw.p, identity_map(), out, (size_t)S->p.nu2 * 3 * s.m2);
+        case SPIRAL_GPU_BUF_ACC: return download_pk_as_ref(S, S->acc, identity_map(), out, (size_t)s.num_per * 6);
+        case SPIRAL_GPU_BUF_RAW: HIP_OK(hipMemcpy(out, S->raw.p, (size_t)s.num_per * 6 * kPolyBytes, hipMemcpyDeviceToHost)); return 0;
+        case SPIRAL_GPU_BUF_FINAL: HIP_OK(hipMemcpy(out, S->raw.p, 6 * kPolyBytes, hipMemcpyDeviceToHost)); return 0;
+        case SPIRAL_GPU_BUF_RESPONSE: HIP_OK(hipMemcpy(out, S->resp.p, 6 * kPolyBytes, hipMemcpyDeviceToHost)); return 0;
+        default: return fail("unknown buffer %d", which);
+    }
+}
+
+int spiral_gpu_server_write_raw(spiral_gpu_server* S, const uint64_t* raw_cts) {
+    if (!S || !raw_cts) return fail("null argument");
+    HIP_OK(hipSetDevice(S->device));
+    HIP_OK(hipMemcpy(S->raw.p, raw_cts, (size_t)S->s.num_per * 6 * kPolyBytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int spiral_gpu_server_time_sweep(spiral_gpu_server* S, int iters, float* avg_ms) {
+    if (!S || !avg_ms || iters <= 0) return fail("bad argument");
+    if (!S->have_db) return fail("no database loaded");
+    HIP_OK(hipSetDevice(S->device));
+    HIP_OK(hipEventRecord(S->ev[0], S->stream));
+    for (int i = 0; i < iters; i++) launch_sweep(S->db.p, (const uint32_t*)S->qs.p, S->acc, S->s.num_per, 2 * S->dim0_shard, S->stream);
+    HIP_OK(hipEventRecord(S->ev[1], S->stream));
+    HIP_OK(hipStreamSynchronize(S->stream));
+    float ms = 0;
+    HIP_OK(hipEventElapsedTime(&ms, S->ev[0], S->ev[1]));
+    *avg_ms = ms / iters;
+    return 0;
+}
+
+uint64_t spiral_gpu_server_sweep_bytes(spiral_gpu_server* S) {
+    if (!S) return 0;
+    // SURVEY.md 8d at 8 B per packed word: database + packed query (3 rows x 2 x dim0) + output (2 limbs as u64)
+    const uint64_t n = kN;
+    return (uint64_t)S->dim0_shard * S->s.num_per * 4 * n * 8 + (uint64_t)S->dim0_shard * 3 * 2 * n * 8 + (uint64_t)S->s.num_per * 6 * 2 * n * 8;
+}
+
+}  // extern "C"

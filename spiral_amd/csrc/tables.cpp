@@ -1,0 +1,91 @@
+// Twiddle tables for the two CRT primes, regenerated from the minimal primitive 4096-th roots of unity
+// (psi_p = 66687, psi_b = 158221) instead of copying the reference's 436 KB blob (src/constants.cpp:16).
+// Layout and scaling follow src/core.cpp:6-17: fwd[bitrev11(i)] = psi^i, inv[bitrev11(i)] = psi^-i / 2,
+// scaled companion W' = floor(W * 2^32 / m).  tests/test_oracle_tables.py + test_capi_cpu.py pin the
+// result to the reference's data via tests/golden/ntt_tables.json.
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace spiral {
+
+static uint64_t powmod(uint64_t b, uint64_t e, uint64_t m) {
+    unsigned __int128 r = 1, x = b % m;
+    while (e) {
+        if (e & 1) r = r * x % m;
+        x = x * x % m;
+        e >>= 1;
+    }
+    return (uint64_t)r;
+}
+static uint32_t bitrev11(uint32_t x) {
+    uint32_t r = 0;
+    for (uint32_t i = 0; i < kLogN; i++) r |= ((x >> i) & 1u) << (kLogN - 1 - i);
+    return r;
+}
+
+// rows in the reference's order: [inv p W][inv p W'][inv b W][inv b W'][fwd p W][fwd p W'][fwd b W][fwd b W']
+void tables_host_rows(uint64_t* out) {
+    const uint64_t mods[2] = {kP, kB}, psis[2] = {66687, 158221};
+    for (int n = 0; n < 2; n++) {
+        uint64_t m = mods[n], psi = psis[n], ipsi = powmod(psi, 2 * kN - 1, m);
+        uint64_t f = 1, v = (m + 1) / 2;
+        for (uint32_t i = 0; i < kN; i++) {
+            uint32_t k = bitrev11(i);
+            out[(4 + 2 * n) * kN + k] = f;
+            out[(5 + 2 * n) * kN + k] = (f << 32) / m;
+            out[(0 + 2 * n) * kN + k] = v;
+            out[(1 + 2 * n) * kN + k] = (v << 32) / m;
+            f = (uint64_t)((unsigned __int128)f * psi % m);
+            v = (uint64_t)((unsigned __int128)v * ipsi % m);
+        }
+    }
+}
+
+static std::mutex g_mu;
+static DeviceTables g_tables[16];
+static bool g_ready[16];
+
+int tables_get(int device, DeviceTables* out) {
+    if (device < 0 || device >= 16) return -1;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_ready[device]) {
+        std::vector<uint64_t> rows(8 * kN);
+        tables_host_rows(rows.data());
+        std::vector<uint4> fwd(kN), inv(kN);
+        for (uint32_t i = 0; i < kN; i++) {
+            fwd[i] = make_uint4((uint32_t)rows[4 * kN + i], (uint32_t)rows[5 * kN + i], (uint32_t)rows[6 * kN + i], (uint32_t)rows[7 * kN + i]);
+            inv[i] = make_uint4((uint32_t)rows[0 * kN + i], (uint32_t)rows[1 * kN + i], (uint32_t)rows[2 * kN + i], (uint32_t)rows[3 * kN + i]);
+        }
+        DeviceTables t;
+        if (hipSetDevice(device) != hipSuccess) return -1;
+        if (hipMalloc(&t.fwd, kN * sizeof(uint4)) != hipSuccess) return -1;
+        if (hipMalloc(&t.inv, kN * sizeof(uint4)) != hipSuccess) return -1;
+        if (hipMalloc(&t.neg1, (size_t)kLogN * kN * sizeof(uint64_t)) != hipSuccess) return -1;
+        if (hipMemcpy(t.fwd, fwd.data(), kN * sizeof(uint4), hipMemcpyHostToDevice) != hipSuccess) return -1;
+        if (hipMemcpy(t.inv, inv.data(), kN * sizeof(uint4), hipMemcpyHostToDevice) != hipSuccess) return -1;
+        // neg1[r] = NTT(-x^(N - 2^r)) (src/spiral.cpp:171-190): raw polynomial with Q-1 at N-2^r
+        std::vector<uint64_t> raw((size_t)kLogN * kN, 0);
+        for (uint32_t r = 0; r < kLogN; r++) raw[(size_t)r * kN + (kN - (1u << r))] = kQ - 1;
+        uint64_t* d_raw = nullptr;
+        if (hipMalloc(&d_raw, raw.size() * sizeof(uint64_t)) != hipSuccess) return -1;
+        if (hipMemcpy(d_raw, raw.data(), raw.size() * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) return -1;
+        FwdParams p{};
+        p.src = d_raw;
+        p.dst = t.neg1;
+        p.src_map = identity_map();
+        p.dst_map = identity_map();
+        p.n_digits = 1;
+        launch_ntt_forward(t, p, LD_RAW, ST_PK, kLogN, 0);
+        if (hipDeviceSynchronize() != hipSuccess) return -1;
+        (void)hipFree(d_raw);
+        g_tables[device] = t;
+        g_ready[device] = true;
+    }
+    *out = g_tables[device];
+    return 0;
+}
+
+}  // namespace spiral

@@ -1,0 +1,133 @@
+"""Resident server handle: the server half of do_test (src/spiral.cpp:2337-2406, 1584-1629) with the
+database, public parameters and intermediates kept in HBM."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import U64P, Params, Shape, check, lib
+
+N = 2048
+
+BUF_EXPANDED, BUF_CTS, BUF_GSW, BUF_ACC, BUF_RAW, BUF_FINAL, BUF_RESPONSE = range(7)
+STAGE_NAMES = ["expansion_us", "conversion_us", "first_dim_us", "folding_us", "response_us", "sweep_kernel_us", "total_us", "reserved"]
+
+
+def _p(a: np.ndarray):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(U64P)
+
+
+class Server:
+    def __init__(self, params: Params, device: int = 0, j_begin: int = 0, j_end: int = 0):
+        self.params = params
+        self.shape = Shape()
+        check(lib().spiral_gpu_get_shape(C.byref(params), C.byref(self.shape)))
+        h = C.c_void_p()
+        check(lib().spiral_gpu_server_create(C.byref(params), device, j_begin, j_end, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().spiral_gpu_server_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- inputs ----
+    def set_stream(self, stream_ptr: int):
+        check(lib().spiral_gpu_server_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def load_db(self, database: np.ndarray):
+        check(lib().spiral_gpu_server_load_db(self.h, _p(np.ascontiguousarray(database, dtype=np.uint64))))
+
+    def gen_db(self, seed: int):
+        check(lib().spiral_gpu_server_gen_db(self.h, seed))
+
+    def fill_db_random(self, seed: int):
+        check(lib().spiral_gpu_server_fill_db_random(self.h, seed))
+
+    def set_pub_params(self, w_left, w_right, w, v):
+        check(lib().spiral_gpu_server_set_pub_params(self.h, _p(w_left), _p(w_right), _p(w), _p(v)))
+
+    def set_query(self, query):
+        check(lib().spiral_gpu_server_set_query(self.h, _p(np.ascontiguousarray(query, dtype=np.uint64))))
+
+    # ---- stages ----
+    def expand(self):
+        check(lib().spiral_gpu_server_expand(self.h))
+
+    def convert(self):
+        check(lib().spiral_gpu_server_convert(self.h))
+
+    def first_dim(self):
+        check(lib().spiral_gpu_server_first_dim(self.h))
+
+    def lift(self, reduce_first: bool = False):
+        check(lib().spiral_gpu_server_lift(self.h, 1 if reduce_first else 0))
+
+    def fold(self):
+        check(lib().spiral_gpu_server_fold(self.h))
+
+    def finish(self):
+        check(lib().spiral_gpu_server_finish(self.h))
+
+    def sync(self):
+        check(lib().spiral_gpu_server_sync(self.h))
+
+    def acc(self):
+        nbytes = C.c_size_t()
+        ptr = lib().spiral_gpu_server_acc(self.h, C.byref(nbytes))
+        return ptr, nbytes.value
+
+    def set_acc(self, device_ptr: int):
+        check(lib().spiral_gpu_server_set_acc(self.h, C.c_void_p(device_ptr)))
+
+    def answer(self, query):
+        """process_crtd_query on one query -> (final raw ct n1 x n2, response, stage times in us)"""
+        fin = np.zeros((3, 2, N), dtype=np.uint64)
+        resp = np.zeros((3, 2, N), dtype=np.uint64)
+        us = (C.c_double * 8)()
+        check(lib().spiral_gpu_server_answer(self.h, _p(np.ascontiguousarray(query, dtype=np.uint64)), _p(fin), _p(resp), us))
+        return fin, resp, dict(zip(STAGE_NAMES, list(us)))
+
+    def answer_resident(self):
+        us = (C.c_double * 8)()
+        check(lib().spiral_gpu_server_answer_resident(self.h, us))
+        return dict(zip(STAGE_NAMES, list(us)))
+
+    # ---- introspection ----
+    def keep_cts(self, on: bool = True):
+        check(lib().spiral_gpu_server_keep_cts(self.h, 1 if on else 0))
+
+    def read(self, which: int) -> np.ndarray:
+        words = lib().spiral_gpu_server_buffer_words(self.h, which)
+        out = np.zeros(words, dtype=np.uint64)
+        check(lib().spiral_gpu_server_read(self.h, which, _p(out)))
+        s, p = self.shape, self.params
+        shapes = {
+            BUF_EXPANDED: (s.n_bits, 2, 2, N),
+            BUF_CTS: (-1, 3, 2, 2, N),
+            BUF_GSW: (p.nu2, 3, s.m2, 2, N),
+            BUF_ACC: (s.num_per, 3, 2, 2, N),
+            BUF_RAW: (s.num_per, 3, 2, N),
+            BUF_FINAL: (3, 2, N),
+            BUF_RESPONSE: (3, 2, N),
+        }
+        return out.reshape(shapes[which])
+
+    def write_raw(self, raw_cts):
+        check(lib().spiral_gpu_server_write_raw(self.h, _p(np.ascontiguousarray(raw_cts, dtype=np.uint64))))
+
+    def time_sweep(self, iters: int = 20) -> float:
+        ms = C.c_float()
+        check(lib().spiral_gpu_server_time_sweep(self.h, iters, C.byref(ms)))
+        return ms.value
+
+    def sweep_bytes(self) -> int:
+        return int(lib().spiral_gpu_server_sweep_bytes(self.h))

@@ -1,0 +1,88 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/spiral_gpu.h declares,
+its host-only entry points agree with the reference's data, and compute entry points fail loudly
+without a GPU (no CPU fallback)."""
+import ctypes as C
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def sa():
+    import spiral_amd
+
+    spiral_amd.build()
+    return spiral_amd
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "spiral_gpu.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(spiral_gpu_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol(sa):
+    from spiral_amd import _lib
+
+    syms = declared_symbols()
+    assert len(syms) >= 45
+    raw = C.CDLL(_lib.LIB_PATH)
+    for name in syms:
+        assert hasattr(raw, name), f"{name} declared in include/spiral_gpu.h but not exported"
+    # and the Python binding declares a prototype for each of them
+    assert sorted(_lib.PROTOTYPES) == syms
+
+
+def test_abi_version_and_shape(sa):
+    assert sa.lib().spiral_gpu_abi_version() == 1
+    s = sa.get_shape(sa.make_params(8, 7))  # config 2 of BASELINE.json, SURVEY.md section 8 header
+    assert (s.dim0, s.num_per, s.m2, s.g, s.stopround, s.n_right, s.n_bits, s.qprime) == (256, 128, 24, 9, 6, 7, 312, 786433)
+    s = sa.get_shape(sa.make_params(11, 9, t_gsw=4, t_conv=56, t_exp=2, qprime_bits=27, p_db=32768, direct_upload=1))
+    assert (s.g, s.n_left, s.n_right, s.n_query_cts) == (0, 0, 0, 2048 + 36)
+    with pytest.raises(sa.SpiralGpuError):
+        sa.get_shape(sa.make_params(8, 7, qprime_bits=5))
+
+
+def test_tables_match_reference_data(sa):
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "ntt_tables.json")))
+    names = ["inv_p_w", "inv_p_wscaled", "inv_b_w", "inv_b_wscaled", "fwd_p_w", "fwd_p_wscaled", "fwd_b_w", "fwd_b_wscaled"]
+    t = sa.get_tables()
+    for r, name in enumerate(names):
+        assert hashlib.sha256(np.ascontiguousarray(t[r], dtype="<u8").tobytes()).hexdigest() == gold["rows"][name]["sha256"]
+
+
+def test_shapes_agree_with_oracle(sa, oracle):
+    for nu1, nu2, kw in [(2, 1, {}), (4, 2, dict(t_gsw=4)), (8, 7, {}), (9, 10, dict(t_gsw=10, qprime_bits=22)),
+                         (5, 2, dict(t_gsw=5, t_exp=2, qprime_bits=19, direct_upload=1))]:
+        a = sa.get_shape(sa.make_params(nu1, nu2, **kw))
+        b = oracle.shape_of(oracle.make_params(nu1, nu2, **kw))
+        for f, _ in a._fields_:
+            assert getattr(a, f) == getattr(b, f), f
+
+
+def test_compute_fails_loudly_without_gpu(sa):
+    if sa.lib().spiral_gpu_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(sa.SpiralGpuError):
+        sa.ntt_forward(np.zeros((2, 2048), dtype=np.uint64))
+    with pytest.raises(sa.SpiralGpuError):
+        sa.Server(sa.make_params(2, 1))
+
+
+def test_product_never_imports_the_oracle():
+    """the oracle is test infrastructure: nothing under spiral_amd/ or include/ may reference it"""
+    bad = []
+    for base in ("spiral_amd", "include"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith((".py", ".cpp", ".hip", ".h", ".cuh", "Makefile")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"liboracle|pyoracle|spiral_oracle|orc_", txt):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad

@@ -1,0 +1,305 @@
+"""GPU parity tests: every seam of the C ABI against the oracle on the same seeded inputs.
+Bit-exact: the whole path is unsigned integer arithmetic (raw-domain values compared verbatim,
+NTT-domain values compared as canonical residues, SURVEY.md section 8c hazard 1)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N = 2048
+
+
+@pytest.fixture(scope="module")
+def sa():
+    import spiral_amd
+
+    assert spiral_amd.lib().spiral_gpu_device_count() > 0, "GPU tests need a device"
+    return spiral_amd
+
+
+def rand_ntt(rng, O, shape):
+    """random canonical NTT-form polys, shape + (2, N)"""
+    return np.stack([rng.integers(0, m, size=shape + (N,), dtype=np.uint64) for m in (O.P, O.B)], axis=-2)
+
+
+def canon(O, a):
+    a = a.copy()
+    a[..., 0, :] %= O.P
+    a[..., 1, :] %= O.B
+    return a
+
+
+def assert_eq(got, exp, what):
+    if not (got.shape == exp.shape and (got == exp).all()):
+        bad = np.argwhere(got != exp)
+        raise AssertionError(f"{what}: {len(bad)} of {got.size} words differ, first at {bad[:5].tolist()}: got {got[tuple(bad[0])]}, exp {exp[tuple(bad[0])]}")
+
+
+# ---- L1 / L2 -----------------------------------------------------------------------------------------------
+def test_ntt_forward_inverse(sa, oracle):
+    O = oracle
+    rng = np.random.default_rng(10)
+    x = rand_ntt(rng, O, (5,))
+    x[0, :, :4] = 0
+    x[1, 0, :] = O.P - 1
+    x[1, 1, :] = O.B - 1
+    x[2] *= 3  # lazy inputs < 4m are legal for ntt_forward (src/core.cpp:274)
+    f = sa.ntt_forward(x)
+    assert_eq(f, O.ntt_forward(x), "ntt_forward")
+    xi = rand_ntt(rng, O, (5,))
+    assert_eq(sa.ntt_inverse(xi), O.ntt_inverse(xi), "ntt_inverse")
+    assert_eq(sa.ntt_inverse(f), canon(O, x), "inverse(forward)")
+
+
+def test_to_from_ntt(sa, oracle):
+    O = oracle
+    rng = np.random.default_rng(11)
+    A = rng.integers(0, O.Q, size=(3, 6, N), dtype=np.uint64)
+    A[0, 0, :5] = [0, 1, O.Q - 1, O.Q, O.P]
+    An = sa.to_ntt(A)
+    assert_eq(An, O.to_ntt(A), "to_ntt")
+    assert_eq(sa.from_ntt(An), A % O.Q, "do_MatPol_test round trip")  # src/spiral.cpp:1181
+    assert_eq(sa.from_ntt(An), O.from_ntt(An), "from_ntt")
+    d = rng.integers(0, 1 << 29, size=(4, N), dtype=np.uint64)
+    assert_eq(sa.to_ntt_no_reduce(d), O.to_ntt(d, reduce=False), "to_ntt_no_reduce")
+
+
+def test_multiply_add_mul_by_const(sa, oracle):
+    O = oracle
+    rng = np.random.default_rng(12)
+    for rs, ms, cs in [(2, 8, 1), (3, 8, 2), (3, 56, 1), (1, 1, 1)]:
+        a, b = rand_ntt(rng, O, (rs, ms)), rand_ntt(rng, O, (ms, cs))
+        assert_eq(sa.multiply(a, b), O.multiply(a, b), f"multiply {rs}x{ms}x{cs}")
+    a, b = rand_ntt(rng, O, (3, 2)), rand_ntt(rng, O, (3, 2))
+    assert_eq(sa.add(a, b), O.add(a, b), "add")
+    s = rand_ntt(rng, O, ())
+    assert_eq(sa.mul_by_const(s, a), O.mul_by_const(s, a), "mul_by_const")
+
+
+def test_raw_domain_ops(sa, oracle):
+    O = oracle
+    rng = np.random.default_rng(13)
+    a = rng.integers(0, O.Q, size=(2, N), dtype=np.uint64)
+    a[0, :3] = [0, O.Q - 1, 1]
+    for r in range(0, 11):
+        t = (N >> r) + 1
+        assert_eq(sa.automorph(a, t), O.automorph(a, t), f"automorph t={t}")
+    assert_eq(sa.invert(a), O.invert(a), "invert")
+    for t in (2, 4, 5, 8, 10, 16, 56):
+        v = rng.integers(0, O.Q, size=(1, 2, N), dtype=np.uint64)
+        v[0, 0, 0] = O.Q
+        assert_eq(sa.gadget_invert(v, t, 1), O.gadget_invert(v, t, 1), f"gadget_invert t={t}")
+    v = rng.integers(0, O.Q, size=(2, 3, N), dtype=np.uint64)
+    assert_eq(sa.gadget_invert(v, 8, 2), O.gadget_invert(v, 8, 2), "gadget_invert rdim=2")
+
+
+def test_rescale(sa, oracle):
+    O = oracle
+    rng = np.random.default_rng(14)
+    a = rng.integers(0, O.Q, size=4096, dtype=np.uint64)
+    a[:8] = [0, 1, O.Q // 2 - 1, O.Q // 2, O.Q // 2 + 1, O.Q - 1, O.Q, 12345]
+    for out_mod in (786433, 1024, 12289, 68718428161, 4 * 32768):
+        exp = np.array([O.rescale(int(x) % O.Q, O.Q, out_mod) for x in a], dtype=np.uint64)
+        assert_eq(sa.getRescaled(a, O.Q, out_mod), exp, f"getRescaled -> {out_mod}")
+
+
+# ---- L5 seams -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nu1,nu2", [(2, 1), (1, 3), (3, 5), (5, 6), (2, 7)])
+def test_multiply_query_by_database(sa, oracle, nu1, nu2):
+    O = oracle
+    dim0, num_per = 1 << nu1, 1 << nu2
+    rng = np.random.default_rng(20 + nu1 * 16 + nu2)
+    cts = rand_ntt(rng, O, (dim0, 3, 2))
+    re = O.reorient_ciphertexts(cts)
+    db = O.fill_db_random(nu1 * 100 + nu2, dim0 * num_per * 4 * N)
+    assert_eq(sa.multiplyQueryByDatabase(re, db, dim0, num_per), O.multiply_query_by_database(re, db, dim0, num_per), "sweep")
+
+
+def test_sweep_accumulator_extremes(sa, oracle):
+    """all operands m-1: the largest partial sums, exercises the 256-term reduction rule with dim0 = 256"""
+    O = oracle
+    dim0, num_per = 256, 32
+    cts = np.zeros((dim0, 3, 2, 2, N), dtype=np.uint64)
+    cts[..., 0, :] = O.P - 1
+    cts[..., 1, :] = O.B - 1
+    re = O.reorient_ciphertexts(cts)
+    db = np.full(dim0 * num_per * 4 * N, (O.P - 1) | ((O.B - 1) << 32), dtype=np.uint64)
+    got = sa.multiplyQueryByDatabase(re, db, dim0, num_per)
+    assert (got[..., 0, :] == (2 * dim0 * (O.P - 1) ** 2) % O.P).all() and (got[..., 1, :] == (2 * dim0 * (O.B - 1) ** 2) % O.B).all()
+
+
+@pytest.mark.parametrize("t_gsw", [4, 5, 8, 10])
+def test_split_and_crt(sa, oracle, t_gsw):
+    O = oracle
+    rng = np.random.default_rng(30 + t_gsw)
+    raw = rng.integers(0, O.Q, size=(3, 3, 2, N), dtype=np.uint64)
+    bits = 56 // t_gsw + 1
+    raw[0, 0, 0, :6] = [0, 1, O.Q - 1, 1 << (bits - 1), (1 << (bits - 1)) + 1, (1 << bits) - 1]
+    assert_eq(sa.split_and_crt(raw, t_gsw), O.split_and_crt(raw, t_gsw), f"split_and_crt t={t_gsw}")
+
+
+@pytest.mark.parametrize("num_per,t_gsw", [(1, 8), (4, 8), (2, 4), (2, 10)])
+def test_fold_one_further_dimension(sa, oracle, num_per, t_gsw):
+    O = oracle
+    rng = np.random.default_rng(40 + num_per + t_gsw)
+    m2 = 3 * t_gsw
+    cts = rng.integers(0, O.Q, size=(2 * num_per, 3, 2, N), dtype=np.uint64)
+    q = rand_ntt(rng, O, (3, m2))
+    qn = rand_ntt(rng, O, (3, m2))
+    q_re, qn_re = np.zeros(N * 3 * m2, dtype=np.uint64), np.zeros(N * 3 * m2, dtype=np.uint64)
+    import ctypes as C
+
+    O.lib().orc_reorient_Q(O._p(q_re), O._p(q), C.c_uint32(m2))
+    O.lib().orc_reorient_Q(O._p(qn_re), O._p(qn), C.c_uint32(m2))
+    exp = cts.copy()
+    O.lib().orc_fold_one_further_dimension(O._p(exp), C.c_size_t(num_per), O._p(q_re), O._p(qn_re), C.c_uint32(t_gsw))
+    got = sa.foldOneFurtherDimension(cts, num_per, q_re, qn_re, t_gsw)
+    assert_eq(got, exp[:num_per], "foldOneFurtherDimension")
+
+
+@pytest.mark.parametrize("g,t_exp,t_right,stopround,max_bits", [(3, 8, 56, 0, 0), (4, 8, 56, 2, 3), (5, 2, 56, 4, 16), (4, 16, 8, 0, 0)])
+def test_expand_improved(sa, oracle, g, t_exp, t_right, stopround, max_bits):
+    O = oracle
+    rng = np.random.default_rng(50 + g)
+    n_right = stopround + 1 if stopround else g
+    cv = np.zeros((1 << g, 2, 2, N), dtype=np.uint64)
+    cv[0] = rand_ntt(rng, O, (2,))
+    wl = rand_ntt(rng, O, (g, 2, t_exp))
+    wr = rand_ntt(rng, O, (n_right, 2, t_right))
+    exp = O.expand_improved(cv, g, t_exp, wl, t_right, wr, n_right, max_bits, stopround)
+    got = sa.expandImproved(cv, g, t_exp, wl, wr, t_right, n_right, max_bits, stopround)
+    # entries the reference never writes/reads (odd slots past stopround) are unspecified: compare the live ones
+    live = np.ones(1 << g, dtype=bool)
+    if stopround:
+        for i in range(1 << g):
+            if i & 1 and i >= (1 << (stopround + 1)):
+                live[i] = False
+    assert_eq(got[live], exp[live], "expandImproved")
+
+
+def test_scal_to_mat_and_regev_to_gsw(sa, oracle):
+    O = oracle
+    rng = np.random.default_rng(60)
+    for t_conv, ell in [(4, 8), (4, 4), (8, 5), (56, 4)]:
+        cv = rand_ntt(rng, O, (ell, 2))
+        w, v = rand_ntt(rng, O, (3, 2 * t_conv)), rand_ntt(rng, O, (3, 2 * t_conv))
+        assert_eq(sa.scalToMat(t_conv, cv[0], w), O.scal_to_mat(cv[0], w, t_conv), f"scalToMat t_conv={t_conv}")
+        assert_eq(sa.regevToGSW(t_conv, ell, cv, w, v), O.regev_to_gsw(cv, w, v, t_conv, ell), f"regevToGSW t_conv={t_conv} ell={ell}")
+
+
+# ---- resident server, stage by stage and end to end -----------------------------------------------------------------
+CONFIGS = [
+    (2, 1, {}),  # stopround == 0
+    (4, 2, dict(t_gsw=4)),  # stopround > 0
+    (3, 3, dict(t_gsw=8)),
+    (6, 2, {}),  # stopround with dim0 >> ell*nu2
+    (2, 2, dict(t_gsw=5, t_exp=2, qprime_bits=19, direct_upload=1)),  # direct upload (SpiralStream-style)
+    (2, 6, dict(t_gsw=4)),  # nic >= 64: the fast sweep path
+]
+
+
+@pytest.mark.parametrize("nu1,nu2,kw", CONFIGS)
+def test_server_stages_match_oracle(sa, oracle, nu1, nu2, kw):
+    O = oracle
+    from spiral_amd import server as SV
+
+    po, pg = O.make_params(nu1, nu2, **kw), sa.make_params(nu1, nu2, **kw)
+    s = O.shape_of(po)
+    total = s.dim0 * s.num_per
+    idx = 1234 % total
+    db = O.gen_db(po, 77)
+    cl = O.Client(po, seed=5)
+    wl, wr, w, v = cl.pub_params()
+    q = cl.query(idx)
+
+    srv = sa.Server(pg)
+    srv.keep_cts(True)
+    srv.load_db(db)
+    srv.set_pub_params(wl, wr, w, v)
+    srv.set_query(q)
+
+    cv = O.stage_expand(po, q, wl, wr)
+    srv.expand()
+    assert_eq(srv.read(SV.BUF_EXPANDED), cv, "expanded ciphertexts")
+    cts, gsw = O.stage_convert(po, cv, w, v)
+    srv.convert()
+    assert_eq(srv.read(SV.BUF_CTS), cts, "scalToMat outputs (expansionLocals.cts)")
+    assert_eq(srv.read(SV.BUF_GSW), gsw, "regevToGSW outputs")
+    raw = O.stage_first_dim(po, cts, db)
+    srv.first_dim()
+    srv.lift()
+    assert_eq(srv.read(SV.BUF_RAW), raw, "first dimension (sweep + INTT + CRT)")
+    fin = O.stage_fold(po, raw, gsw)
+    srv.fold()
+    assert_eq(srv.read(SV.BUF_FINAL), fin, "folded ciphertext")
+    srv.finish()
+    resp = O.stage_rescale(po, fin)
+    assert_eq(srv.read(SV.BUF_RESPONSE), resp, "response")
+    # the reference's own functional check: Is correct?
+    assert_eq(cl.decode(srv.read(SV.BUF_RESPONSE)), O.db_item(po, 77, idx), "decoded plaintext")
+    srv.close()
+
+
+@pytest.mark.parametrize("nu1,nu2,kw", [(4, 3, dict(t_gsw=4)), (2, 2, dict(t_gsw=5, t_exp=2, qprime_bits=19, direct_upload=1))])
+def test_answer_and_device_db(sa, oracle, nu1, nu2, kw):
+    """answer() in one call with the database generated ON the device (same seeded coefficients as the oracle's)"""
+    O = oracle
+    po, pg = O.make_params(nu1, nu2, **kw), sa.make_params(nu1, nu2, **kw)
+    s = O.shape_of(po)
+    cl = O.Client(po, seed=9)
+    wl, wr, w, v = cl.pub_params()
+    srv = sa.Server(pg)
+    srv.gen_db(4321)
+    srv.set_pub_params(wl, wr, w, v)
+    db = O.gen_db(po, 4321)
+    for idx in (0, s.dim0 * s.num_per - 1, 7):
+        q = cl.query(idx)
+        fin, resp, us = srv.answer(q)
+        assert_eq(fin, O.answer(po, q, wl, wr, w, v, db), "answer")
+        assert_eq(cl.decode(resp), O.db_item(po, 4321, idx), "decoded plaintext")
+        assert us["total_us"] > 0
+    srv.close()
+
+
+def test_sharded_first_dim_sums_to_unsharded(sa, oracle):
+    """two j-shards on one device: summing their accumulators (what the RCCL reduce does) == one server"""
+    O = oracle
+    from spiral_amd import server as SV
+
+    kw = dict(t_gsw=4)
+    po, pg = O.make_params(4, 3, **kw), sa.make_params(4, 3, **kw)
+    cl = O.Client(po, seed=2)
+    wl, wr, w, v = cl.pub_params()
+    q = cl.query(99)
+    accs = []
+    for j0, j1 in [(0, 16), (0, 8), (8, 16)]:
+        srv = sa.Server(pg, 0, j0, j1)
+        srv.gen_db(55)
+        srv.set_pub_params(wl, wr, w, v)
+        srv.set_query(q)
+        srv.expand()
+        srv.convert()
+        srv.first_dim()
+        accs.append(srv.read(SV.BUF_ACC).astype(object))
+        srv.close()
+    tot = accs[1] + accs[2]
+    tot[..., 0, :] %= O.P
+    tot[..., 1, :] %= O.B
+    assert (tot == accs[0]).all()
+
+
+@pytest.mark.slow
+def test_full_size_config2_end_to_end(sa, oracle):
+    """BASELINE.json config 2 (nu1=8, nu2=7, 2^20 x 256 B): size-independent property -- the response decodes
+    to the database item (the reference's Is correct?), database generated on the device."""
+    O = oracle
+    po, pg = O.make_params(8, 7), sa.make_params(8, 7)
+    cl = O.Client(po, seed=1)
+    wl, wr, w, v = cl.pub_params()
+    srv = sa.Server(pg)
+    srv.gen_db(1234)
+    srv.set_pub_params(wl, wr, w, v)
+    for idx in (1234, (1 << 15) - 1):
+        fin, resp, us = srv.answer(cl.query(idx))
+        assert_eq(cl.decode(resp), O.db_item(po, 1234, idx), "decoded plaintext at full size")
+    srv.close()
