@@ -194,7 +194,7 @@ CONFIGS = [
     (3, 3, dict(t_gsw=8)),
     (6, 2, {}),  # stopround with dim0 >> ell*nu2
     (2, 2, dict(t_gsw=5, t_exp=2, qprime_bits=19, direct_upload=1)),  # direct upload (SpiralStream-style)
-    (2, 6, dict(t_gsw=4)),  # nic >= 64: the fast sweep path
+    (2, 6, dict(t_gsw=8)),  # nic >= 64: the fast sweep path
 ]
 
 
