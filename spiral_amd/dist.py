@@ -1,0 +1,31 @@
+"""Multi-GPU plumbing for the first-dimension shard.
+
+The database is partitioned by first-dimension index j across the ranks of one node; every rank sweeps
+its shard and produces full-shape partial accumulators (packed words, each 28-bit field already reduced
+mod its prime).  One sum-reduce of those words as integers is carry-safe for up to 16 ranks
+(16 * 2^28 = 2^32), after which the root reduces each field mod its prime and continues with the
+INTT / CRT lift and the folding.  torch.distributed (backend "nccl" = RCCL over xGMI on ROCm, "gloo"
+on CPU) carries the single collective; nothing else crosses ranks.
+"""
+from __future__ import annotations
+
+MAX_RANKS = 16  # carry-safety bound of the packed sum
+
+
+def shard_range(rank: int, world: int, dim0: int) -> tuple[int, int]:
+    """contiguous j-range [j0, j1) of `rank`; dim0 and world are powers of two in every Spiral geometry"""
+    if world < 1 or world > MAX_RANKS:
+        raise ValueError(f"world size {world} outside [1, {MAX_RANKS}] (packed-sum carry bound)")
+    if dim0 % world != 0:
+        raise ValueError(f"first dimension {dim0} does not split evenly over {world} ranks")
+    per = dim0 // world
+    return rank * per, (rank + 1) * per
+
+
+def reduce_accumulators(acc, dst: int = 0, group=None):
+    """sum the ranks' packed accumulators into rank `dst` (one collective).  `acc` is an int64 tensor
+    viewing the words the sweep wrote; the fields never carry into each other (see module docstring)."""
+    import torch.distributed as dist
+
+    dist.reduce(acc, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    return acc
