@@ -39,6 +39,16 @@ __device__ __forceinline__ uint64_t crt_compose(uint32_t x, uint32_t y) {
     return (uint64_t)x + (uint64_t)kP * k;
 }
 
+// Device database layout (internal; built at load time).  The nic = 2*num_per output columns ic = ii*2 + c are
+// grouped in blocks of W = min(64, nic) -- one wave of the sweep owns one block -- and a block's words are
+// contiguous over (j, lane, m): word(z, j, ic, m) at (((z*nblk + ic/W)*dim0 + j)*W + ic%W)*2 + m.
+// A wave therefore streams dim0 KiB of strictly sequential addresses.
+__host__ __device__ inline uint32_t db_block_width(uint32_t nic) { return nic < 64u ? nic : 64u; }
+__host__ __device__ inline size_t db_word_index(uint32_t z, uint32_t j, uint32_t ic, uint32_t m, uint32_t nic, uint32_t dim0) {
+    const uint32_t w = db_block_width(nic), nblk = nic / w;
+    return ((((size_t)z * nblk + ic / w) * dim0 + j) * w + ic % w) * 2u + m;
+}
+
 // include/util.h:34-38
 __host__ __device__ inline uint32_t get_bits_per(uint32_t dim) { return dim == 56 ? 1u : 56u / dim + 1u; }
 

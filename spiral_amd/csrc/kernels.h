@@ -29,6 +29,8 @@ enum FwdLoad : uint32_t {
     LD_SDIGIT = 2,  // balanced digit with the fold's carry rules        (split_and_crt, src/spiral.cpp:270)
     LD_LIMBS = 3,   // reference NTT layout [2][N] u64 taken as per-limb coefficient arrays (ntt_forward)
     LD_DBGEN = 4,   // seeded plaintext coefficient, centred lift        (load_db, src/spiral.cpp:1116-1127)
+    LD_EXPAND = 5,  // one expansion round: digits of automorph(c)[0] and the reduced automorph(c)[1] of every
+                    // active ciphertext, both parities, in one launch      (src/spiral.cpp:1711-1720)
 };
 enum FwdStore : uint32_t {
     ST_PK = 0,      // packed slot words
@@ -45,6 +47,8 @@ struct FwdParams {
     uint32_t ell;       // LD_SDIGIT: digits per value (t_GSW)
     uint32_t tinv;      // automorphism gather x -> x^t folded into the load: t^-1 mod 2N, 0 = none
     uint32_t fold_np;   // LD_SDIGIT: num_per' (destination is the fold operand layout)
+    // LD_EXPAND: active ct a < cnt_e is even (t_e digits), the rest odd (t_o digits); jobs per ct = t + 1
+    uint32_t cnt_e, t_e, t_o;
     // LD_DBGEN / ST_DB
     uint64_t seed, p_db;
     uint64_t item_base;                 // first item handled by this launch
@@ -63,8 +67,14 @@ struct InvParams {
     IndexMap src_map, dst_map;
     uint32_t pre_reduce;  // 1: fields are lazy sums (< 2^32), reduce mod m first
     uint32_t src_ref;     // 1: source is reference layout [2][N] u64 instead of PK
+    // expansion round (launch_ntt_inverse_expand): block b = (active ct a, row); a < cnt_e -> i = 2a, else
+    // i = 2(a - cnt_e) + 1; a ct with i >= num_in is first created as neg1 * cv[i - num_in] (src/spiral.cpp:1709)
+    uint64_t* cv;
+    const uint64_t* neg1;
+    uint32_t num_in, cnt_e;
 };
 void launch_ntt_inverse(const DeviceTables& t, const InvParams& p, uint32_t store, uint32_t nblocks, hipStream_t s);
+void launch_ntt_inverse_expand(const DeviceTables& t, const InvParams& p, uint32_t nblocks, hipStream_t s);
 
 // ---- layout conversion at the C-ABI boundary -------------------------------------------------------
 // reference polynomial b <-> packed polynomial pk_map(b)
@@ -98,6 +108,16 @@ void launch_mul_neg1(uint64_t* cv, const uint64_t* neg1_r, uint32_t src0, uint32
 // cv[i][j] = cv[i][j] + sum_k W[j][k] * G[a][k] + j * A1[a],  i = i0 + step*a   (src/spiral.cpp:1722-1733)
 void launch_expand_mac(uint64_t* cv, const uint64_t* w, const uint64_t* g, const uint64_t* a1, uint32_t t_dim, uint32_t i0, uint32_t step,
                        uint32_t count, hipStream_t s);
+// the same for a whole round in one launch: active ct a < cnt_e even (W_left, t_e digits) else odd (W_right, t_o);
+// g holds t+1 polynomials per ct (digits, then NTT(c'_1)) in LD_EXPAND job order
+struct ExpandMacParams {
+    uint64_t* cv;
+    const uint64_t* w_e;
+    const uint64_t* w_o;
+    const uint64_t* g;
+    uint32_t cnt_e, cnt_o, t_e, t_o;
+};
+void launch_expand_mac_round(const ExpandMacParams& p, hipStream_t s);
 // scalToMat product: out[a][r][c] = sum_k W[r][2k+c] * G[a][k] + pad(cv[pos(a)][1])   (src/spiral.cpp:1850-1885)
 // qs != null: also (or instead, out may be null) write the sweep's query records (see sweep)
 struct Scal2MatParams {
@@ -127,8 +147,8 @@ void launch_fold_key(const uint64_t* gsw, uint64_t* key, uint32_t dims, uint32_t
 void launch_fold_key_from_reoriented(const uint64_t* q_re, const uint64_t* qneg_re, uint64_t* key, uint32_t m2, hipStream_t s);
 
 // ---- first-dimension sweep (sweep.hip) -----------------------------------------------------------------
-// device DB layout: word(z, jm, ic) at ((z * (JM/2) + jm/2) * nic + ic) * 2 + (jm & 1), jm = (j - j0)*2 + m,
-// ic = ii*2 + c, nic = 2*num_per.  acc[ii][r][c][z] PK (fields < m).
+// device DB layout: common.h db_word_index(z, j - j0, ic, m), ic = ii*2 + c, nic = 2*num_per.
+// acc[ii][r][c][z] PK (fields < m).
 void launch_sweep(const uint64_t* db, const uint32_t* qs, uint64_t* acc, uint32_t num_per, uint32_t jm_total, hipStream_t s);
 // reference DB layout (src/spiral.cpp:1139-1153) -> device layout, for the j-range [j0, j0 + dim0_shard) and
 // nz consecutive z slabs starting at the given pointers

@@ -54,7 +54,7 @@ template <uint32_t LOAD, uint32_t STORE>
 __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p) {
     __shared__ uint64_t sh[kLdsWords];
     const uint32_t tid = threadIdx.x, b = blockIdx.x;
-    const uint32_t s = b / p.n_digits, k = b - s * p.n_digits;
+    uint32_t s = b / p.n_digits, k = b - s * p.n_digits;
     uint32_t lo[8], hi[8];
 
     if constexpr (LOAD == LD_DBGEN) {
@@ -75,6 +75,39 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
                 hi[r] = mod_b(v);
             }
         }
+    } else if constexpr (LOAD == LD_EXPAND) {
+        // job b -> (active ct a, k); k < tdim: digit k of automorph(c)[0]; k == tdim: automorph(c)[1] reduced
+        const uint32_t je = p.cnt_e * (p.t_e + 1u);
+        uint32_t a, tdim;
+        if (b < je) {
+            tdim = p.t_e;
+            a = b / (tdim + 1u);
+            k = b - a * (tdim + 1u);
+        } else {
+            tdim = p.t_o;
+            const uint32_t bb = b - je;
+            a = bb / (tdim + 1u);
+            k = bb - a * (tdim + 1u);
+            a += p.cnt_e;
+        }
+        const bool is_digit = k < tdim;
+        const uint64_t* src = p.src + ((size_t)a * 2u + (is_digit ? 0u : 1u)) * kN;
+        const uint32_t bits = get_bits_per(tdim);
+        const uint64_t mask = (1ull << bits) - 1;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            uint32_t idx = ix_a(tid, r);
+            uint64_t v = load_raw(src, idx, p.tinv);
+            if (is_digit) {
+                uint32_t d = (uint32_t)digit_of(v, k, bits, mask);
+                lo[r] = d;
+                hi[r] = d;
+            } else {
+                lo[r] = mod_p(v);
+                hi[r] = mod_b(v);
+            }
+        }
+        s = b;
     } else if constexpr (LOAD == LD_LIMBS) {
         const uint64_t* src = p.src + (size_t)p.src_map(s) * (2 * kN);
 #pragma unroll
@@ -132,20 +165,48 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
         const uint64_t item = p.item_base + (b >> 2);
         const uint32_t mc = b & 3u, m = mc >> 1, c = mc & 1u;
         const uint32_t ii = (uint32_t)(item % p.num_per), j = (uint32_t)(item / p.num_per);
-        const uint32_t jm = (j - p.j0) * 2u + m, ic = ii * 2u + c, nic = 2u * p.num_per;
-        const size_t zstride = (size_t)p.dim0_shard * nic * 2u;  // words per z slab = (JM/2) * nic * 2
-        uint64_t* dst = p.dst + ((size_t)(jm >> 1) * nic + ic) * 2u + (jm & 1u);
+        const uint32_t ic = ii * 2u + c, nic = 2u * p.num_per;
+        const size_t zstride = (size_t)p.dim0_shard * nic * 2u;  // words per z slab
+        uint64_t* dst = p.dst + db_word_index(0, j - p.j0, ic, m, nic, p.dim0_shard);
 #pragma unroll
         for (int r = 0; r < 8; r++) dst[(size_t)(8u * tid + r) * zstride] = pack(lo[r], hi[r]);
     }
 }
 
-template <uint32_t STORE>
+template <uint32_t STORE, bool EXPAND = false>
 __global__ __launch_bounds__(256) void ntt_inverse_kernel(Tables t, InvParams p) {
     __shared__ uint64_t sh[kLdsWords];
     const uint32_t tid = threadIdx.x, b = blockIdx.x;
     uint32_t lo[8], hi[8];
-    if (p.src_ref) {
+    if constexpr (EXPAND) {
+        const uint32_t a = b >> 1, row = b & 1u;
+        const uint32_t i = a < p.cnt_e ? 2u * a : 2u * (a - p.cnt_e) + 1u;
+        if (i >= p.num_in) {  // cv[i] = neg1 * cv[i - num_in], created here and transformed in the same pass
+            const uint64_t* src = p.cv + ((size_t)(i - p.num_in) * 2u + row) * kN + 8u * tid;
+            const uint64_t* ng = p.neg1 + 8u * tid;
+            uint64_t* dstc = p.cv + ((size_t)i * 2u + row) * kN + 8u * tid;
+#pragma unroll
+            for (int r = 0; r < 8; r += 2) {
+                ulonglong2 v2 = *reinterpret_cast<const ulonglong2*>(src + r);
+                ulonglong2 w2 = *reinterpret_cast<const ulonglong2*>(ng + r);
+                lo[r] = mod_p((uint64_t)lo32(v2.x) * lo32(w2.x));
+                hi[r] = mod_b((uint64_t)hi32(v2.x) * hi32(w2.x));
+                lo[r + 1] = mod_p((uint64_t)lo32(v2.y) * lo32(w2.y));
+                hi[r + 1] = mod_b((uint64_t)hi32(v2.y) * hi32(w2.y));
+                *reinterpret_cast<ulonglong2*>(dstc + r) = make_ulonglong2(pack(lo[r], hi[r]), pack(lo[r + 1], hi[r + 1]));
+            }
+        } else {
+            const uint64_t* src = p.cv + ((size_t)i * 2u + row) * kN + 8u * tid;
+#pragma unroll
+            for (int r = 0; r < 8; r += 2) {
+                ulonglong2 v2 = *reinterpret_cast<const ulonglong2*>(src + r);
+                lo[r] = lo32(v2.x);
+                hi[r] = hi32(v2.x);
+                lo[r + 1] = lo32(v2.y);
+                hi[r + 1] = hi32(v2.y);
+            }
+        }
+    } else if (p.src_ref) {
         const uint64_t* src = p.src + (size_t)p.src_map(b) * (2 * kN) + 8u * tid;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -215,7 +276,14 @@ void launch_ntt_forward(const DeviceTables& t, const FwdParams& p, uint32_t load
     FWD_CASE(LD_LIMBS, ST_REF)
     FWD_CASE(LD_LIMBS, ST_PK)
     FWD_CASE(LD_DBGEN, ST_DB)
+    FWD_CASE(LD_EXPAND, ST_PK)
     abort();
+}
+
+void launch_ntt_inverse_expand(const DeviceTables& t, const InvParams& p, uint32_t nblocks, hipStream_t s) {
+    if (nblocks == 0) return;
+    Tables tb{t.fwd, t.inv};
+    hipLaunchKernelGGL((ntt_inverse_kernel<IST_CRT, true>), dim3(nblocks), dim3(256), 0, s, tb, p);
 }
 
 void launch_ntt_inverse(const DeviceTables& t, const InvParams& p, uint32_t store, uint32_t nblocks, hipStream_t s) {

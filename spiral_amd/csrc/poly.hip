@@ -156,6 +156,47 @@ void launch_expand_mac(uint64_t* cv, const uint64_t* w, const uint64_t* g, const
     if (count) hipLaunchKernelGGL(expand_mac_kernel, dim3(kBpp, count), dim3(kTpb), 0, s, cv, w, g, a1, t_dim, i0, step);
 }
 
+// whole-round MAC: 64 slots x 4 k-groups per workgroup, partial sums combined through LDS
+__global__ __launch_bounds__(kTpb) void expand_mac_round_kernel(ExpandMacParams p) {
+    __shared__ uint64_t sh[3][64][4];
+    const uint32_t zz = threadIdx.x & 63u, kg = threadIdx.x >> 6, z = blockIdx.x * 64u + zz, a = blockIdx.y;
+    const bool odd = a >= p.cnt_e;
+    const uint32_t tdim = odd ? p.t_o : p.t_e;
+    const uint32_t i = odd ? 2u * (a - p.cnt_e) + 1u : 2u * a;
+    const size_t gbase = odd ? (size_t)p.cnt_e * (p.t_e + 1u) + (size_t)(a - p.cnt_e) * (p.t_o + 1u) : (size_t)a * (p.t_e + 1u);
+    const uint64_t* w = (odd ? p.w_o : p.w_e) + z;
+    const uint64_t* gp = p.g + gbase * kN + z;
+    Acc2 acc0, acc1;
+#pragma unroll 4
+    for (uint32_t k = kg; k < tdim; k += 4) {
+        const uint64_t gv = gp[(size_t)k * kN];
+        acc0.mac(w[(size_t)k * kN], gv);
+        acc1.mac(w[(size_t)(tdim + k) * kN], gv);
+    }
+    if (kg > 0) {
+        sh[kg - 1][zz][0] = acc0.lo;
+        sh[kg - 1][zz][1] = acc0.hi;
+        sh[kg - 1][zz][2] = acc1.lo;
+        sh[kg - 1][zz][3] = acc1.hi;
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) {  // <= 56 terms of < 2^56 in total: no overflow
+            acc0.lo += sh[q][zz][0];
+            acc0.hi += sh[q][zz][1];
+            acc1.lo += sh[q][zz][2];
+            acc1.hi += sh[q][zz][3];
+        }
+        uint64_t* c = p.cv + (size_t)i * 2 * kN + z;
+        c[0] = add_pk(c[0], acc0.reduced());
+        c[kN] = add_pk(add_pk(c[kN], acc1.reduced()), gp[(size_t)tdim * kN]);
+    }
+}
+void launch_expand_mac_round(const ExpandMacParams& p, hipStream_t s) {
+    if (p.cnt_e + p.cnt_o) hipLaunchKernelGGL(expand_mac_round_kernel, dim3(kN / 64, p.cnt_e + p.cnt_o), dim3(kTpb), 0, s, p);
+}
+
 // ---- scalToMat (src/spiral.cpp:1834-1885) ----------------------------------------------------------------------
 // prod[r][c] = sum_k W[r][2k + c] * g[k]  (special_distribute makes column c see only W's columns 2k+c),
 // out = prod + pad(cv row 1) at (1,0) and (2,1)

@@ -127,12 +127,11 @@ int current_tables(DeviceTables* t) {
 // ---- expansion on PK buffers, shared by the seam and the resident server ---------------------------------
 struct ExpandWork {
     uint64_t* raw;  // [2^g][2] RAW
-    uint64_t* g;    // digit polynomials
-    uint64_t* a1;   // [2^g] PK
+    uint64_t* g;    // per active ct: t digits + NTT(c'_1), PK
 };
 size_t expand_g_polys(uint32_t g, uint32_t t_exp, uint32_t t_exp_right) {
-    size_t half = (size_t)1 << (g ? g - 1 : 0);
-    return half * (t_exp > t_exp_right ? t_exp : t_exp_right);
+    size_t half = (size_t)1 << (g ? g - 1 : 0);  // at most 2^(g-1) active cts per parity
+    return half * ((size_t)t_exp + 1 + t_exp_right + 1);
 }
 
 // src/spiral.cpp:1664-1743.  cv: 2^g cts (2 PK polys each).
@@ -145,47 +144,39 @@ void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_t t_exp
         uint32_t cnt_even = num_in, cnt_odd = num_in;
         if (stopround > 0 && r > stopround) cnt_odd = 0;
         if (stopround > 0 && r == stopround) cnt_odd = std::min(num_in, max_bits_right + 1);
-        // cv[num_in + i] = neg1 * cv[i] for the active i < num_in (:1709), before cv[i] is updated
-        const uint64_t* neg1 = tb.neg1 + (size_t)r * kN;
-        if (r == 0) {
-            launch_mul_neg1(cv, neg1, 0, 1, 1, 1, st);
-        } else {
-            launch_mul_neg1(cv, neg1, 0, num_in, 2, num_in / 2, st);
-            launch_mul_neg1(cv, neg1, 1, num_in + 1, 2, std::min(num_in / 2, cnt_odd), st);
-        }
-        for (int parity = 0; parity < 2; parity++) {
-            const uint32_t cnt = parity ? cnt_odd : cnt_even;
-            if (cnt == 0) continue;
-            const uint32_t tdim = parity ? t_exp_right : t_exp;
-            const uint64_t* w = (parity ? w_right : w_left) + (size_t)r * 2 * tdim * kN;
-            // c = from_ntt(cv[i]) for i = parity + 2a
-            InvParams ip{};
-            ip.src = cv;
-            ip.dst = wk.raw;
-            ip.src_map = IndexMap{2, 4, 2u * parity};
-            ip.dst_map = identity_map();
-            launch_ntt_inverse(tb, ip, IST_CRT, 2 * cnt, st);
-            // G^-1(automorph(c)[0]) -> tdim digit polynomials per ct, NTT'd without reduction
-            FwdParams fp{};
-            fp.src = wk.raw;
-            fp.dst = wk.g;
-            fp.src_map = IndexMap{1, 2, 0};
-            fp.dst_map = identity_map();
-            fp.n_digits = tdim;
-            fp.bits = get_bits_per(tdim);
-            fp.tinv = tinv;
-            launch_ntt_forward(tb, fp, LD_DIGIT, ST_PK, cnt * tdim, st);
-            // NTT(automorph(c)[1])
-            FwdParams fa{};
-            fa.src = wk.raw;
-            fa.dst = wk.a1;
-            fa.src_map = IndexMap{1, 2, 1};
-            fa.dst_map = identity_map();
-            fa.n_digits = 1;
-            fa.tinv = tinv;
-            launch_ntt_forward(tb, fa, LD_RAW, ST_PK, cnt, st);
-            launch_expand_mac(cv, w, wk.g, wk.a1, tdim, parity, 2, cnt, st);
-        }
+        // 1) INTT + CRT of every active ct (both parities); cts with i >= num_in are first created as
+        //    neg1 * cv[i - num_in] (:1709) inside the same kernel
+        const uint32_t cnt = cnt_even + cnt_odd;
+        InvParams ip{};
+        ip.dst = wk.raw;
+        ip.src_map = ip.dst_map = identity_map();
+        ip.cv = cv;
+        ip.neg1 = tb.neg1 + (size_t)r * kN;
+        ip.num_in = num_in;
+        ip.cnt_e = cnt_even;
+        launch_ntt_inverse_expand(tb, ip, 2 * cnt, st);
+        // 2) G^-1(automorph(c)[0]) digits (t_exp / t_exp_right per ct) and NTT(automorph(c)[1]), one launch
+        FwdParams fp{};
+        fp.src = wk.raw;
+        fp.dst = wk.g;
+        fp.src_map = fp.dst_map = identity_map();
+        fp.n_digits = 1;
+        fp.tinv = tinv;
+        fp.cnt_e = cnt_even;
+        fp.t_e = t_exp;
+        fp.t_o = t_exp_right;
+        launch_ntt_forward(tb, fp, LD_EXPAND, ST_PK, cnt_even * (t_exp + 1) + cnt_odd * (t_exp_right + 1), st);
+        // 3) cv[i] += W * digits + (0, NTT(c'_1))
+        ExpandMacParams mp{};
+        mp.cv = cv;
+        mp.w_e = w_left + (size_t)r * 2 * t_exp * kN;
+        mp.w_o = w_right + (size_t)r * 2 * t_exp_right * kN;  // never dereferenced when cnt_odd == 0
+        mp.g = wk.g;
+        mp.cnt_e = cnt_even;
+        mp.cnt_o = cnt_odd;
+        mp.t_e = t_exp;
+        mp.t_o = t_exp_right;
+        launch_expand_mac_round(mp, st);
     }
 }
 
@@ -230,7 +221,6 @@ int srv_alloc(spiral_gpu_server* S) {
     if (!p.direct_upload) {
         if (S->ex_raw.alloc((size_t)S->n_cv * 2 * kN)) return -1;
         if (S->ex_g.alloc(expand_g_polys(s.g, p.t_exp, p.t_exp_right) * kN)) return -1;
-        if (S->ex_a1.alloc((size_t)S->n_cv * kN)) return -1;
     }
     if (S->cv_raw.alloc((size_t)S->dim0_shard * kN)) return -1;
     if (S->cv_g.alloc((size_t)S->dim0_shard * p.t_conv * kN)) return -1;
@@ -567,8 +557,8 @@ int spiral_gpu_expand_improved(uint64_t* cv_v, uint32_t g, uint32_t t_exp, const
     uint64_t* d_cv = upload_pk(sc, cv_v, ncv * 2);
     uint64_t* d_wl = upload_pk(sc, w_left, (size_t)g * 2 * t_exp);
     uint64_t* d_wr = upload_pk(sc, w_right, (size_t)n_right * 2 * t_exp_right);
-    ExpandWork wk{sc.get(ncv * 2 * kN), sc.get(expand_g_polys(g, t_exp, t_exp_right) * kN), sc.get(ncv * kN)};
-    if (!d_cv || !d_wl || !d_wr || !wk.raw || !wk.g || !wk.a1) return fail("device allocation/upload failed");
+    ExpandWork wk{sc.get(ncv * 2 * kN), sc.get(expand_g_polys(g, t_exp, t_exp_right) * kN)};
+    if (!d_cv || !d_wl || !d_wr || !wk.raw || !wk.g) return fail("device allocation/upload failed");
     run_expand(tb, d_cv, g, t_exp, d_wl, t_exp_right, d_wr, max_bits_to_gen_right, stopround, wk, 0);
     return download_pk(sc, d_cv, identity_map(), cv_v, ncv * 2);
 }
@@ -797,7 +787,7 @@ int spiral_gpu_server_expand(spiral_gpu_server* S) {
         return 0;
     }
     HIP_OK(hipMemcpyAsync(S->cv.p, S->query.p, 2 * kPolyBytes, hipMemcpyDeviceToDevice, S->stream));
-    ExpandWork wk{S->ex_raw.p, S->ex_g.p, S->ex_a1.p};
+    ExpandWork wk{S->ex_raw.p, S->ex_g.p};
     run_expand(S->tb, S->cv.p, S->s.g, p.t_exp, S->w_left.p, p.t_exp_right, S->w_right.p, S->s.ell * p.nu2, S->s.stopround, wk, S->stream);
     return 0;
 }

@@ -7,10 +7,10 @@
 // (ii, c) and JM = 2*dim0 terms (j, m): 6 integer MADs per 8-byte database word, so the kernel is bound
 // by streaming the database once from HBM.  MFMA does not apply (32x32->64-bit modular integer MACs).
 //
-// Device database layout (built at load time, any re-layout is internal):
-//     word(z, j, ic, m)  at  ((z * dim0 + j) * nic + ic) * 2 + m          [z][j][ic][m], u64 = p-limb | b-limb << 32
-// so that one wave reads 64 lanes x 16 B = 1 KiB contiguous per step (lane = ic, both m of one j), and
-// steps walk j with a fixed stride.  The query is stored as one 48-byte record per (z, j):
+// Device database layout (built at load time, any re-layout is internal; common.h db_word_index):
+//     [z][column block of 64][j][lane][m], u64 = p-limb | b-limb << 32
+// so that one wave reads 64 lanes x 16 B = 1 KiB per step (lane = column, both m of one j) and its dim0
+// steps are strictly sequential addresses (a dim0 KiB contiguous stream per wave).  The query is stored as one 48-byte record per (z, j):
 //     {p-limb rows 0..2 | b-limb rows 0..2} for m = 0, then the same for m = 1      (12 u32)
 // which are wave-uniform (a wave works on one z) and are fetched through the scalar cache into SGPRs,
 // so the vector memory pipe carries only the database stream.  Accumulation is v_mad_u64_u32 into six
@@ -58,14 +58,14 @@ __global__ __launch_bounds__(256) void sweep_kernel(const uint64_t* __restrict__
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
     const uint32_t wpz = nic >> 6;  // waves per z
     const uint32_t z = wave / wpz, ic = (wave - z * wpz) * 64u + lane;
-    const u64x2* dbp = reinterpret_cast<const u64x2*>(db) + (size_t)z * dim0 * nic + ic;
+    const u64x2* dbp = reinterpret_cast<const u64x2*>(db) + (size_t)wave * dim0 * 64u + lane;  // block (z, icb) = wave
     const uint4* q = reinterpret_cast<const uint4*>(qs) + (size_t)z * dim0 * 3u;  // wave-uniform, 3 x uint4 per j
     uint64_t a[6] = {0, 0, 0, 0, 0, 0};
     for (uint32_t j0 = 0; j0 < dim0; j0 += 128) {  // 128 j = 256 terms per accumulator between reductions
         const uint32_t jend = min(j0 + 128u, dim0);
 #pragma unroll 4
         for (uint32_t j = j0; j < jend; j++) {
-            const u64x2 w = __builtin_nontemporal_load(dbp + (size_t)j * nic);
+            const u64x2 w = __builtin_nontemporal_load(dbp + (size_t)j * 64u);
             mac_j(a, q + j * 3u, w.x, w.y);
         }
         reduce6(a);
@@ -79,11 +79,11 @@ __global__ __launch_bounds__(256) void sweep_small_kernel(const uint64_t* __rest
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     const uint32_t z = g / nic, ic = g - z * nic;
     if (z >= kN) return;
-    const ulonglong2* dbp = reinterpret_cast<const ulonglong2*>(db) + (size_t)z * dim0 * nic + ic;
+    const ulonglong2* dbp = reinterpret_cast<const ulonglong2*>(db + db_word_index(z, 0, ic, 0, nic, dim0));
     const uint4* q = reinterpret_cast<const uint4*>(qs) + (size_t)z * dim0 * 3u;
     uint64_t a[6] = {0, 0, 0, 0, 0, 0};
     for (uint32_t j = 0; j < dim0; j++) {
-        const ulonglong2 w = dbp[(size_t)j * nic];
+        const ulonglong2 w = dbp[(size_t)j * nic];  // nic < 64: one block per z, block width = nic
         mac_j(a, q + j * 3u, w.x, w.y);
         if ((j & 127u) == 127u) reduce6(a);
     }
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void db_relayout_kernel(const uint64_t* __rest
     rem >>= 1;
     const uint32_t ic = (uint32_t)(rem % nic), jl = (uint32_t)(rem / nic);
     const uint32_t ii = ic >> 1, c = ic & 1u, j = j0 + jl;
-    dev[o] = ref[(size_t)z * ((size_t)num_per * 2u * dim0 * 2u) + (size_t)ii * (2u * dim0 * 2u) + (size_t)c * (dim0 * 2u) + (size_t)j * 2u + m];
+    dev[db_word_index(z, jl, ic, m, nic, dim0_shard)] = ref[(size_t)z * ((size_t)num_per * 2u * dim0 * 2u) + (size_t)ii * (2u * dim0 * 2u) + (size_t)c * (dim0 * 2u) + (size_t)j * 2u + m];
 }
 void launch_db_relayout(const uint64_t* db_ref, uint64_t* db_dev, uint32_t num_per, uint32_t dim0, uint32_t j0, uint32_t dim0_shard, uint32_t nz,
                         hipStream_t s) {

@@ -168,11 +168,12 @@ def test_expand_improved(sa, oracle, g, t_exp, t_right, stopround, max_bits):
     wr = rand_ntt(rng, O, (n_right, 2, t_right))
     exp = O.expand_improved(cv, g, t_exp, wl, t_right, wr, n_right, max_bits, stopround)
     got = sa.expandImproved(cv, g, t_exp, wl, wr, t_right, n_right, max_bits, stopround)
-    # entries the reference never writes/reads (odd slots past stopround) are unspecified: compare the live ones
+    # odd slots the reference never processes nor reads again (created in round `stopround` or later but past
+    # max_bits, src/spiral.cpp:1701-1702 + reorderFromStopround :2027) are dead: compare the live ones
     live = np.ones(1 << g, dtype=bool)
     if stopround:
         for i in range(1 << g):
-            if i & 1 and i >= (1 << (stopround + 1)):
+            if i & 1 and (i >= (1 << (stopround + 1)) or (i >= (1 << stopround) and i // 2 > max_bits)):
                 live[i] = False
     assert_eq(got[live], exp[live], "expandImproved")
 
