@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--nu1", type=int, default=8)
     ap.add_argument("--nu2", type=int, default=7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     args = ap.parse_args()
 
     import numpy as np
@@ -87,7 +88,7 @@ def main():
     j0, j1 = sdist.shard_range(rank, world, shp.dim0)
 
     srv = sa.Server(pg, local_rank, j0, j1)
-    stream = torch.cuda.current_stream()
+    stream = torch.cuda.Stream(device=dev)  # a real (capturable) stream shared by the library and RCCL
     srv.set_stream(stream.cuda_stream)
     srv.gen_db(1234)  # explicit database generated on the device, this rank's j-shard
     rng = np.random.default_rng(1)  # same synthetic inputs on every rank
@@ -96,50 +97,50 @@ def main():
     srv.set_query(synth_residues(rng, np, (shp.n_query_cts, 2)))
     acc = torch.zeros(shp.num_per * 6 * sa.N, dtype=torch.int64, device=dev)
     srv.set_acc(acc.data_ptr())
+    srv.use_graphs(not args.no_graphs)  # expand+convert and lift+fold+finish replay as two hipGraphs
 
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(7)] for _ in range(args.steps)]
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
 
     def step(e=None):
+        # one query: [expand, convert] -> sweep -> [reduce over ranks] -> [lift, fold, response switch]
         if e: e[0].record(stream)
-        srv.expand()
+        srv.run_pre()
         if e: e[1].record(stream)
-        srv.convert()
-        if e: e[2].record(stream)
         srv.first_dim()
-        if e: e[3].record(stream)
+        if e: e[2].record(stream)
         if world > 1:
             sdist.reduce_accumulators(acc, dst=0)
         if rank == 0:
-            srv.lift(reduce_first=world > 1)
-            if e: e[4].record(stream)
-            srv.fold()
-            if e: e[5].record(stream)
-            srv.finish()
-        elif e:
-            e[4].record(stream)
-            e[5].record(stream)
-        if e: e[6].record(stream)
+            srv.run_post(reduce_first=world > 1)
+        if e: e[3].record(stream)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(ev[k])
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(ev[k])
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        # untimed: the reference's stage buckets (src/spiral.cpp:246-257) from one eager pass with HIP events
+        detail = None
+        if world == 1:
+            srv.use_graphs(False)
+            detail = srv.answer_resident()
+            detail = srv.answer_resident()
 
     ms_per_step = dt * 1e3 / args.steps
-    names = ["expansion", "conversion", "sweep", "reduce_lift", "folding", "response"]
+    names = ["expand_convert", "sweep", "reduce_lift_fold_switch"]
     stages = {n: sum(ev[k][i].elapsed_time(ev[k][i + 1]) for k in range(args.steps)) / args.steps * 1e3 for i, n in enumerate(names)}
     sweep_ms = stages["sweep"] / 1e3
     bytes_sweep = srv.sweep_bytes()
@@ -162,6 +163,7 @@ def main():
                    "db_bytes_ntt_form": int(shp.dim0) * int(shp.num_per) * 4 * sa.N * 8, "parallelism": f"j-shard x{world} + 1 reduce"},
         "queries_per_s": round(1e3 / ms_per_step, 2),
         "stages_us": {k: round(v, 1) for k, v in stages.items()},
+        "reference_buckets_us_eager": ({k: round(v, 1) for k, v in detail.items() if k != "reserved"} if detail else None),
         "roofline": {"bound": "hbm", "kernel": "sweep_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "algorithmic_bytes_per_launch": int(bytes_sweep),
                      "avg_launch_ms": round(sweep_ms, 4), "shard": f"j in [{j0},{j1}) on rank 0"},

@@ -150,6 +150,12 @@ int spiral_gpu_server_lift(spiral_gpu_server *s, int reduce_first); /* nttInvAnd
 int spiral_gpu_server_fold(spiral_gpu_server *s);      /* foldOneFurtherDimension x nu2               */
 int spiral_gpu_server_finish(spiral_gpu_server *s);    /* response modulus switch, :1441-1447         */
 int spiral_gpu_server_sync(spiral_gpu_server *s);
+/* stage groups either side of the (possibly distributed) first-dimension reduce: run_pre = expand + convert,
+ * run_post = lift + fold + finish.  With use_graphs on, each group is captured once into a hipGraph on the
+ * server stream (which must not be the default stream) and replayed afterwards. */
+int spiral_gpu_server_use_graphs(spiral_gpu_server *s, int on);
+int spiral_gpu_server_run_pre(spiral_gpu_server *s);
+int spiral_gpu_server_run_post(spiral_gpu_server *s, int reduce_first);
 /* per-shard first-dimension accumulators: num_per*n1*n2*2048 packed words (p-limb | b-limb << 32, each
  * field < 2^28).  Summing the shards' buffers as uint64 (one RCCL reduce) and calling lift with
  * reduce_first = 1 gives the unsharded result.  Returns a device pointer. */

@@ -91,6 +91,8 @@ struct MatmulParams {
     uint32_t a_batch, b_batch, out_batch;  // strides in polynomials
 };
 void launch_matmul(const MatmulParams& p, uint32_t batch, hipStream_t s);
+// fold product: out[i][3][2] = key[3][K] * d[i][K][2], K = 2*m2 (src/spiral.cpp:1361-1383)
+void launch_fold_mac(const uint64_t* key, const uint64_t* d, uint64_t* out, uint32_t K, uint32_t np, hipStream_t s);
 // out = (a + b) mod m ; out = single * a (src/poly.cpp:138,190)
 void launch_add(const uint64_t* a, const uint64_t* b, uint64_t* out, uint32_t npolys, hipStream_t s);
 void launch_mul_by_const(const uint64_t* single, const uint64_t* a, uint64_t* out, uint32_t npolys, hipStream_t s);

@@ -36,6 +36,62 @@ void launch_matmul(const MatmulParams& p, uint32_t batch, hipStream_t s) {
     hipLaunchKernelGGL(matmul_kernel, dim3(kBpp, p.rs * p.cs, batch), dim3(kTpb), 0, s, p);
 }
 
+// ---- fold product (cpu_mul_query_by_ct x2 + add, src/spiral.cpp:464-582, 1361-1383) ------------------
+// out[i][r][c] = sum_{mm < K} key[r][mm] * D[i][mm][c], K = 2*m2 (Q_neg half then Q half).  One workgroup =
+// 64 slots x 4 k-groups; every D word feeds 3 rows and every key word 2 columns; partial sums meet in LDS.
+struct FoldMacParams {
+    const uint64_t* key;  // [3][K]
+    const uint64_t* d;    // [np][K][2]
+    uint64_t* out;        // [np][3][2]
+    uint32_t K;
+};
+__global__ __launch_bounds__(kTpb) void fold_mac_kernel(FoldMacParams p) {
+    __shared__ uint64_t sh[3][64][12];
+    const uint32_t zz = threadIdx.x & 63u, kg = threadIdx.x >> 6, z = blockIdx.x * 64u + zz, i = blockIdx.y;
+    const uint64_t* dp = p.d + (size_t)i * p.K * 2 * kN + z;
+    const uint64_t* kp = p.key + z;
+    Acc2 acc[3][2];
+#pragma unroll 2
+    for (uint32_t mm = kg; mm < p.K; mm += 4) {
+        const uint64_t d0 = dp[(size_t)(2 * mm) * kN], d1 = dp[(size_t)(2 * mm + 1) * kN];
+#pragma unroll
+        for (uint32_t r = 0; r < 3; r++) {
+            const uint64_t kv = kp[((size_t)r * p.K + mm) * kN];
+            acc[r][0].mac(kv, d0);
+            acc[r][1].mac(kv, d1);
+        }
+    }
+    if (kg > 0) {
+#pragma unroll
+        for (uint32_t r = 0; r < 3; r++)
+#pragma unroll
+            for (uint32_t c = 0; c < 2; c++) {
+                sh[kg - 1][zz][(r * 2 + c) * 2] = acc[r][c].lo;
+                sh[kg - 1][zz][(r * 2 + c) * 2 + 1] = acc[r][c].hi;
+            }
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+        for (uint32_t r = 0; r < 3; r++)
+#pragma unroll
+            for (uint32_t c = 0; c < 2; c++) {
+                Acc2 a = acc[r][c];
+#pragma unroll
+                for (int q = 0; q < 3; q++) {  // K <= 256 terms in total (m2 * q fits u64, src/spiral.cpp:465)
+                    a.lo += sh[q][zz][(r * 2 + c) * 2];
+                    a.hi += sh[q][zz][(r * 2 + c) * 2 + 1];
+                }
+                p.out[((size_t)i * 6 + r * 2 + c) * kN + z] = a.reduced();
+            }
+    }
+}
+void launch_fold_mac(const uint64_t* key, const uint64_t* d, uint64_t* out, uint32_t K, uint32_t np, hipStream_t s) {
+    if (np == 0) return;
+    FoldMacParams p{key, d, out, K};
+    hipLaunchKernelGGL(fold_mac_kernel, dim3(kN / 64, np), dim3(kTpb), 0, s, p);
+}
+
 // ---- add / mul_by_const (src/poly.cpp:138-155, 190-211) ----------------------------------------------
 __global__ __launch_bounds__(kTpb) void add_kernel(const uint64_t* a, const uint64_t* b, uint64_t* out) {
     const size_t i = (size_t)blockIdx.x * kTpb + threadIdx.x;

@@ -201,6 +201,10 @@ struct spiral_gpu_server {
     DevBuf qs, acc_own, raw, fold_d, fold_c, resp, stage;
     uint64_t* acc = nullptr;
     hipEvent_t ev[8] = {};
+    // captured stage groups (hipGraph): [0] expand + convert, [1] lift + fold + finish, [2] the same with
+    // reduce_first; instantiated lazily, invalidated when a captured pointer or flag changes
+    bool use_graphs = false;
+    hipGraphExec_t graph[3] = {nullptr, nullptr, nullptr};
 };
 
 namespace {
@@ -240,7 +244,16 @@ int srv_alloc(spiral_gpu_server* S) {
     return 0;
 }
 
+void srv_drop_graphs(spiral_gpu_server* S) {
+    for (auto& g : S->graph)
+        if (g) {
+            (void)hipGraphExecDestroy(g);
+            g = nullptr;
+        }
+}
+
 void srv_free(spiral_gpu_server* S) {
+    srv_drop_graphs(S);
     DevBuf* all[] = {&S->db, &S->w_left, &S->w_right, &S->w, &S->v, &S->query, &S->cv, &S->ex_raw, &S->ex_g, &S->ex_a1, &S->cv_raw,
                      &S->cv_g, &S->gs_raw, &S->gs_chat, &S->gsw, &S->key, &S->cts_keep, &S->qs, &S->acc_own, &S->raw, &S->fold_d, &S->fold_c,
                      &S->resp, &S->stage};
@@ -534,8 +547,7 @@ int spiral_gpu_fold_one_further_dimension(uint64_t* cts, size_t num_per, const u
     fp.ell = t_gsw;
     fp.fold_np = (uint32_t)num_per;
     launch_ntt_forward(tb, fp, LD_SDIGIT, ST_PK, (uint32_t)(2 * num_per * 6 * t_gsw), 0);
-    MatmulParams mp{d_key, d_d, d_c, 3, 2 * m2, 2, 0, 2 * m2 * 2, 6};
-    launch_matmul(mp, (uint32_t)num_per, 0);
+    launch_fold_mac(d_key, d_d, d_c, 2 * m2, (uint32_t)num_per, 0);
     InvParams ip{};
     ip.src = d_c;
     ip.dst = d_cts;
@@ -695,6 +707,13 @@ void spiral_gpu_server_destroy(spiral_gpu_server* S) {
 int spiral_gpu_server_set_stream(spiral_gpu_server* S, void* hip_stream) {
     if (!S) return fail("null server");
     S->stream = hip_stream ? (hipStream_t)hip_stream : S->own_stream;
+    return 0;
+}
+
+int spiral_gpu_server_use_graphs(spiral_gpu_server* S, int on) {
+    if (!S) return fail("null server");
+    S->use_graphs = on != 0;
+    if (!on) srv_drop_graphs(S);
     return 0;
 }
 
@@ -891,8 +910,7 @@ int spiral_gpu_server_fold(spiral_gpu_server* S) {
         fp.ell = s.ell;
         fp.fold_np = np;
         launch_ntt_forward(S->tb, fp, LD_SDIGIT, ST_PK, 2 * np * 6 * s.ell, S->stream);
-        MatmulParams mp{S->key.p + (size_t)d * 3 * 2 * s.m2 * kN, S->fold_d.p, S->fold_c.p, 3, 2 * s.m2, 2, 0, 2 * s.m2 * 2, 6};
-        launch_matmul(mp, np, S->stream);
+        launch_fold_mac(S->key.p + (size_t)d * 3 * 2 * s.m2 * kN, S->fold_d.p, S->fold_c.p, 2 * s.m2, np, S->stream);
         InvParams ip{};
         ip.src = S->fold_c.p;
         ip.dst = S->raw.p;
@@ -927,25 +945,85 @@ void* spiral_gpu_server_acc(spiral_gpu_server* S, size_t* bytes) {
 int spiral_gpu_server_set_acc(spiral_gpu_server* S, void* device_ptr) {
     if (!S) return fail("null server");
     S->acc = device_ptr ? (uint64_t*)device_ptr : S->acc_own.p;
+    srv_drop_graphs(S);  // the accumulator pointer is baked into the captured lift
     return 0;
+}
+
+}  // extern "C"
+
+namespace {
+// run `body` (kernel launches on S->stream) directly, or capture it once into a hipGraph and replay it
+template <class F>
+int run_group(spiral_gpu_server* S, int slot, F body) {
+    if (!S->use_graphs) return body();
+    if (!S->graph[slot]) {
+        if (S->stream == nullptr) return fail("graph capture needs a non-default stream");
+        HIP_OK(hipStreamBeginCapture(S->stream, hipStreamCaptureModeRelaxed));
+        int rc = body();
+        hipGraph_t g = nullptr;
+        hipError_t e = hipStreamEndCapture(S->stream, &g);
+        if (rc) {
+            if (g) (void)hipGraphDestroy(g);
+            return rc;
+        }
+        if (e != hipSuccess) return fail("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        e = hipGraphInstantiate(&S->graph[slot], g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) return fail("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    }
+    HIP_OK(hipGraphLaunch(S->graph[slot], S->stream));
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int spiral_gpu_server_run_pre(spiral_gpu_server* S) {
+    if (!S) return fail("null server");
+    if (!S->have_query || !S->have_pp) return fail("query and public parameters must be set first");
+    return run_group(S, 0, [&]() {
+        if (spiral_gpu_server_expand(S)) return -1;
+        return spiral_gpu_server_convert(S);
+    });
+}
+
+int spiral_gpu_server_run_post(spiral_gpu_server* S, int reduce_first) {
+    if (!S) return fail("null server");
+    return run_group(S, reduce_first ? 2 : 1, [&]() {
+        if (spiral_gpu_server_lift(S, reduce_first)) return -1;
+        if (spiral_gpu_server_fold(S)) return -1;
+        return spiral_gpu_server_finish(S);
+    });
 }
 
 int spiral_gpu_server_answer_resident(spiral_gpu_server* S, double stage_us[8]) {
     if (!S) return fail("null server");
     HIP_OK(hipSetDevice(S->device));
     hipStream_t st = S->stream;
+    const bool g = S->use_graphs;
     HIP_OK(hipEventRecord(S->ev[0], st));
-    if (spiral_gpu_server_expand(S)) return -1;
-    HIP_OK(hipEventRecord(S->ev[1], st));
-    if (spiral_gpu_server_convert(S)) return -1;
+    if (g) {
+        if (spiral_gpu_server_run_pre(S)) return -1;
+        HIP_OK(hipEventRecord(S->ev[1], st));
+    } else {
+        if (spiral_gpu_server_expand(S)) return -1;
+        HIP_OK(hipEventRecord(S->ev[1], st));
+        if (spiral_gpu_server_convert(S)) return -1;
+    }
     HIP_OK(hipEventRecord(S->ev[2], st));
     if (spiral_gpu_server_first_dim(S)) return -1;
     HIP_OK(hipEventRecord(S->ev[3], st));
-    if (spiral_gpu_server_lift(S, 0)) return -1;
-    HIP_OK(hipEventRecord(S->ev[4], st));
-    if (spiral_gpu_server_fold(S)) return -1;
-    HIP_OK(hipEventRecord(S->ev[5], st));
-    if (spiral_gpu_server_finish(S)) return -1;
+    if (g) {
+        if (spiral_gpu_server_run_post(S, 0)) return -1;
+        HIP_OK(hipEventRecord(S->ev[4], st));
+        HIP_OK(hipEventRecord(S->ev[5], st));
+    } else {
+        if (spiral_gpu_server_lift(S, 0)) return -1;
+        HIP_OK(hipEventRecord(S->ev[4], st));
+        if (spiral_gpu_server_fold(S)) return -1;
+        HIP_OK(hipEventRecord(S->ev[5], st));
+        if (spiral_gpu_server_finish(S)) return -1;
+    }
     HIP_OK(hipEventRecord(S->ev[6], st));
     HIP_OK(hipStreamSynchronize(st));
     HIP_OK(hipGetLastError());
@@ -954,6 +1032,7 @@ int spiral_gpu_server_answer_resident(spiral_gpu_server* S, double stage_us[8]) 
         for (int i = 0; i < 6; i++) HIP_OK(hipEventElapsedTime(&ms[i], S->ev[i], S->ev[i + 1]));
         float total = 0;
         HIP_OK(hipEventElapsedTime(&total, S->ev[0], S->ev[6]));
+        // with graphs on, expansion+conversion land in [0] and lift+fold+switch in [2]/[3] as one group
         stage_us[0] = ms[0] * 1e3;
         stage_us[1] = ms[1] * 1e3;
         stage_us[2] = (ms[2] + ms[3]) * 1e3;

@@ -80,6 +80,17 @@ class Server:
     def sync(self):
         check(lib().spiral_gpu_server_sync(self.h))
 
+    def use_graphs(self, on: bool = True):
+        check(lib().spiral_gpu_server_use_graphs(self.h, 1 if on else 0))
+
+    def run_pre(self):
+        """expand + convert (one hipGraph replay when graphs are on)"""
+        check(lib().spiral_gpu_server_run_pre(self.h))
+
+    def run_post(self, reduce_first: bool = False):
+        """lift + fold + finish"""
+        check(lib().spiral_gpu_server_run_post(self.h, 1 if reduce_first else 0))
+
     def acc(self):
         nbytes = C.c_size_t()
         ptr = lib().spiral_gpu_server_acc(self.h, C.byref(nbytes))

@@ -262,6 +262,34 @@ def test_answer_and_device_db(sa, oracle, nu1, nu2, kw):
     srv.close()
 
 
+def test_graph_replay_matches_eager(sa, oracle):
+    """run_pre / run_post captured into hipGraphs and replayed for several queries == the eager stages"""
+    O = oracle
+    from spiral_amd import server as SV
+
+    kw = dict(t_gsw=4)
+    po, pg = O.make_params(4, 3, **kw), sa.make_params(4, 3, **kw)
+    cl = O.Client(po, seed=21)
+    wl, wr, w, v = cl.pub_params()
+    srv = sa.Server(pg)
+    srv.gen_db(8)
+    srv.set_pub_params(wl, wr, w, v)
+    db = O.gen_db(po, 8)
+    srv.use_graphs(True)
+    for idx in (3, 100, 127, 3):
+        q = cl.query(idx)
+        srv.set_query(q)
+        srv.run_pre()
+        srv.first_dim()
+        srv.run_post()
+        srv.sync()
+        assert_eq(srv.read(SV.BUF_FINAL), O.answer(po, q, wl, wr, w, v, db), f"graph replay idx={idx}")
+        assert_eq(cl.decode(srv.read(SV.BUF_RESPONSE)), O.db_item(po, 8, idx), "decoded plaintext")
+    fin, resp, us = srv.answer(cl.query(5))  # answer() through the graphs too
+    assert_eq(cl.decode(resp), O.db_item(po, 8, 5), "decoded plaintext via answer()")
+    srv.close()
+
+
 def test_sharded_first_dim_sums_to_unsharded(sa, oracle):
     """two j-shards on one device: summing their accumulators (what the RCCL reduce does) == one server"""
     O = oracle
