@@ -22,6 +22,19 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def pmc_traffic(n_gpus, nu1, nu2):
+    """HBM bytes per sweep launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
+    runs, corrected as MI355X_MICROARCH.md prescribes); only valid for the configuration it was taken on"""
+    try:
+        files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("sweep_pmc.json"))
+        d = json.load(open(os.path.join(ROOT, "profiles", files[-1])))
+        if n_gpus == 1 and (nu1, nu2) == (8, 7):
+            return d["traffic_bytes_per_launch"], files[-1]
+    except Exception:
+        pass
+    return None, None
+
+
 def synth_residues(rng, np, shape):
     """uniform canonical NTT-form polynomials [..., 2, N] (synthetic query / public parameters)"""
     import spiral_amd as sa
@@ -145,6 +158,7 @@ def main():
     sweep_ms = stages["sweep"] / 1e3
     bytes_sweep = srv.sweep_bytes()
     achieved = bytes_sweep / (sweep_ms * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic(world, args.nu1, args.nu2)
     out = {
         "metric": "server ms/query (2^20 x 256B, Base Spiral nu1=8 nu2=7) + first-dim sweep GB/s vs HBM roofline",
         "value": round(ms_per_step, 4),
@@ -165,7 +179,7 @@ def main():
         "stages_us": {k: round(v, 1) for k, v in stages.items()},
         "reference_buckets_us_eager": ({k: round(v, 1) for k, v in detail.items() if k != "reserved"} if detail else None),
         "roofline": {"bound": "hbm", "kernel": "sweep_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "algorithmic_bytes_per_launch": int(bytes_sweep),
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(bytes_sweep),
                      "avg_launch_ms": round(sweep_ms, 4), "shard": f"j in [{j0},{j1}) on rank 0"},
     }
     if rank == 0:
