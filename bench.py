@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--nu2", type=int, default=7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the reduce even with one rank (self-test)")
     args = ap.parse_args()
 
     import numpy as np
@@ -89,10 +90,14 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
     params_kw = dict(nu1=args.nu1, nu2=args.nu2, t_gsw=8, t_conv=4, t_exp=8, t_exp_right=56, qprime_bits=20, p_db=256)
@@ -121,14 +126,14 @@ def main():
         if e: e[1].record(stream)
         srv.first_dim()
         if e: e[2].record(stream)
-        if world > 1:
+        if use_dist:
             sdist.reduce_accumulators(acc, dst=0)
         if rank == 0:
-            srv.run_post(reduce_first=world > 1)
+            srv.run_post(reduce_first=use_dist)
         if e: e[3].record(stream)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -141,7 +146,7 @@ def main():
             step(ev[k])
         fence()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -187,7 +192,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(params_kw, np)
         print(json.dumps(out), flush=True)
     srv.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

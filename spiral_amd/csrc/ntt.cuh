@@ -18,24 +18,32 @@ struct Tables {
 };
 
 // ---- butterflies --------------------------------------------------------------------------------
-// forward (Cooley-Tukey, Harvey lazy): x, y in [0, 4m) -> [0, 4m)      (src/core.cpp:274-290)
-__device__ __forceinline__ void ct_bfly(uint32_t& x, uint32_t& y, uint32_t w, uint32_t ws, uint32_t m) {
-    const uint32_t m2 = 2 * m;
-    uint32_t cx = x >= m2 ? x - m2 : x;
-    uint32_t q = __umulhi(y, ws);
-    uint32_t t = w * y - q * m;  // [0, 2m)
-    x = cx + t;
-    y = cx + (m2 - t);
+// Both primes are < 2^28, so a u32 holds values up to 16 m.  The butterflies are therefore fully lazy: no
+// conditional subtraction inside a stage, one multiply-based range reduction where the bound would otherwise
+// pass 14 m.  (The reference keeps [0, 4m) with a conditional subtract per butterfly, src/core.cpp:274-290;
+// the canonical results are identical.)
+//
+// Shoup product: t = W*y - floor(W'*y / 2^32)*m lies in [0, 2m) for ANY y < 2^32.
+__device__ __forceinline__ uint32_t shoup(uint32_t y, uint32_t w, uint32_t ws, uint32_t m) {
+    return w * y - __umulhi(y, ws) * m;
 }
-// inverse (Gentleman-Sande, 1/2 per stage): u, v in [0, 2m) -> [0, 2m)  (src/core.cpp:445-472)
+// [0, 14m] -> [0, 2m): x - floor(x / 2^28) * m  (m > 0.9296 * 2^28, so the quotient is off by at most one)
+__device__ __forceinline__ uint32_t lazy_reduce(uint32_t x, uint32_t m) { return x - (x >> 28) * m; }
+// forward (Cooley-Tukey): bound grows by 2m per stage
+__device__ __forceinline__ void ct_bfly(uint32_t& x, uint32_t& y, uint32_t w, uint32_t ws, uint32_t m) {
+    const uint32_t t = shoup(y, w, ws, m);
+    const uint32_t x0 = x;
+    x = x0 + t;
+    y = x0 + 2 * m - t;
+}
+// inverse (Gentleman-Sande, 1/2 folded per stage, src/core.cpp:445-472): the sum side grows by m/2 per stage,
+// the product side is always < 2m.  8m - v keeps the difference positive (v < 8m) and, 8m being even and m odd,
+// u + 8m - v has the parity of u + v, which is what the exact halving needs.
 __device__ __forceinline__ void gs_bfly(uint32_t& u, uint32_t& v, uint32_t w, uint32_t ws, uint32_t m) {
-    const uint32_t m2 = 2 * m;
-    uint32_t t = m2 - v + u;
-    uint32_t s = u + v;
-    s = s >= m2 ? s - m2 : s;
-    u = (s + ((t & 1u) ? m : 0u)) >> 1;
-    uint32_t q = __umulhi(t, ws);
-    v = w * t - q * m;
+    const uint32_t t = u + 8 * m - v;
+    const uint32_t s = u + v;
+    u = (s + ((s & 1u) ? m : 0u)) >> 1;
+    v = shoup(t, w, ws, m);
 }
 
 __device__ __forceinline__ void ct2(uint32_t* lo, uint32_t* hi, int a, int b, uint4 tw) {
@@ -120,8 +128,9 @@ __device__ __forceinline__ void lds_get(const uint64_t* sh, uint32_t tid, uint32
     }
 }
 
-// Forward transform of the 2048 coefficients held as (lo,hi)[k] <-> index ix_a(tid,k), values < 4m.
+// Forward transform of the 2048 coefficients held as (lo,hi)[k] <-> index ix_a(tid,k), values < 2m.
 // On return (lo,hi)[k] <-> slot ix_d(tid,k) = 8*tid + k, canonical in [0, m).
+// Bounds: < 2m in; +6m per pass: < 14m after passes A and B -> reduced to < 2m; < 12m after C and D.
 __device__ __forceinline__ void ntt_forward_block(uint32_t* lo, uint32_t* hi, uint64_t* sh, const uint4* tw, uint32_t tid) {
     ct_radix8(lo, hi, tw, 1, 2, 4);
     lds_put<ix_a>(sh, tid, lo, hi);
@@ -129,6 +138,11 @@ __device__ __forceinline__ void ntt_forward_block(uint32_t* lo, uint32_t* hi, ui
     lds_get<ix_b>(sh, tid, lo, hi);
     uint32_t g = tid >> 5;
     ct_radix8(lo, hi, tw, 8 + g, 16 + 2 * g, 32 + 4 * g);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        lo[k] = lazy_reduce(lo[k], kP);
+        hi[k] = lazy_reduce(hi[k], kB);
+    }
     lds_put<ix_b>(sh, tid, lo, hi);
     __syncthreads();
     lds_get<ix_c>(sh, tid, lo, hi);
@@ -140,13 +154,14 @@ __device__ __forceinline__ void ntt_forward_block(uint32_t* lo, uint32_t* hi, ui
     ct_radix4x2(lo, hi, tw, 512 + 2 * tid, 1024 + 4 * tid);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        lo[k] = csub(csub(lo[k], 2 * kP), kP);
-        hi[k] = csub(csub(hi[k], 2 * kB), kB);
+        lo[k] = csub(lazy_reduce(lo[k], kP), kP);
+        hi[k] = csub(lazy_reduce(hi[k], kB), kB);
     }
 }
 
 // Inverse transform: in (lo,hi)[k] <-> slot ix_d(tid,k), values in [0, 2m);
 // out (lo,hi)[k] <-> coefficient ix_a(tid,k) = tid + 256k, canonical in [0, m).
+// Bounds: sum side < 2m + 11 * m/2 = 7.5m, product side < 2m: every t = u + 8m - v is in (0, 15.5m).
 __device__ __forceinline__ void ntt_inverse_block(uint32_t* lo, uint32_t* hi, uint64_t* sh, const uint4* tw, uint32_t tid) {
     gs_radix4x2(lo, hi, tw, 512 + 2 * tid, 1024 + 4 * tid);
     lds_put<ix_d>(sh, tid, lo, hi);
@@ -165,8 +180,8 @@ __device__ __forceinline__ void ntt_inverse_block(uint32_t* lo, uint32_t* hi, ui
     gs_radix8(lo, hi, tw, 1, 2, 4);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        lo[k] = csub(lo[k], kP);
-        hi[k] = csub(hi[k], kB);
+        lo[k] = csub(lazy_reduce(lo[k], kP), kP);
+        hi[k] = csub(lazy_reduce(hi[k], kB), kB);
     }
 }
 

@@ -26,6 +26,10 @@ __device__ __forceinline__ uint64_t digit_of(uint64_t v, uint32_t k, uint32_t bi
     return sh >= 64 ? 0ull : ((v >> sh) & mask);  // a shift count >= 64 is UB in src/util.cpp:136; defined as 0
 }
 
+// a gadget digit is < 2^bits <= 2^32 (bits = 32 only through the to_ntt_no_reduce seam, whose contract is
+// values < 2^29); the forward transform wants its inputs below 2m
+__device__ __forceinline__ uint32_t digit_residue(uint32_t d, uint32_t m) { return d < (1u << 28) ? d : d % m; }
+
 // balanced digit k of v under split_and_crt's two carry chains (src/spiral.cpp:283-292, 313-322),
 // returned as residues (mod p, mod b); a borrowed digit is piece + Q - 2^bits == piece - 2^bits (mod m)
 __device__ __forceinline__ void sdigit_of(uint64_t v, uint32_t k, uint32_t bits, uint32_t ell, uint32_t& rp, uint32_t& rb) {
@@ -45,8 +49,8 @@ __device__ __forceinline__ void sdigit_of(uint64_t v, uint32_t k, uint32_t bits,
         rp = kP - d;
         rb = kB - d;
     } else {
-        rp = (uint32_t)piece;
-        rb = (uint32_t)piece;
+        rp = digit_residue((uint32_t)piece, kP);
+        rb = digit_residue((uint32_t)piece, kB);
     }
 }
 
@@ -100,8 +104,8 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
             uint64_t v = load_raw(src, idx, p.tinv);
             if (is_digit) {
                 uint32_t d = (uint32_t)digit_of(v, k, bits, mask);
-                lo[r] = d;
-                hi[r] = d;
+                lo[r] = digit_residue(d, kP);
+                hi[r] = digit_residue(d, kB);
             } else {
                 lo[r] = mod_p(v);
                 hi[r] = mod_b(v);
@@ -113,8 +117,8 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             uint32_t idx = ix_a(tid, r);
-            lo[r] = (uint32_t)src[idx];
-            hi[r] = (uint32_t)src[kN + idx];
+            lo[r] = csub((uint32_t)src[idx], 2 * kP);  // the reference accepts lazy inputs < 4m here
+            hi[r] = csub((uint32_t)src[kN + idx], 2 * kB);
         }
     } else {
         const uint64_t* src = p.src + (size_t)p.src_map(s) * kN;
@@ -128,8 +132,8 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
                 hi[r] = mod_b(v);
             } else if constexpr (LOAD == LD_DIGIT) {
                 uint32_t d = (uint32_t)digit_of(v, k, p.bits, mask);
-                lo[r] = d;
-                hi[r] = d;
+                lo[r] = digit_residue(d, kP);
+                hi[r] = digit_residue(d, kB);
             } else {
                 sdigit_of(v, k, p.bits, p.ell, lo[r], hi[r]);
             }
