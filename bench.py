@@ -187,13 +187,14 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(bytes_sweep),
                      "avg_launch_ms": round(sweep_ms, 4), "shard": f"j in [{j0},{j1}) on rank 0"},
     }
-    if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(params_kw, np)
-        print(json.dumps(out), flush=True)
     srv.close()
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(params_kw, np)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)  # the ONE JSON line, last thing on stdout
 
 
 if __name__ == "__main__":
