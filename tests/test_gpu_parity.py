@@ -332,3 +332,41 @@ def test_full_size_config2_end_to_end(sa, oracle):
         fin, resp, us = srv.answer(cl.query(idx))
         assert_eq(cl.decode(resp), O.db_item(po, 1234, idx), "decoded plaintext at full size")
     srv.close()
+
+
+@pytest.mark.slow
+def test_full_size_stream_direct_upload(sa, oracle):
+    """SpiralStream-style direct upload at the published "(20, 256)/spiralstream" parameters
+    (all_parameter_choices.txt:82-97: nu1=9, nu2=6, p=256, q'=2^19, t_GSW=5, t_conv=4): 512 + 30 uploaded
+    Regev ciphertexts, no expansion, 2 GiB NTT-form database on the device.  Property: decodes to the item."""
+    O = oracle
+    kw = dict(t_gsw=5, t_conv=4, t_exp=2, t_exp_right=56, qprime_bits=19, p_db=256, direct_upload=1)
+    po, pg = O.make_params(9, 6, **kw), sa.make_params(9, 6, **kw)
+    cl = O.Client(po, seed=4)
+    wl, wr, w, v = cl.pub_params()
+    srv = sa.Server(pg)
+    srv.gen_db(777)
+    srv.set_pub_params(wl, wr, w, v)
+    for idx in (31337 % (1 << 15), 0):
+        fin, resp, us = srv.answer(cl.query(idx))
+        assert_eq(cl.decode(resp), O.db_item(po, 777, idx), "decoded plaintext (direct upload, full size)")
+    srv.close()
+
+
+@pytest.mark.slow
+def test_full_size_config3_on_one_gpu(sa, oracle):
+    """BASELINE.json config 3 geometry (2^24 x 256 B: nu1=9, nu2=10, t_GSW=10, q'=2^22) held on ONE
+    MI355X: 32 GiB NTT-form database generated on the device.  Property: the response decodes to the item."""
+    O = oracle
+    kw = dict(t_gsw=10, t_conv=4, t_exp=8, t_exp_right=56, qprime_bits=22, p_db=256)
+    po, pg = O.make_params(9, 10, **kw), sa.make_params(9, 10, **kw)
+    cl = O.Client(po, seed=6)
+    wl, wr, w, v = cl.pub_params()
+    srv = sa.Server(pg)
+    srv.gen_db(99)
+    srv.set_pub_params(wl, wr, w, v)
+    idx = 424242 % (1 << 19)
+    fin, resp, us = srv.answer(cl.query(idx))
+    assert_eq(cl.decode(resp), O.db_item(po, 99, idx), "decoded plaintext (config 3, 32 GiB)")
+    print("config 3 on one GPU, stage us:", {k: round(x) for k, x in us.items()}, "sweep GB/s:", round(srv.sweep_bytes() / us["sweep_kernel_us"] / 1e3))
+    srv.close()
