@@ -166,7 +166,7 @@ int spiral_gpu_server_set_acc(spiral_gpu_server *s, void *device_ptr);
 /* whole path for one query: set_query, expand, convert, first_dim, lift, fold, finish, sync.
  * final_ct: raw n1 x n2 (may be NULL); response: rescaled n1 x n2 (may be NULL).
  * stage_us (may be NULL): [0] expansion [1] conversion [2] first-dimension multiply (sweep + lift)
- * [3] folding [4] response switch [5] sweep kernel alone [6] total device time [7] reserved,
+ * [3] folding [4] response switch [5] sweep kernel alone [6] total device time [7] ScalToMat share of [1],
  * the reference's buckets of src/spiral.cpp:246-257, measured with HIP events on the server stream. */
 int spiral_gpu_server_answer(spiral_gpu_server *s, const uint64_t *query, uint64_t *final_ct,
                              uint64_t *response, double stage_us[8]);

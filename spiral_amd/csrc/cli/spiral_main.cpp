@@ -1,0 +1,200 @@
+// ./spiral -- drop-in for the reference executable's command line and text summary (src/spiral.cpp:1228-1346,
+// 209-265), with the server-answer path running on an MI355X through libspiral_gpu.so.
+//
+//   ./spiral <nu1> <nu2> <IDX_TARGET> <dbfile|"a"> [--random-data] [--direct-upload] [--nonoise] [--show-diff] [--seed N]
+//
+// The reference fixes its scheme parameters at compile time (-DTEXP ... -DOUTN, include/values.h:78-93,
+// select_params.py:337); here the same nine values are read at run time from the environment variables or
+// flags of the same names (TEXP, TEXPRIGHT, TCONV, TGSW, QPBITS, PVALUE, QNUMFIRST, QNUMREST, OUTN), defaulting
+// to the paper's (20, 256) set.  The stdout lines select_params.py scrapes (:386-401) keep their wording.
+// --high-rate (SpiralPack) is not implemented yet and exits with an error rather than computing something else.
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iomanip>
+#include <iostream>
+#include <string>
+
+#include "client.hpp"
+
+using namespace spiral_cli;
+using std::cout;
+using std::endl;
+
+static uint64_t now_us() {
+    return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static uint64_t param(int argc, char** argv, const char* name, uint64_t dflt) {
+    std::string flag = std::string("--") + name;
+    for (auto& ch : flag) ch = (char)tolower(ch);
+    for (int i = 5; i + 1 < argc; i++)
+        if (flag == argv[i]) return strtoull(argv[i + 1], nullptr, 10);
+    if (const char* e = getenv(name)) return strtoull(e, nullptr, 10);
+    return dflt;
+}
+
+#define GPU_OK(x)                                                              \
+    do {                                                                       \
+        if ((x) != 0) {                                                        \
+            fprintf(stderr, "spiral: %s\n", spiral_gpu_last_error());          \
+            exit(1);                                                           \
+        }                                                                      \
+    } while (0)
+
+int main(int argc, char** argv) {
+    if (argc < 4) {
+        fprintf(stderr, "usage: %s <nu1> <nu2> <IDX_TARGET> [dbfile|a] [--random-data] [--direct-upload] [--nonoise] [--show-diff] [--seed N]\n", argv[0]);
+        return 1;
+    }
+    const uint32_t nu1 = (uint32_t)strtol(argv[1], nullptr, 10), nu2 = (uint32_t)strtol(argv[2], nullptr, 10);
+    const uint64_t total_n = (1ull << nu1) * (1ull << nu2);
+    const uint64_t idx_target = strtoull(argv[3], nullptr, 10);
+    bool nonoise = false, random_data = false, show_diff = false, direct_flag = false, high_rate = false;
+    uint64_t seed = std::chrono::steady_clock::now().time_since_epoch().count();  // reference: random_device (src/core.cpp:202)
+    for (int i = 5; i < argc; i++) {  // flags are only parsed after the db filename (src/spiral.cpp:1250-1303)
+        if (!strcmp(argv[i], "--nonoise")) { cout << "Using no noise" << endl; nonoise = true; }
+        if (!strcmp(argv[i], "--high-rate")) { cout << "Using high rate variant..." << endl; high_rate = true; }
+        if (!strcmp(argv[i], "--random-data")) { cout << "Using random data..." << endl; random_data = true; }
+        if (!strcmp(argv[i], "--show-diff")) { cout << "Showing diff..." << endl; show_diff = true; }
+        if (!strcmp(argv[i], "--direct-upload")) { cout << "Direct uploading of query (no compression)" << endl; direct_flag = true; }
+        if (!strcmp(argv[i], "--seed") && i + 1 < argc) seed = strtoull(argv[++i], nullptr, 10);
+    }
+    if (high_rate) {
+        fprintf(stderr, "spiral: --high-rate (SpiralPack, src/testing.cpp) is not implemented in this build\n");
+        return 1;
+    }
+    if (idx_target >= total_n) {
+        fprintf(stderr, "spiral: IDX_TARGET %llu out of range (n = %llu)\n", (unsigned long long)idx_target, (unsigned long long)total_n);
+        return 1;
+    }
+
+    spiral_gpu_params p{};
+    p.nu1 = nu1;
+    p.nu2 = nu2;
+    p.t_exp = (uint32_t)param(argc, argv, "TEXP", 8);
+    p.t_exp_right = (uint32_t)param(argc, argv, "TEXPRIGHT", 56);
+    p.t_conv = (uint32_t)param(argc, argv, "TCONV", 4);
+    p.t_gsw = (uint32_t)param(argc, argv, "TGSW", 8);
+    p.qprime_bits = (uint32_t)param(argc, argv, "QPBITS", 20);
+    p.p_db = param(argc, argv, "PVALUE", 256);
+    const uint64_t qnum_first = param(argc, argv, "QNUMFIRST", direct_flag ? (1ull << nu1) : 1);
+    const uint64_t qnum_rest = param(argc, argv, "QNUMREST", direct_flag ? (uint64_t)p.t_gsw * nu2 : 0);
+    const bool du_first = qnum_first >= (1ull << nu1), du_rest = qnum_rest >= (uint64_t)nu2 * p.t_gsw;  // src/spiral.cpp:2060-2061
+    if (du_first != du_rest || (!du_first && (qnum_first != 1 || qnum_rest != 0))) {
+        fprintf(stderr, "spiral: unsupported QNUMFIRST/QNUMREST combination (supported: 1/0 and 2^nu1 / t_GSW*nu2)\n");
+        return 1;
+    }
+    p.direct_upload = du_first ? 1 : 0;
+    if (du_rest) cout << "directly uploading Regev -> GSW ciphertexts" << endl;
+
+    if (spiral_gpu_device_count() <= 0) {
+        fprintf(stderr, "spiral: no ROCm device found; this build has no CPU path\n");
+        return 1;
+    }
+    spiral_gpu_shape s;
+    GPU_OK(spiral_gpu_get_shape(&p, &s));
+    cout << "dim0: " << s.dim0 << endl;
+    cout << "num_per: " << s.num_per << endl;
+
+    // ---- database (load_db, src/spiral.cpp:1028-1172): explicit seeded database generated on the device; with
+    // --random-data the same (a full-size database is cheap on the GPU, so the result is still checkable)
+    const uint64_t db_seed = 1234;
+    spiral_gpu_server* srv = nullptr;
+    GPU_OK(spiral_gpu_server_create(&p, 0, 0, 0, &srv));
+    cout << "starting generation of db" << endl;
+    GPU_OK(spiral_gpu_server_gen_db(srv, db_seed));
+    cout << "done loading/generating db." << endl;
+    (void)random_data;
+
+    // ---- client: keys, public parameters, query
+    double time_key_gen = 0, time_query_gen = 0, time_decoding = 0;
+    Client cl(p, seed, nonoise);
+    uint64_t t0 = now_us();
+    cl.keygen();
+    cl.gen_pub_params();
+    time_key_gen = (double)(now_us() - t0);
+    if (!p.direct_upload) {
+        cout << "g = " << s.g << endl;
+        cout << "stopround = " << s.stopround << endl;
+    }
+    t0 = now_us();
+    Poly query = cl.query(idx_target);
+    time_query_gen = (double)(now_us() - t0);
+
+    // ---- server
+    cout << "Beginning query processing..." << endl;
+    GPU_OK(spiral_gpu_server_set_pub_params(srv, cl.w_left.data(), cl.w_right.data(), cl.w.data(), cl.v.data()));
+    Poly final_ct(6 * N), resp(6 * N);
+    double us[8];
+    GPU_OK(spiral_gpu_server_answer(srv, query.data(), final_ct.data(), resp.data(), us));  // warm-up (table upload, first launches)
+    GPU_OK(spiral_gpu_server_answer(srv, query.data(), final_ct.data(), resp.data(), us));
+    const double time_expansion_main = us[0], time_conversion = us[1], time_first_multiply = us[2], time_folding = us[3];
+    cout << std::fixed << std::setprecision(0);
+    cout << "Expansion took (CPU·us): " << time_expansion_main << endl;
+    if (p.direct_upload) cout << "directly uploading Regev ciphertexts" << endl;
+    cout << "ScalToMat took (CPU·us): " << us[7] << endl;
+    cout << "RegevToGSW took (CPU·us): " << (us[1] - us[7]) << endl;
+    cout << "done folding" << endl;
+    cout << "Done with query processing!" << endl;
+
+    // ---- client decode + check_final (src/spiral.cpp:1412-1494)
+    t0 = now_us();
+    Poly pt = cl.decode(resp.data());
+    time_decoding = (double)(now_us() - t0);
+    Poly corr = db_item(db_seed, idx_target, p.p_db);
+    const bool is_corr = pt == corr;
+    cout << "Is correct?: " << (is_corr ? 1 : 0) << endl;
+    if (show_diff)
+        for (size_t i = 0; i < pt.size(); i++)
+            if (pt[i] != corr[i]) cout << i << " " << corr[i] << ", " << pt[i] << endl;
+
+    // ---- print_summary (src/spiral.cpp:209-265)
+    const double pt_mod = std::log2((double)p.p_db);
+    const size_t pt_elem_size = (size_t)((2.0 * 2 * N * pt_mod) / 8.0);
+    const size_t b_per_elem = (size_t)((double)N * 56 / 8.0);
+    const size_t dim0_query_size = (size_t)(qnum_first + qnum_rest) * 2 * b_per_elem;
+    const size_t total_resp_size = (size_t)(((2 * 2 * (double)N * (pt_mod + 2)) + (2 * (double)N * (double)p.qprime_bits)) / 8.0);
+    cout << endl;
+    cout << "PIR over n=" << total_n << " elements of size " << pt_elem_size << " bytes each." << endl;
+    cout << "The database is structured as " << (1 << nu1) << " x 2^" << nu2 << "." << endl;
+    cout << endl;
+    cout << "Communication" << endl;
+    cout << endl;
+    cout << "         Total offline query size (b): " << cl.offline_bytes << endl;
+    cout << "                  First dimension (b): " << dim0_query_size << endl;
+    cout << "       Total for other dimensions (b): " << 0 << endl;
+    cout << "          Total online query size (b): " << dim0_query_size << endl;
+    cout << "                    Response size (b) : " << total_resp_size << endl;
+    cout << endl;
+    cout << endl;
+    cout << "Database-independent computation" << endl;
+    cout << endl;
+    cout << "              Main expansion  (CPU·us): " << time_expansion_main << endl;
+    cout << "  Further dimension expansion (CPU·us): " << 0 << endl;
+    cout << "                   Conversion (CPU·us): " << time_conversion << endl;
+    cout << "                        Total (CPU·us): " << (time_expansion_main + time_conversion) << endl;
+    cout << endl;
+    cout << "Database-dependent computation" << endl;
+    cout << endl;
+    cout << "     First dimension multiply (CPU·us): " << time_first_multiply << endl;
+    cout << "                      Folding (CPU·us): " << time_folding << endl;
+    cout << "                        Total (CPU·us): " << (time_first_multiply + time_folding) << endl;
+    cout << endl;
+    cout << "Client computation" << endl;
+    cout << endl;
+    cout << "               Key generation (CPU·us): " << time_key_gen << endl;
+    cout << "             Query generation (CPU·us): " << time_query_gen << endl;
+    cout << "                     Decoding (CPU·us): " << time_decoding << endl;
+    cout << endl;
+    // MI355X extras (not scraped by select_params.py)
+    cout << "GPU extras" << endl;
+    cout << endl;
+    cout << "        Sweep kernel alone (GPU·us): " << us[5] << endl;
+    cout << "      Response switch kernel (GPU·us): " << us[4] << endl;
+    cout << "        Whole answer, device (GPU·us): " << us[6] << endl;
+    spiral_gpu_server_destroy(srv);
+    return is_corr ? 0 : 2;
+}

@@ -845,6 +845,7 @@ int spiral_gpu_server_convert(spiral_gpu_server* S) {
         sp.j_base = 0;
         launch_scal2mat(sp, st);
     }
+    if (!S->use_graphs) HIP_OK(hipEventRecord(S->ev[7], st));  // ScalToMat | RegevToGSW split of the reference summary
     // ---- regevToGSW for the nu2 further dimensions + fold keys (src/spiral.cpp:2315-2331, 2361-2386)
     if (p.nu2) {
         const uint32_t ngs = p.nu2 * s.ell;
@@ -1041,6 +1042,11 @@ int spiral_gpu_server_answer_resident(spiral_gpu_server* S, double stage_us[8]) 
         stage_us[5] = ms[2] * 1e3;
         stage_us[6] = total * 1e3;
         stage_us[7] = 0;
+        if (!g) {  // ScalToMat share of the conversion bucket (src/spiral.cpp:2254-2256)
+            float s2m = 0;
+            HIP_OK(hipEventElapsedTime(&s2m, S->ev[1], S->ev[7]));
+            stage_us[7] = s2m * 1e3;
+        }
     }
     return 0;
 }

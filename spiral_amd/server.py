@@ -11,7 +11,7 @@ from ._lib import U64P, Params, Shape, check, lib
 N = 2048
 
 BUF_EXPANDED, BUF_CTS, BUF_GSW, BUF_ACC, BUF_RAW, BUF_FINAL, BUF_RESPONSE = range(7)
-STAGE_NAMES = ["expansion_us", "conversion_us", "first_dim_us", "folding_us", "response_us", "sweep_kernel_us", "total_us", "reserved"]
+STAGE_NAMES = ["expansion_us", "conversion_us", "first_dim_us", "folding_us", "response_us", "sweep_kernel_us", "total_us", "scaltomat_us"]
 
 
 def _p(a: np.ndarray):
