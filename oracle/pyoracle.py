@@ -52,8 +52,8 @@ class Shape(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(HERE, "spiral_oracle.c")
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(HERE, f) for f in ("spiral_oracle.c", "spiral_oracle_pack.c", "spiral_oracle.h")]
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", HERE, "-s"])
     return LIB_PATH
 
@@ -82,6 +82,14 @@ def lib():
         _lib.orc_get_bits_per.argtypes = [C.c_uint32]
         _lib.orc_db_coeff.restype = C.c_uint64
         _lib.orc_db_coeff.argtypes = [C.c_uint64] * 4
+        _lib.orc_pack_client_new.restype = C.c_void_p
+        _lib.orc_pack_client_new.argtypes = [C.POINTER(Params), C.c_uint32, C.c_uint64, C.c_int]
+        _lib.orc_pack_client_free.argtypes = [C.c_void_p]
+        _lib.orc_pack_words_v.restype = C.c_size_t
+        _lib.orc_pack_words_v.argtypes = [C.POINTER(Params)]
+        for name in ("orc_pack_words_vw", "orc_pack_words_query"):
+            getattr(_lib, name).restype = C.c_size_t
+            getattr(_lib, name).argtypes = [C.POINTER(Params), C.c_uint32]
     return _lib
 
 
@@ -345,4 +353,106 @@ class Client:
     def decode(self, resp):
         out = u64(2, 2, N)
         lib().orc_client_decode(C.c_void_p(self.h), _p(np.ascontiguousarray(resp)), _p(out))
+        return out
+
+
+# ---- SpiralPack (src/testing.cpp) ----
+class PackShape(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("dim0", "num_per", "ell", "g", "stopround", "n_left", "n_right", "n_query_cts", "trials")] + [("qprime", C.c_uint64)]
+
+
+def pack_shape_of(p: Params, out_n: int) -> PackShape:
+    s = PackShape()
+    if lib().orc_pack_get_shape(C.byref(p), C.c_uint32(out_n), C.byref(s)) != 0:
+        raise ValueError("unsupported SpiralPack parameter set")
+    return s
+
+
+def pack_gen_db(p, out_n, seed):
+    s = pack_shape_of(p, out_n)
+    db = u64(s.trials, s.dim0 * s.num_per * N)
+    lib().orc_pack_gen_db(C.byref(p), C.c_uint32(out_n), C.c_uint64(seed), _p(db))
+    return db
+
+
+def pack_db_item(p, out_n, seed, item):
+    out = u64(out_n, out_n, N)
+    lib().orc_pack_db_item(C.byref(p), C.c_uint32(out_n), C.c_uint64(seed), C.c_uint64(item), _p(out))
+    return out
+
+
+def pack_answer(p, out_n, query, w_left, w_right, v, v_w, db):
+    resp = u64(out_n + 1, out_n, N)
+    fin = u64(out_n + 1, out_n, 2, N)
+    rc = lib().orc_pack_answer(C.byref(p), C.c_uint32(out_n), _p(query), _p(w_left), _p(w_right), _p(v), _p(v_w), _p(np.ascontiguousarray(db)), _p(resp), _p(fin))
+    assert rc == 0
+    return resp, fin
+
+
+def reorient_dim1(cts, dim0, idx_factor):
+    out = u64(N, dim0, 2)
+    lib().orc_reorient_dim1(_p(out), _p(np.ascontiguousarray(cts)), C.c_size_t(dim0), C.c_size_t(idx_factor))
+    return out
+
+
+def sweep_dim1(db, reoriented, dim0, num_per):
+    out = u64(num_per, 2, 2, N)
+    lib().orc_sweep_dim1(_p(out), _p(np.ascontiguousarray(db)), _p(reoriented), C.c_size_t(dim0), C.c_size_t(num_per))
+    return out
+
+
+def regev_to_simple_gsw(cv, v, t_conv, ell, nu2):
+    out = u64(nu2, 2, 2 * ell, 2, N)
+    lib().orc_regev_to_simple_gsw(_p(out), _p(np.ascontiguousarray(cv)), _p(np.ascontiguousarray(v)), C.c_uint32(t_conv), C.c_uint32(ell), C.c_uint32(nu2))
+    return out
+
+
+def pack_fold_neg(gsw, ell, nu2):
+    out = np.zeros_like(gsw)
+    lib().orc_pack_fold_neg(_p(out), _p(np.ascontiguousarray(gsw)), C.c_uint32(ell), C.c_uint32(nu2))
+    return out
+
+
+def fold_dim1(raw_cts, folding, folding_neg, ell, nu2):
+    x = np.ascontiguousarray(raw_cts, dtype=np.uint64).copy()
+    lib().orc_fold_dim1(_p(x), C.c_size_t(x.shape[0]), _p(np.ascontiguousarray(folding)), _p(np.ascontiguousarray(folding_neg)), C.c_uint32(ell), C.c_uint32(nu2))
+    return x[0]
+
+
+def pack(v_ct, v_w, out_n, t_conv):
+    out = u64(out_n + 1, out_n, 2, N)
+    lib().orc_pack(_p(out), C.c_uint32(out_n), C.c_uint32(t_conv), _p(np.ascontiguousarray(v_ct)), _p(np.ascontiguousarray(v_w)))
+    return out
+
+
+class PackClient:
+    def __init__(self, p: Params, out_n: int, seed: int = 1, nonoise: bool = False):
+        self.p, self.out_n = p, out_n
+        self.h = lib().orc_pack_client_new(C.byref(p), C.c_uint32(out_n), C.c_uint64(seed), C.c_int(1 if nonoise else 0))
+        if not self.h:
+            raise ValueError("unsupported SpiralPack parameter set")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_pack_client_free(C.c_void_p(self.h))
+            self.h = None
+
+    def pub_params(self):
+        L, p = lib(), self.p
+        s = pack_shape_of(p, self.out_n)
+        wl = u64(max(s.n_left * 2 * p.t_exp * NTTP, 1))
+        wr = u64(max(s.n_right * 2 * p.t_exp_right * NTTP, 1))
+        v = u64(L.orc_pack_words_v(C.byref(p)))
+        vw = u64(L.orc_pack_words_vw(C.byref(p), C.c_uint32(self.out_n)))
+        L.orc_pack_client_pub_params(C.c_void_p(self.h), _p(wl), _p(wr), _p(v), _p(vw))
+        return wl, wr, v, vw
+
+    def query(self, idx):
+        q = u64(lib().orc_pack_words_query(C.byref(self.p), C.c_uint32(self.out_n)))
+        lib().orc_pack_client_query(C.c_void_p(self.h), C.c_uint64(idx), _p(q))
+        return q
+
+    def decode(self, resp):
+        out = u64(self.out_n, self.out_n, N)
+        lib().orc_pack_client_decode(C.c_void_p(self.h), _p(np.ascontiguousarray(resp)), _p(out))
         return out

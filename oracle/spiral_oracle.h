@@ -151,4 +151,61 @@ void orc_client_decode(orc_client *c, const uint64_t *resp, uint64_t *pt_out);
 #ifdef __cplusplus
 }
 #endif
+
+/* =====================================================================================================
+ * SpiralPack / SpiralStreamPack path (reference src/testing.cpp, `--high-rate`): base_dim x 1 scalar Regev
+ * ciphertexts, 1 x 1 plaintexts, out_n^2 independent database "trials", key-switch packing into one
+ * (out_n+1) x out_n ciphertext.  Same test-infrastructure-only status as the rest of this header.
+ * ===================================================================================================== */
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_pack_shape {
+    uint32_t dim0, num_per, ell, g, stopround;
+    uint32_t n_left, n_right;   /* expansion key-switching matrices (0 with direct upload)               */
+    uint32_t n_query_cts;       /* 1, or dim0 + nu2 * 2*ell (first-dimension cts + uploaded GSW columns)  */
+    uint32_t trials;            /* out_n^2 */
+    uint64_t qprime;
+} orc_pack_shape;
+int orc_pack_get_shape(const orc_params *p, uint32_t out_n, orc_pack_shape *s);
+
+/* regevToSimpleGsw, src/testing.cpp:108-139: cv = expanded cts (2^g, tree order); inputs at 2*(i*ell+j)+1 */
+void orc_regev_to_simple_gsw(uint64_t *gsw /* [nu2][2][2*ell] NTT */, const uint64_t *cv, const uint64_t *v /* 2 x 2*t_conv */,
+                             uint32_t t_conv, uint32_t ell, uint32_t nu2);
+/* v_folding_neg = gadget + to_ntt(invert(from_ntt(v_folding))), src/testing.cpp:1027-1032 */
+void orc_pack_fold_neg(uint64_t *neg, const uint64_t *gsw, uint32_t ell, uint32_t nu2);
+/* reorientCiphertextsDim1, src/testing.cpp:342-362: cts at index j*idx_factor -> packed (z, j, m=0, r) */
+void orc_reorient_dim1(uint64_t *out, const uint64_t *cts, size_t dim0, size_t idx_factor);
+/* fastMultiplyQueryByDatabaseDim1, src/testing.cpp:364-593 (scalar semantics :527-592):
+ * db word at z*(num_per*dim0) + ii*dim0 + j; out [num_per][2][1] NTT */
+void orc_sweep_dim1(uint64_t *out, const uint64_t *db, const uint64_t *reoriented, size_t dim0, size_t num_per);
+/* foldCiphertextsDim1, src/testing.cpp:596-624: raw cts [num_per][2][N] folded in place, result in cts[0] */
+void orc_fold_dim1(uint64_t *cts, size_t num_per, const uint64_t *folding, const uint64_t *folding_neg, uint32_t ell, uint32_t nu2);
+/* pack, src/testing.cpp:198-241: result (out_n+1) x out_n NTT from out_n^2 raw cts and out_n matrices W */
+void orc_pack(uint64_t *result, uint32_t out_n, uint32_t t_conv, const uint64_t *v_ct, const uint64_t *v_w);
+/* whole server path of testHighRate (src/testing.cpp:1009-1081).  db: trials databases back to back, each
+ * dim0*num_per*N words in convertDb's layout (:316-340).  resp: rescaled (out_n+1) x out_n raw.  final_ntt (may be
+ * NULL): the packed ciphertext before the modulus switch. */
+int orc_pack_answer(const orc_params *p, uint32_t out_n, const uint64_t *query, const uint64_t *w_left, const uint64_t *w_right,
+                    const uint64_t *v, const uint64_t *v_w, const uint64_t *db, uint64_t *resp, uint64_t *final_ntt);
+
+/* seeded database: coefficient z of item i of trial t */
+uint64_t orc_pack_db_coeff(uint64_t seed, uint64_t trial, uint64_t item, uint64_t z, uint64_t total_n, uint64_t p_db);
+void orc_pack_gen_db(const orc_params *p, uint32_t out_n, uint64_t seed, uint64_t *db);
+void orc_pack_db_item(const orc_params *p, uint32_t out_n, uint64_t seed, uint64_t item, uint64_t *pt /* raw [out_n][out_n][N] */);
+
+typedef struct orc_pack_client orc_pack_client;
+orc_pack_client *orc_pack_client_new(const orc_params *p, uint32_t out_n, uint64_t seed, int nonoise);
+void orc_pack_client_free(orc_pack_client *c);
+size_t orc_pack_words_v(const orc_params *p);                       /* 2 x 2*t_conv NTT          */
+size_t orc_pack_words_vw(const orc_params *p, uint32_t out_n);      /* out_n x (out_n+1) x t_conv */
+size_t orc_pack_words_query(const orc_params *p, uint32_t out_n);
+void orc_pack_client_pub_params(orc_pack_client *c, uint64_t *w_left, uint64_t *w_right, uint64_t *v, uint64_t *v_w);
+void orc_pack_client_query(orc_pack_client *c, uint64_t idx_target, uint64_t *query);
+void orc_pack_client_decode(orc_pack_client *c, const uint64_t *resp, uint64_t *pt_out /* raw [out_n][out_n][N] */);
+
+#ifdef __cplusplus
+}
+#endif
 #endif
