@@ -195,6 +195,46 @@ int spiral_gpu_server_time_sweep(spiral_gpu_server *s, int iters, float *avg_ms)
 /* algorithmic bytes of one sweep on this shard: DB + query records + accumulators */
 uint64_t spiral_gpu_server_sweep_bytes(spiral_gpu_server *s);
 
+/* ------------------------------------------------------------------------------------------------
+ * SpiralPack / SpiralStreamPack (`--high-rate`, src/testing.cpp): base_dim x 1 scalar Regev ciphertexts,
+ * 1 x 1 plaintexts, out_n^2 database trials packed into one (out_n+1) x out_n response.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct spiral_gpu_pack_shape {
+    uint32_t dim0, num_per, ell, g, stopround;
+    uint32_t n_left, n_right; /* expansion key-switching matrices n0 x t_exp / n0 x t_exp_right (0 with direct upload) */
+    uint32_t n_query_cts;     /* 1, or dim0 + nu2*2*ell uploaded ciphertexts */
+    uint32_t trials;          /* out_n^2 */
+    uint64_t qprime;
+} spiral_gpu_pack_shape;
+typedef struct spiral_gpu_pack_server spiral_gpu_pack_server;
+int spiral_gpu_pack_get_shape(const spiral_gpu_params *p, uint32_t out_n, spiral_gpu_pack_shape *out);
+
+/* pack, include/testing.h:36-42, src/testing.cpp:198.  v_ct: out_n^2 raw base_dim x 1 ciphertexts; v_W: out_n
+ * matrices (out_n+1) x m_conv NTT; result: (out_n+1) x out_n NTT */
+int spiral_gpu_pack(uint64_t *result, uint32_t out_n, uint32_t m_conv, const uint64_t *v_ct, const uint64_t *v_W);
+/* fastMultiplyQueryByDatabaseDim1, src/testing.cpp:364.  db: convertDb's layout (:316-340); v_firstdim:
+ * reorientCiphertextsDim1's layout (:342-362); out: num_per ciphertexts base_dim x 1 NTT */
+int spiral_gpu_fast_multiply_query_by_database_dim1(uint64_t *out, const uint64_t *db, const uint64_t *v_firstdim,
+                                                    size_t dim0, size_t num_per);
+
+/* resident server for testHighRate's server half (src/testing.cpp:1009-1081) */
+int spiral_gpu_pack_server_create(const spiral_gpu_params *p, uint32_t out_n, int device, spiral_gpu_pack_server **out);
+void spiral_gpu_pack_server_destroy(spiral_gpu_pack_server *s);
+/* the out_n^2 trial databases: seeded explicit data generated on the device (coefficient z of item i of trial t =
+ * splitmix64(seed ^ ((t*n + i)*N + z)) % p_db), one trial from host memory in convertDb's layout, or arbitrary words */
+int spiral_gpu_pack_server_gen_db(spiral_gpu_pack_server *s, uint64_t seed);
+int spiral_gpu_pack_server_load_db(spiral_gpu_pack_server *s, uint32_t trial, const uint64_t *db);
+int spiral_gpu_pack_server_fill_db_random(spiral_gpu_pack_server *s, uint64_t seed);
+/* W_exp_left / W_exp_right (expansion only), V base_dim x base_dim*t_conv (expansion only), v_W out_n x ((out_n+1) x t_conv) */
+int spiral_gpu_pack_server_set_pub_params(spiral_gpu_pack_server *s, const uint64_t *w_left, const uint64_t *w_right,
+                                          const uint64_t *v, const uint64_t *v_w);
+/* response: (out_n+1) x out_n raw, row 0 mod q', rows 1.. mod 4p; packed_ct (may be NULL): the (out_n+1) x out_n NTT
+ * ciphertext before the modulus switch.  stage_us (may be NULL): [0] expansion [1] conversion [2] first dimension
+ * (out_n^2 sweeps + lift) [3] folding [4] packing + modulus switch [5] the sweep kernels alone [6] total. */
+int spiral_gpu_pack_server_answer(spiral_gpu_pack_server *s, const uint64_t *query, uint64_t *response, uint64_t *packed_ct,
+                                  double stage_us[8]);
+uint64_t spiral_gpu_pack_server_sweep_bytes(spiral_gpu_pack_server *s); /* algorithmic bytes of ONE trial's sweep */
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,12 @@ class Shape(C.Structure):
     ]
 
 
+class PackShape(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("dim0", "num_per", "ell", "g", "stopround", "n_left", "n_right", "n_query_cts", "trials")] + [
+        ("qprime", C.c_uint64)
+    ]
+
+
 U64P = C.POINTER(C.c_uint64)
 
 # name -> (restype, argtypes); every symbol include/spiral_gpu.h declares
@@ -100,6 +106,17 @@ PROTOTYPES = {
     "spiral_gpu_server_write_raw": (C.c_int, [C.c_void_p, U64P]),
     "spiral_gpu_server_time_sweep": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "spiral_gpu_server_sweep_bytes": (C.c_uint64, [C.c_void_p]),
+    "spiral_gpu_pack_get_shape": (C.c_int, [C.POINTER(Params), C.c_uint32, C.POINTER(PackShape)]),
+    "spiral_gpu_pack": (C.c_int, [U64P, C.c_uint32, C.c_uint32, U64P, U64P]),
+    "spiral_gpu_fast_multiply_query_by_database_dim1": (C.c_int, [U64P, U64P, U64P, C.c_size_t, C.c_size_t]),
+    "spiral_gpu_pack_server_create": (C.c_int, [C.POINTER(Params), C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]),
+    "spiral_gpu_pack_server_destroy": (None, [C.c_void_p]),
+    "spiral_gpu_pack_server_gen_db": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "spiral_gpu_pack_server_load_db": (C.c_int, [C.c_void_p, C.c_uint32, U64P]),
+    "spiral_gpu_pack_server_fill_db_random": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "spiral_gpu_pack_server_set_pub_params": (C.c_int, [C.c_void_p, U64P, U64P, U64P, U64P]),
+    "spiral_gpu_pack_server_answer": (C.c_int, [C.c_void_p, U64P, U64P, U64P, C.POINTER(C.c_double)]),
+    "spiral_gpu_pack_server_sweep_bytes": (C.c_uint64, [C.c_void_p]),
 }
 
 

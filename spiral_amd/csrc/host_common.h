@@ -1,0 +1,199 @@
+// Host-side helpers shared by server.cpp and pack_server.cpp (error reporting, device buffers, the
+// coefficient-expansion driver).  Internal to libspiral_gpu.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/spiral_gpu.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace spiral {
+namespace host {
+
+extern thread_local std::string g_err;
+
+inline int fail(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return -1;
+}
+
+#define HIP_OK(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+constexpr size_t kPolyBytes = (size_t)kN * sizeof(uint64_t);  // PK or RAW polynomial
+constexpr size_t kRefNtt = 2 * (size_t)kN;                     // words of a reference NTT-form polynomial
+constexpr uint64_t kQprimeMods[37] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 12289, 12289, 61441, 65537, 65537, 520193, 786433, 786433,
+                                      3604481, 7340033, 16515073, 33292289, 67043329, 132120577, 268369921, 469762049, 1073479681,
+                                      2013265921, 4293918721ull, 8588886017ull, 17175674881ull, 34359214081ull, 68718428161ull};  // values.h:74-76
+
+inline uint32_t ceil_log2(uint64_t x) {
+    uint32_t r = 0;
+    while ((1ull << r) < x) r++;
+    return r;
+}
+
+inline int shape_of(const spiral_gpu_params* p, spiral_gpu_shape* s) {
+    if (!p || !s) return fail("null argument");
+    if (p->nu1 > 16 || p->nu2 > 16) return fail("nu1/nu2 out of range");
+    if (p->t_gsw < 2 || p->t_gsw > 28 || p->t_conv < 1 || p->t_conv > 56 || p->t_exp < 1 || p->t_exp > 56 || p->t_exp_right < 1 ||
+        p->t_exp_right > 56)
+        return fail("gadget dimension out of range");
+    if (p->qprime_bits >= 37 || kQprimeMods[p->qprime_bits] == 0) return fail("unsupported q' bit width %u", p->qprime_bits);
+    if (p->p_db < 2 || p->p_db > (1ull << 40)) return fail("unsupported plaintext modulus");
+    s->dim0 = 1u << p->nu1;
+    s->num_per = 1u << p->nu2;
+    s->ell = p->t_gsw;
+    s->m2 = 3 * p->t_gsw;
+    s->n_bits = s->dim0 + s->ell * p->nu2;
+    s->qprime = kQprimeMods[p->qprime_bits];
+    if (p->direct_upload) {
+        s->g = s->stopround = s->n_left = s->n_right = 0;
+        s->n_query_cts = s->n_bits;
+    } else {
+        s->g = ceil_log2(s->n_bits);
+        s->stopround = p->nu2 ? ceil_log2((uint64_t)s->ell * p->nu2) : 0;
+        if (s->ell * p->nu2 > s->dim0) s->stopround = 0;  // src/spiral.cpp:2083
+        s->n_left = s->g;
+        s->n_right = s->stopround ? s->stopround + 1 : s->g;
+        s->n_query_cts = 1;
+        if (s->g > kLogN) return fail("query does not fit one polynomial (g = %u)", s->g);
+    }
+    return 0;
+}
+
+inline uint32_t inv_mod_2n(uint32_t t) {  // t odd, inverse modulo 2N = 4096
+    uint32_t x = 1;
+    for (int i = 0; i < 12; i++) x = x * (2 - t * x);  // Newton, doubles the valid bits
+    return x & (2 * kN - 1);
+}
+
+struct DevBuf {
+    uint64_t* p = nullptr;
+    size_t words = 0;
+    int alloc(size_t w) {
+        words = w ? w : 1;
+        HIP_OK(hipMalloc(&p, words * sizeof(uint64_t)));
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
+};
+
+// scoped device scratch for the host-buffer seams
+struct Scratch {
+    std::vector<void*> ptrs;
+    ~Scratch() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+    uint64_t* get(size_t words) {
+        void* p = nullptr;
+        if (hipMalloc(&p, (words ? words : 1) * sizeof(uint64_t)) != hipSuccess) return nullptr;
+        ptrs.push_back(p);
+        return (uint64_t*)p;
+    }
+    uint64_t* upload(const uint64_t* host, size_t words) {
+        uint64_t* d = get(words);
+        if (d && hipMemcpy(d, host, words * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        return d;
+    }
+};
+
+inline int current_tables(DeviceTables* t) {
+    int dev = 0;
+    HIP_OK(hipGetDevice(&dev));
+    if (tables_get(dev, t) != 0) return fail("twiddle table setup failed on device %d", dev);
+    return 0;
+}
+
+// ---- expansion on PK buffers, shared by the seam and the resident server ---------------------------------
+struct ExpandWork {
+    uint64_t* raw;  // [2^g][2] RAW
+    uint64_t* g;    // per active ct: t digits + NTT(c'_1), PK
+};
+inline size_t expand_g_polys(uint32_t g, uint32_t t_exp, uint32_t t_exp_right) {
+    size_t half = (size_t)1 << (g ? g - 1 : 0);  // at most 2^(g-1) active cts per parity
+    return half * ((size_t)t_exp + 1 + t_exp_right + 1);
+}
+
+// src/spiral.cpp:1664-1743.  cv: 2^g cts (2 PK polys each).
+inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_t t_exp, const uint64_t* w_left, uint32_t t_exp_right,
+                const uint64_t* w_right, uint32_t max_bits_right, uint32_t stopround, const ExpandWork& wk, hipStream_t st) {
+    for (uint32_t r = 0; r < g; r++) {
+        const uint32_t num_in = 1u << r;
+        const uint32_t t = (kN >> r) + 1, tinv = inv_mod_2n(t);
+        // active ciphertexts of this round, by parity (:1701-1702)
+        uint32_t cnt_even = num_in, cnt_odd = num_in;
+        if (stopround > 0 && r > stopround) cnt_odd = 0;
+        if (stopround > 0 && r == stopround) cnt_odd = std::min(num_in, max_bits_right + 1);
+        // 1) INTT + CRT of every active ct (both parities); cts with i >= num_in are first created as
+        //    neg1 * cv[i - num_in] (:1709) inside the same kernel
+        const uint32_t cnt = cnt_even + cnt_odd;
+        InvParams ip{};
+        ip.dst = wk.raw;
+        ip.src_map = ip.dst_map = identity_map();
+        ip.cv = cv;
+        ip.neg1 = tb.neg1 + (size_t)r * kN;
+        ip.num_in = num_in;
+        ip.cnt_e = cnt_even;
+        launch_ntt_inverse_expand(tb, ip, 2 * cnt, st);
+        // 2) G^-1(automorph(c)[0]) digits (t_exp / t_exp_right per ct) and NTT(automorph(c)[1]), one launch
+        FwdParams fp{};
+        fp.src = wk.raw;
+        fp.dst = wk.g;
+        fp.src_map = fp.dst_map = identity_map();
+        fp.n_digits = 1;
+        fp.tinv = tinv;
+        fp.cnt_e = cnt_even;
+        fp.t_e = t_exp;
+        fp.t_o = t_exp_right;
+        launch_ntt_forward(tb, fp, LD_EXPAND, ST_PK, cnt_even * (t_exp + 1) + cnt_odd * (t_exp_right + 1), st);
+        // 3) cv[i] += W * digits + (0, NTT(c'_1))
+        ExpandMacParams mp{};
+        mp.cv = cv;
+        mp.w_e = w_left + (size_t)r * 2 * t_exp * kN;
+        mp.w_o = w_right + (size_t)r * 2 * t_exp_right * kN;  // never dereferenced when cnt_odd == 0
+        mp.g = wk.g;
+        mp.cnt_e = cnt_even;
+        mp.cnt_o = cnt_odd;
+        mp.t_e = t_exp;
+        mp.t_o = t_exp_right;
+        launch_expand_mac_round(mp, st);
+    }
+}
+
+
+// upload reference NTT-form polynomials and convert to PK / the converse
+inline uint64_t* upload_pk(Scratch& sc, const uint64_t* host_ref, size_t npolys) {
+    uint64_t* d_ref = sc.upload(host_ref, npolys * kRefNtt);
+    uint64_t* d_pk = sc.get(npolys * kN);
+    if (!d_ref || !d_pk) return nullptr;
+    launch_ref_to_pk(d_ref, d_pk, (uint32_t)npolys, identity_map(), 0);
+    return d_pk;
+}
+inline int download_pk(Scratch& sc, const uint64_t* d_pk, IndexMap map, uint64_t* host_ref, size_t npolys) {
+    uint64_t* d_ref = sc.get(npolys * kRefNtt);
+    if (!d_ref) return fail("device allocation failed");
+    launch_pk_to_ref(d_pk, d_ref, (uint32_t)npolys, map, 0);
+    HIP_OK(hipMemcpy(host_ref, d_ref, npolys * kRefNtt * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // namespace host
+}  // namespace spiral

@@ -29,6 +29,9 @@ enum FwdLoad : uint32_t {
     LD_SDIGIT = 2,  // balanced digit with the fold's carry rules        (split_and_crt, src/spiral.cpp:270)
     LD_LIMBS = 3,   // reference NTT layout [2][N] u64 taken as per-limb coefficient arrays (ntt_forward)
     LD_DBGEN = 4,   // seeded plaintext coefficient, centred lift        (load_db, src/spiral.cpp:1116-1127)
+    LD_PDIGIT = 6,  // SpiralPack: unsigned reduced digit k (gadget_invert + to_ntt, src/testing.cpp:130-131, 226-227, 612-617)
+                    // with the source / destination maps of FwdParams::pmode
+    LD_DBGEN1 = 7,  // SpiralPack database: 1 x 1 plaintext of (trial, item), centred lift (src/testing.cpp:845-869)
     LD_EXPAND = 5,  // one expansion round: digits of automorph(c)[0] and the reduced automorph(c)[1] of every
                     // active ciphertext, both parities, in one launch      (src/spiral.cpp:1711-1720)
 };
@@ -36,6 +39,12 @@ enum FwdStore : uint32_t {
     ST_PK = 0,      // packed slot words
     ST_REF = 1,     // reference layout [2][N] u64
     ST_DB = 2,      // scatter into the device DB layout (see sweep)
+    ST_DB1 = 3,     // scatter into the SpiralPack device DB layout (pack.hip)
+};
+enum PackMap : uint32_t {
+    PM_GSW = 0,   // s = (input ct, row); dst = chat[ct][row + 2k]                     (regevToSimpleGsw)
+    PM_FOLD = 1,  // s = (trial, ct i' < 2np', row); dst = D[trial][i' % np'][(i' / np') * 2ell + row + 2k]
+    PM_PACK = 2,  // s = trial; source = row 0 of the trial's folded ct; dst = ginv[trial][k]   (pack)
 };
 struct FwdParams {
     const uint64_t* src;
@@ -47,6 +56,11 @@ struct FwdParams {
     uint32_t ell;       // LD_SDIGIT: digits per value (t_GSW)
     uint32_t tinv;      // automorphism gather x -> x^t folded into the load: t^-1 mod 2N, 0 = none
     uint32_t fold_np;   // LD_SDIGIT: num_per' (destination is the fold operand layout)
+    // LD_PDIGIT: map selector; fold_np = np' and num_per (ct stride of a trial in the raw buffer) for PM_FOLD / PM_PACK
+    uint32_t pmode, pk_num_per;
+    // LD_DBGEN1: trial and total item count
+    uint32_t trial;
+    uint64_t total_n;
     // LD_EXPAND: active ct a < cnt_e is even (t_e digits), the rest odd (t_o digits); jobs per ct = t + 1
     uint32_t cnt_e, t_e, t_o;
     // LD_DBGEN / ST_DB
@@ -159,5 +173,26 @@ void launch_db_relayout(const uint64_t* db_ref, uint64_t* db_dev, uint32_t num_p
 // reference reorientCiphertexts layout (z, j, m, r_pad4) u64 -> sweep query records
 void launch_qs_from_reoriented(const uint64_t* reoriented, uint32_t* qs, uint32_t jm_total, hipStream_t s);
 void launch_fill_db_random(uint64_t* db_dev, uint64_t nwords, uint64_t seed, hipStream_t s);
+
+// ---- SpiralPack (pack.hip; reference src/testing.cpp) -----------------------------------------------------------
+// device DB layout, 1 x 1 plaintexts: word(z, j, ii) at (((z*nblk + ii/W)*(dim0/2) + j/2)*W + ii%W)*2 + (j&1), W = min(64, num_per)
+__host__ __device__ inline size_t db1_word_index(uint32_t z, uint32_t j, uint32_t ii, uint32_t num_per, uint32_t dim0) {
+    const uint32_t w = num_per < 64u ? num_per : 64u, nblk = num_per / w;
+    return ((((size_t)z * nblk + ii / w) * (dim0 / 2) + (j >> 1)) * w + ii % w) * 2u + (j & 1u);
+}
+// fastMultiplyQueryByDatabaseDim1 (src/testing.cpp:364): acc[ii][r][z] PK; qs1 records [z][j] = {p r0, p r1, b r0, b r1}
+void launch_sweep1(const uint64_t* db, const uint32_t* qs1, uint64_t* acc, uint32_t num_per, uint32_t dim0, hipStream_t s);
+// query records from the expanded cts: first-dimension ct j is cv[j * idx_factor] (reorientCiphertextsDim1, :342)
+void launch_qs1_from_cv(const uint64_t* cv, uint32_t* qs1, uint32_t dim0, uint32_t idx_factor, hipStream_t s);
+void launch_qs1_from_reoriented(const uint64_t* re, uint32_t* qs1, uint32_t dim0, hipStream_t s);
+// convertDb layout (:316-340) z*(num_per*dim0) + ii*dim0 + j -> device layout
+void launch_db1_relayout(const uint64_t* ref, uint64_t* dev, uint32_t num_per, uint32_t dim0, hipStream_t s);
+// gsw[i][r][2j] = tmp[i*ell+j][r], gsw[i][r][2j+1] = cv[2*(i*ell+j)+1][r]   (regevToSimpleGsw, :108-139)
+void launch_pack_gsw_assemble(const uint64_t* tmp, const uint64_t* cv, uint64_t* gsw, uint32_t ell, uint32_t nu2, hipStream_t s);
+void launch_pack_gsw_from_upload(const uint64_t* query, uint64_t* gsw, uint32_t dim0, uint32_t ell, uint32_t nu2, hipStream_t s);
+// key[cur][r][0..2ell) = gadget - F, [2ell..4ell) = F with F = gsw[nu2-1-cur]   (:1027-1032, 611-618)
+void launch_pack_fold_key(const uint64_t* gsw, uint64_t* key, uint32_t ell, uint32_t nu2, hipStream_t s);
+// pack (:198-241): result[row][c] = sum_r sum_k W_r[row][k] * ginv[r*out_n+c][k] + (row >= 1 ? ct2[(row-1)*out_n+c] : 0)
+void launch_pack_mac(const uint64_t* v_w, const uint64_t* ginv, const uint64_t* ct2, uint64_t* result, uint32_t out_n, uint32_t t_conv, hipStream_t s);
 
 }  // namespace spiral

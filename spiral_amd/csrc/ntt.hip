@@ -79,6 +79,40 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
                 hi[r] = mod_b(v);
             }
         }
+    } else if constexpr (LOAD == LD_DBGEN1) {
+        const uint64_t item = p.item_base + b;
+        const uint64_t half_p = p.p_db >> 1;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            uint32_t idx = ix_a(tid, r);
+            uint64_t v = splitmix64(p.seed ^ (((uint64_t)p.trial * p.total_n + item) * kN + idx)) % p.p_db;
+            if (v >= half_p) {
+                uint64_t d = p.p_db - v;
+                lo[r] = kP - mod_p(d);
+                hi[r] = kB - mod_b(d);
+            } else {
+                lo[r] = mod_p(v);
+                hi[r] = mod_b(v);
+            }
+        }
+    } else if constexpr (LOAD == LD_PDIGIT) {
+        uint32_t sp;  // source polynomial
+        if (p.pmode == PM_GSW) {
+            sp = s;
+        } else if (p.pmode == PM_FOLD) {
+            const uint32_t per_t = 4u * p.fold_np, t = s / per_t, rem = s - t * per_t;
+            sp = (t * p.pk_num_per + (rem >> 1)) * 2u + (rem & 1u);
+        } else {
+            sp = s * p.pk_num_per * 2u;
+        }
+        const uint64_t* src = p.src + (size_t)sp * kN;
+        const uint64_t mask = (1ull << p.bits) - 1;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            uint32_t d = (uint32_t)digit_of(src[ix_a(tid, r)], k, p.bits, mask);
+            lo[r] = digit_residue(d, kP);
+            hi[r] = digit_residue(d, kB);
+        }
     } else if constexpr (LOAD == LD_EXPAND) {
         // job b -> (active ct a, k); k < tdim: digit k of automorph(c)[0]; k == tdim: automorph(c)[1] reduced
         const uint32_t je = p.cnt_e * (p.t_e + 1u);
@@ -144,7 +178,18 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
 
     if constexpr (STORE == ST_PK) {
         uint32_t di;
-        if constexpr (LOAD == LD_SDIGIT) {
+        if constexpr (LOAD == LD_PDIGIT) {
+            const uint32_t nd = p.n_digits;
+            if (p.pmode == PM_GSW) {
+                di = (s >> 1) * (2u * nd) + 2u * k + (s & 1u);
+            } else if (p.pmode == PM_FOLD) {
+                const uint32_t per_t = 4u * p.fold_np, t = s / per_t, rem = s - t * per_t, ip = rem >> 1, row = rem & 1u;
+                const uint32_t hh = ip / p.fold_np, i = ip - hh * p.fold_np;
+                di = ((t * p.fold_np + i) * 2u + hh) * (2u * nd) + 2u * k + row;
+            } else {
+                di = s * nd + k;
+            }
+        } else if constexpr (LOAD == LD_SDIGIT) {
             // source s = (ct i', r, c) over [2*np][3][2]; operand layout D[i' % np][(i' / np)*m2 + r + 3k][c]
             const uint32_t ct = s / 6u, rc = s - ct * 6u, r = rc >> 1, c = rc & 1u;
             const uint32_t m2 = 3u * p.ell, hi_half = ct / p.fold_np, i = ct - hi_half * p.fold_np;
@@ -165,6 +210,13 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
             dst[r] = lo[r];
             dst[kN + r] = hi[r];
         }
+    } else if constexpr (STORE == ST_DB1) {
+        const uint64_t item = p.item_base + b;
+        const uint32_t ii = (uint32_t)(item % p.num_per), j = (uint32_t)(item / p.num_per);
+        const size_t zstride = (size_t)p.dim0_shard * p.num_per;  // words per z slab
+        uint64_t* dst = p.dst + db1_word_index(0, j, ii, p.num_per, p.dim0_shard);
+#pragma unroll
+        for (int r = 0; r < 8; r++) dst[(size_t)(8u * tid + r) * zstride] = pack(lo[r], hi[r]);
     } else {  // ST_DB: scatter into the sweep layout
         const uint64_t item = p.item_base + (b >> 2);
         const uint32_t mc = b & 3u, m = mc >> 1, c = mc & 1u;
@@ -281,6 +333,8 @@ void launch_ntt_forward(const DeviceTables& t, const FwdParams& p, uint32_t load
     FWD_CASE(LD_LIMBS, ST_PK)
     FWD_CASE(LD_DBGEN, ST_DB)
     FWD_CASE(LD_EXPAND, ST_PK)
+    FWD_CASE(LD_PDIGIT, ST_PK)
+    FWD_CASE(LD_DBGEN1, ST_DB1)
     abort();
 }
 

@@ -1,0 +1,83 @@
+"""SpiralPack / SpiralStreamPack (`--high-rate`, reference src/testing.cpp): host mirror of the function seams and
+the resident server handle, each a direct call through the C ABI."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import U64P, PackShape, Params, check, lib
+
+N = 2048
+PACK_STAGE_NAMES = ["expansion_us", "conversion_us", "first_dim_us", "folding_us", "packing_us", "sweep_kernels_us", "total_us", "reserved"]
+
+
+def _p(a: np.ndarray):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(U64P)
+
+
+def _c(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def get_pack_shape(p: Params, out_n: int) -> PackShape:
+    s = PackShape()
+    check(lib().spiral_gpu_pack_get_shape(C.byref(p), out_n, C.byref(s)))
+    return s
+
+
+def pack(out_n, m_conv, v_ct, v_W) -> np.ndarray:
+    """pack (include/testing.h:36): out_n^2 raw 2x1 cts + out_n key matrices -> (out_n+1) x out_n NTT ciphertext"""
+    out = np.zeros((out_n + 1, out_n, 2, N), dtype=np.uint64)
+    check(lib().spiral_gpu_pack(_p(out), out_n, m_conv, _p(_c(v_ct)), _p(_c(v_W))))
+    return out
+
+
+def fastMultiplyQueryByDatabaseDim1(db, v_firstdim, dim0, num_per) -> np.ndarray:
+    out = np.zeros((num_per, 2, 2, N), dtype=np.uint64)
+    check(lib().spiral_gpu_fast_multiply_query_by_database_dim1(_p(out), _p(_c(db)), _p(_c(v_firstdim)), dim0, num_per))
+    return out
+
+
+class PackServer:
+    def __init__(self, params: Params, out_n: int, device: int = 0):
+        self.params, self.out_n = params, out_n
+        self.shape = get_pack_shape(params, out_n)
+        h = C.c_void_p()
+        check(lib().spiral_gpu_pack_server_create(C.byref(params), out_n, device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().spiral_gpu_pack_server_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def gen_db(self, seed: int):
+        check(lib().spiral_gpu_pack_server_gen_db(self.h, seed))
+
+    def load_db(self, trial: int, db):
+        check(lib().spiral_gpu_pack_server_load_db(self.h, trial, _p(_c(db))))
+
+    def fill_db_random(self, seed: int):
+        check(lib().spiral_gpu_pack_server_fill_db_random(self.h, seed))
+
+    def set_pub_params(self, w_left, w_right, v, v_w):
+        check(lib().spiral_gpu_pack_server_set_pub_params(self.h, _p(w_left), _p(w_right), _p(v), _p(v_w)))
+
+    def answer(self, query, want_packed: bool = True):
+        n = self.out_n
+        resp = np.zeros((n + 1, n, N), dtype=np.uint64)
+        packed = np.zeros((n + 1, n, 2, N), dtype=np.uint64) if want_packed else None
+        us = (C.c_double * 8)()
+        check(lib().spiral_gpu_pack_server_answer(self.h, _p(_c(query)), _p(resp), _p(packed) if want_packed else None, us))
+        return resp, packed, dict(zip(PACK_STAGE_NAMES, list(us)))
+
+    def sweep_bytes(self) -> int:
+        return int(lib().spiral_gpu_pack_server_sweep_bytes(self.h))

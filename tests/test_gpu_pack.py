@@ -1,0 +1,109 @@
+"""GPU parity of the SpiralPack / SpiralStreamPack path (reference src/testing.cpp) against the oracle, through the
+C ABI: the two function seams, the resident server (packed ciphertext and response bit-exact, response decodes to
+the out_n x out_n items), and BASELINE.json config 5 at full size as a decode property."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+N = 2048
+
+
+@pytest.fixture(scope="module")
+def sa():
+    import spiral_amd
+
+    assert spiral_amd.lib().spiral_gpu_device_count() > 0
+    return spiral_amd
+
+
+def rand_ntt(rng, O, shape):
+    return np.stack([rng.integers(0, m, size=shape + (N,), dtype=np.uint64) for m in (O.P, O.B)], axis=-2)
+
+
+def assert_eq(got, exp, what):
+    if not (got.shape == exp.shape and (got == exp).all()):
+        bad = np.argwhere(got != exp)
+        raise AssertionError(f"{what}: {len(bad)} of {got.size} words differ, first at {bad[:5].tolist()}")
+
+
+@pytest.mark.parametrize("dim0,num_per", [(4, 2), (8, 32), (64, 64), (2, 128)])
+def test_sweep_dim1(sa, oracle, dim0, num_per):
+    O = oracle
+    rng = np.random.default_rng(dim0 * 1000 + num_per)
+    cts = rand_ntt(rng, O, (dim0, 2))
+    re = O.reorient_dim1(cts, dim0, 1)
+    db = O.fill_db_random(dim0 + num_per, dim0 * num_per * N)
+    assert_eq(sa.fastMultiplyQueryByDatabaseDim1(db, re, dim0, num_per), O.sweep_dim1(db, re, dim0, num_per), "fastMultiplyQueryByDatabaseDim1")
+
+
+@pytest.mark.parametrize("out_n,t_conv", [(2, 4), (3, 4), (4, 8), (2, 56)])
+def test_pack_seam(sa, oracle, out_n, t_conv):
+    O = oracle
+    rng = np.random.default_rng(out_n * 100 + t_conv)
+    v_ct = rng.integers(0, O.Q, size=(out_n * out_n, 2, N), dtype=np.uint64)
+    v_ct[0, 0, :3] = [0, O.Q - 1, 1]
+    v_w = rand_ntt(rng, O, (out_n, out_n + 1, t_conv))
+    assert_eq(sa.pack(out_n, t_conv, v_ct, v_w), O.pack(v_ct, v_w, out_n, t_conv), "pack")
+
+
+@pytest.mark.parametrize(
+    "nu1,nu2,out_n,kw",
+    [
+        (6, 2, 2, {}),
+        (5, 2, 3, dict(t_gsw=4)),
+        (4, 6, 2, dict(t_gsw=4)),  # num_per = 64: the fast sweep path
+        (3, 2, 2, dict(t_gsw=5, t_exp=2, qprime_bits=19, direct_upload=1)),
+    ],
+)
+def test_pack_server_matches_oracle(sa, oracle, nu1, nu2, out_n, kw):
+    O = oracle
+    po, pg = O.make_params(nu1, nu2, **kw), sa.make_params(nu1, nu2, **kw)
+    s = O.pack_shape_of(po, out_n)
+    g = sa.get_pack_shape(pg, out_n)
+    for f, _ in g._fields_:
+        assert getattr(g, f) == getattr(s, f), f
+    db = O.pack_gen_db(po, out_n, 31)
+    cl = O.PackClient(po, out_n, seed=8)
+    wl, wr, v, vw = cl.pub_params()
+    total = s.dim0 * s.num_per
+    srv = sa.PackServer(pg, out_n)
+    srv.gen_db(31)  # on-device generation must equal the oracle's database
+    srv.set_pub_params(wl, wr, v, vw)
+    for idx in (77 % total, total - 1):
+        q = cl.query(idx)
+        resp, packed, us = srv.answer(q)
+        exp_resp, exp_packed = O.pack_answer(po, out_n, q, wl, wr, v, vw, db)
+        assert_eq(packed, exp_packed, "packed ciphertext")
+        assert_eq(resp, exp_resp, "response")
+        assert_eq(cl.decode(resp), O.pack_db_item(po, out_n, 31, idx), "decoded items")
+    # the same database uploaded in the reference's convertDb layout
+    srv2 = sa.PackServer(pg, out_n)
+    for t in range(s.trials):
+        srv2.load_db(t, db[t])
+    srv2.set_pub_params(wl, wr, v, vw)
+    q = cl.query(3 % total)
+    assert_eq(srv2.answer(q)[0], O.pack_answer(po, out_n, q, wl, wr, v, vw, db)[0], "response with uploaded database")
+    srv.close()
+    srv2.close()
+
+
+@pytest.mark.slow
+def test_full_size_config5_pack(sa, oracle):
+    """BASELINE.json config 5: SpiralPack 2^18 x 30KB (all_parameter_choices.txt:610-624: nu1=10, nu2=8, n=4, p=256, q'=2^20,
+    t_GSW=8, t_conv=4, t_exp=16): 16 trial databases of 4 GiB each, generated on the device.  Property: decodes to the items."""
+    O = oracle
+    kw = dict(t_gsw=8, t_conv=4, t_exp=16, t_exp_right=56, qprime_bits=20, p_db=256)
+    po, pg = O.make_params(10, 8, **kw), sa.make_params(10, 8, **kw)
+    out_n = 4
+    cl = O.PackClient(po, out_n, seed=12)
+    wl, wr, v, vw = cl.pub_params()
+    srv = sa.PackServer(pg, out_n)
+    srv.gen_db(2024)
+    srv.set_pub_params(wl, wr, v, vw)
+    idx = 123456 % (1 << 18)
+    resp, _, us = srv.answer(cl.query(idx), want_packed=False)
+    resp, _, us = srv.answer(cl.query(idx), want_packed=False)
+    assert_eq(cl.decode(resp), O.pack_db_item(po, out_n, 2024, idx), "decoded items (config 5)")
+    gbps = 16 * srv.sweep_bytes() / us["sweep_kernels_us"] / 1e3
+    print("config 5 stage us:", {k: round(x) for k, x in us.items()}, "sweep GB/s:", round(gbps))
+    srv.close()
