@@ -160,6 +160,15 @@ int spiral_gpu_server_run_post(spiral_gpu_server *s, int reduce_first);
  * field < 2^28).  Summing the shards' buffers as uint64 (one RCCL reduce) and calling lift with
  * reduce_first = 1 gives the unsharded result.  Returns a device pointer. */
 void *spiral_gpu_server_acc(spiral_gpu_server *s, size_t *bytes);
+/* Distributed folding over G = 2^k ranks (reduce-scatter variant).  set_fold_ranks(G) makes the
+ * sweep group its accumulators by ii mod G, so that ONE reduce-scatter of the acc buffers hands rank g the summed
+ * chunk of the num_per/G ciphertexts ii = g + G*k.  fold_local lifts that chunk (device pointer, packed words) and
+ * runs the first nu2-k folding rounds, leaving one raw n1 x n2 ciphertext in out_ct (device pointer, 6*2048 words);
+ * after an all-gather of those G ciphertexts in rank order, fold_root runs the last k rounds and the response
+ * switch on the root.  Bit-identical to lift + fold on one device. */
+int spiral_gpu_server_set_fold_ranks(spiral_gpu_server *s, uint32_t n_ranks);
+int spiral_gpu_server_fold_local(spiral_gpu_server *s, const void *acc_chunk, void *out_ct);
+int spiral_gpu_server_fold_root(spiral_gpu_server *s, const void *gathered_cts);
 /* make the sweep write into caller-owned device memory (e.g. a torch tensor) */
 int spiral_gpu_server_set_acc(spiral_gpu_server *s, void *device_ptr);
 

@@ -165,7 +165,8 @@ void launch_fold_key_from_reoriented(const uint64_t* q_re, const uint64_t* qneg_
 // ---- first-dimension sweep (sweep.hip) -----------------------------------------------------------------
 // device DB layout: common.h db_word_index(z, j - j0, ic, m), ic = ii*2 + c, nic = 2*num_per.
 // acc[ii][r][c][z] PK (fields < m).
-void launch_sweep(const uint64_t* db, const uint32_t* qs, uint64_t* acc, uint32_t num_per, uint32_t jm_total, hipStream_t s);
+// g_log: log2 of the number of ranks of a distributed fold (accumulators grouped by ii mod 2^g_log), 0 = natural order
+void launch_sweep(const uint64_t* db, const uint32_t* qs, uint64_t* acc, uint32_t num_per, uint32_t jm_total, uint32_t g_log, hipStream_t s);
 // reference DB layout (src/spiral.cpp:1139-1153) -> device layout, for the j-range [j0, j0 + dim0_shard) and
 // nz consecutive z slabs starting at the given pointers
 void launch_db_relayout(const uint64_t* db_ref, uint64_t* db_dev, uint32_t num_per, uint32_t dim0, uint32_t j0, uint32_t dim0_shard, uint32_t nz,

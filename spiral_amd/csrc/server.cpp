@@ -32,6 +32,7 @@ struct spiral_gpu_server {
     // reduce_first; instantiated lazily, invalidated when a captured pointer or flag changes
     bool use_graphs = false;
     hipGraphExec_t graph[3] = {nullptr, nullptr, nullptr};
+    uint32_t fold_g_log = 0;  // distributed fold over 2^fold_g_log ranks: the sweep groups its output by ii mod G
 };
 
 namespace {
@@ -309,7 +310,7 @@ int spiral_gpu_multiply_query_by_database(uint64_t* output, const uint64_t* reor
     if (!d_ref || !d_db || !d_re || !d_qs || !d_acc) return fail("device allocation/upload failed");
     launch_db_relayout(d_ref, d_db, (uint32_t)num_per, (uint32_t)dim0, 0, (uint32_t)dim0, kN, 0);
     launch_qs_from_reoriented(d_re, (uint32_t*)d_qs, (uint32_t)(2 * dim0), 0);
-    launch_sweep(d_db, (const uint32_t*)d_qs, d_acc, (uint32_t)num_per, (uint32_t)(2 * dim0), 0);
+    launch_sweep(d_db, (const uint32_t*)d_qs, d_acc, (uint32_t)num_per, (uint32_t)(2 * dim0), 0, 0);
     return download_pk(sc, d_acc, identity_map(), output, num_per * 6);
 }
 
@@ -691,7 +692,7 @@ int spiral_gpu_server_convert(spiral_gpu_server* S) {
 int spiral_gpu_server_first_dim(spiral_gpu_server* S) {
     if (!S) return fail("null server");
     if (!S->have_db) return fail("no database loaded");
-    launch_sweep(S->db.p, (const uint32_t*)S->qs.p, S->acc, S->s.num_per, 2 * S->dim0_shard, S->stream);
+    launch_sweep(S->db.p, (const uint32_t*)S->qs.p, S->acc, S->s.num_per, 2 * S->dim0_shard, S->fold_g_log, S->stream);
     return 0;
 }
 
@@ -706,11 +707,14 @@ int spiral_gpu_server_lift(spiral_gpu_server* S, int reduce_first) {
     return 0;
 }
 
-int spiral_gpu_server_fold(spiral_gpu_server* S) {
-    if (!S) return fail("null server");
+}  // extern "C"
+
+namespace {
+// foldOneFurtherDimension rounds [d0, d0 + rounds) on the np0 ciphertexts at the head of S->raw (src/spiral.cpp:1349-1410)
+void run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t rounds) {
     const spiral_gpu_shape& s = S->s;
-    uint32_t np = s.num_per, d = 0;
-    while (np >= 2) {  // src/spiral.cpp:1622-1626
+    uint32_t np = np0;
+    for (uint32_t d = d0; d < d0 + rounds; d++) {
         np /= 2;
         FwdParams fp{};
         fp.src = S->raw.p;
@@ -727,9 +731,48 @@ int spiral_gpu_server_fold(spiral_gpu_server* S) {
         ip.dst = S->raw.p;
         ip.src_map = ip.dst_map = identity_map();
         launch_ntt_inverse(S->tb, ip, IST_CRT, np * 6, S->stream);
-        d++;
     }
+}
+}  // namespace
+
+extern "C" {
+
+int spiral_gpu_server_finish(spiral_gpu_server* S);
+
+int spiral_gpu_server_fold(spiral_gpu_server* S) {
+    if (!S) return fail("null server");
+    run_fold_rounds(S, S->s.num_per, 0, S->p.nu2);  // src/spiral.cpp:1622-1626
     return 0;
+}
+
+int spiral_gpu_server_set_fold_ranks(spiral_gpu_server* S, uint32_t n_ranks) {
+    if (!S) return fail("null server");
+    if (n_ranks == 0 || (n_ranks & (n_ranks - 1)) || n_ranks > S->s.num_per) return fail("fold ranks must be a power of two <= num_per");
+    S->fold_g_log = ceil_log2(n_ranks);
+    srv_drop_graphs(S);
+    return 0;
+}
+
+int spiral_gpu_server_fold_local(spiral_gpu_server* S, const void* acc_chunk, void* out_ct) {
+    if (!S || !acc_chunk || !out_ct) return fail("null argument");
+    const uint32_t L = S->s.num_per >> S->fold_g_log;
+    InvParams ip{};
+    ip.src = (const uint64_t*)acc_chunk;
+    ip.dst = S->raw.p;
+    ip.src_map = ip.dst_map = identity_map();
+    ip.pre_reduce = 1;
+    launch_ntt_inverse(S->tb, ip, IST_CRT, L * 6, S->stream);
+    run_fold_rounds(S, L, 0, S->p.nu2 - S->fold_g_log);
+    HIP_OK(hipMemcpyAsync(out_ct, S->raw.p, 6 * kPolyBytes, hipMemcpyDeviceToDevice, S->stream));
+    return 0;
+}
+
+int spiral_gpu_server_fold_root(spiral_gpu_server* S, const void* gathered_cts) {
+    if (!S || !gathered_cts) return fail("null argument");
+    const uint32_t G = 1u << S->fold_g_log;
+    HIP_OK(hipMemcpyAsync(S->raw.p, gathered_cts, (size_t)G * 6 * kPolyBytes, hipMemcpyDeviceToDevice, S->stream));
+    run_fold_rounds(S, G, S->p.nu2 - S->fold_g_log, S->fold_g_log);
+    return spiral_gpu_server_finish(S);
 }
 
 int spiral_gpu_server_finish(spiral_gpu_server* S) {
@@ -932,7 +975,7 @@ int spiral_gpu_server_time_sweep(spiral_gpu_server* S, int iters, float* avg_ms)
     if (!S->have_db) return fail("no database loaded");
     HIP_OK(hipSetDevice(S->device));
     HIP_OK(hipEventRecord(S->ev[0], S->stream));
-    for (int i = 0; i < iters; i++) launch_sweep(S->db.p, (const uint32_t*)S->qs.p, S->acc, S->s.num_per, 2 * S->dim0_shard, S->stream);
+    for (int i = 0; i < iters; i++) launch_sweep(S->db.p, (const uint32_t*)S->qs.p, S->acc, S->s.num_per, 2 * S->dim0_shard, S->fold_g_log, S->stream);
     HIP_OK(hipEventRecord(S->ev[1], S->stream));
     HIP_OK(hipStreamSynchronize(S->stream));
     float ms = 0;

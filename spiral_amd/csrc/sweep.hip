@@ -44,9 +44,12 @@ __device__ __forceinline__ void reduce6(uint64_t (&a)[6]) {
         a[3 + r] = mod_b(a[3 + r]);
     }
 }
-__device__ __forceinline__ void store_acc(uint64_t* acc, const uint64_t (&a)[6], uint32_t ic, uint32_t z) {
-    // acc[ii][r][c][z], ic = ii*2 + c  ->  polynomial index 6*ii + 2*r + c
-    const uint32_t ii = ic >> 1, c = ic & 1u;
+// acc[perm(ii)][r][c][z], ic = ii*2 + c  ->  polynomial index 6*perm(ii) + 2*r + c.  perm groups the ciphertexts by
+// ii mod G (G = 2^g_log ranks of a distributed fold: rank g then owns the contiguous chunk of cts ii = g + G*k, which
+// is what one reduce-scatter hands it); G = 1 is the identity.
+__device__ __forceinline__ void store_acc(uint64_t* acc, const uint64_t (&a)[6], uint32_t ic, uint32_t z, uint32_t num_per, uint32_t g_log) {
+    const uint32_t i0 = ic >> 1, c = ic & 1u;
+    const uint32_t ii = (i0 & ((1u << g_log) - 1u)) * (num_per >> g_log) + (i0 >> g_log);
 #pragma unroll
     for (uint32_t r = 0; r < 3; r++) acc[((size_t)(6u * ii + 2u * r + c)) * kN + z] = pack((uint32_t)a[r], (uint32_t)a[3 + r]);
 }
@@ -55,7 +58,7 @@ __device__ __forceinline__ void store_acc(uint64_t* acc, const uint64_t (&a)[6],
 // loads in flight per wave (tools/sweep_tune.hip: 348 us vs 390 us for 4 waves x unroll 4 at config 2).
 constexpr uint32_t kSweepWaves = 2;
 __global__ __launch_bounds__(kSweepWaves * 64) void sweep_kernel(const uint64_t* __restrict__ db, const uint32_t* __restrict__ qs, uint64_t* __restrict__ acc,
-                                                    uint32_t nic, uint32_t dim0) {
+                                                    uint32_t nic, uint32_t dim0, uint32_t g_log) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * kSweepWaves + (threadIdx.x >> 6));
     const uint32_t wpz = nic >> 6;  // waves per z
@@ -72,12 +75,12 @@ __global__ __launch_bounds__(kSweepWaves * 64) void sweep_kernel(const uint64_t*
         }
         reduce6(a);
     }
-    store_acc(acc, a, ic, z);
+    store_acc(acc, a, ic, z, nic >> 1, g_log);
 }
 
 // small-geometry path (nic < 64, test sizes only): one thread per (z, ic), no wave-uniform query
 __global__ __launch_bounds__(256) void sweep_small_kernel(const uint64_t* __restrict__ db, const uint32_t* __restrict__ qs,
-                                                          uint64_t* __restrict__ acc, uint32_t nic, uint32_t dim0) {
+                                                          uint64_t* __restrict__ acc, uint32_t nic, uint32_t dim0, uint32_t g_log) {
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     const uint32_t z = g / nic, ic = g - z * nic;
     if (z >= kN) return;
@@ -90,18 +93,18 @@ __global__ __launch_bounds__(256) void sweep_small_kernel(const uint64_t* __rest
         if ((j & 127u) == 127u) reduce6(a);
     }
     reduce6(a);
-    store_acc(acc, a, ic, z);
+    store_acc(acc, a, ic, z, nic >> 1, g_log);
 }
 
-void launch_sweep(const uint64_t* db, const uint32_t* qs, uint64_t* acc, uint32_t num_per, uint32_t jm_total, hipStream_t s) {
+void launch_sweep(const uint64_t* db, const uint32_t* qs, uint64_t* acc, uint32_t num_per, uint32_t jm_total, uint32_t g_log, hipStream_t s) {
     const uint32_t nic = 2 * num_per, dim0 = jm_total / 2;
     if (dim0 == 0) return;
     if (nic >= 64) {
         const uint32_t waves = kN * (nic >> 6);
-        hipLaunchKernelGGL(sweep_kernel, dim3(waves / kSweepWaves), dim3(kSweepWaves * 64), 0, s, db, qs, acc, nic, dim0);
+        hipLaunchKernelGGL(sweep_kernel, dim3(waves / kSweepWaves), dim3(kSweepWaves * 64), 0, s, db, qs, acc, nic, dim0, g_log);
     } else {
         const uint32_t threads = kN * nic;
-        hipLaunchKernelGGL(sweep_small_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, db, qs, acc, nic, dim0);
+        hipLaunchKernelGGL(sweep_small_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, db, qs, acc, nic, dim0, g_log);
     }
 }
 

@@ -29,3 +29,32 @@ def reduce_accumulators(acc, dst: int = 0, group=None):
 
     dist.reduce(acc, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return acc
+
+
+def reduce_scatter_accumulators(chunk, acc, group=None):
+    """one collective: every rank receives the element-wise sum of its contiguous chunk of the ranks' accumulator
+    buffers (the sweep wrote them grouped by ii mod world, Server.set_fold_ranks).  RCCL has a native reduce-scatter;
+    gloo (CPU tests) does not, there the same result is an all-reduce followed by a slice."""
+    import torch.distributed as dist
+
+    if dist.get_backend(group) == "gloo":
+        tmp = acc.clone()
+        dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group)
+        n = chunk.numel()
+        chunk.copy_(tmp[dist.get_rank(group) * n:(dist.get_rank(group) + 1) * n])
+    else:
+        dist.reduce_scatter_tensor(chunk, acc, op=dist.ReduceOp.SUM, group=group)
+    return chunk
+
+
+def all_gather_cts(gathered, ct, group=None):
+    """collect the ranks' locally folded ciphertexts in rank order (96 KiB each)"""
+    import torch.distributed as dist
+
+    dist.all_gather_into_tensor(gathered, ct, group=group)
+    return gathered
+
+
+def fold_ranks(world: int, num_per: int) -> int:
+    """ranks taking part in the distributed fold: all of them when they divide num_per, else 1 (root folds alone)"""
+    return world if world >= 1 and (world & (world - 1)) == 0 and world <= num_per else 1

@@ -91,6 +91,17 @@ class Server:
         """lift + fold + finish"""
         check(lib().spiral_gpu_server_run_post(self.h, 1 if reduce_first else 0))
 
+    def set_fold_ranks(self, n_ranks: int):
+        check(lib().spiral_gpu_server_set_fold_ranks(self.h, n_ranks))
+
+    def fold_local(self, acc_chunk_ptr: int, out_ct_ptr: int):
+        """lift this rank's reduce-scattered chunk and run the local folding rounds -> one raw ct at out_ct_ptr"""
+        check(lib().spiral_gpu_server_fold_local(self.h, C.c_void_p(acc_chunk_ptr), C.c_void_p(out_ct_ptr)))
+
+    def fold_root(self, gathered_ptr: int):
+        """last log2(G) folding rounds + response switch on the G gathered cts (rank order)"""
+        check(lib().spiral_gpu_server_fold_root(self.h, C.c_void_p(gathered_ptr)))
+
     def acc(self):
         nbytes = C.c_size_t()
         ptr = lib().spiral_gpu_server_acc(self.h, C.byref(nbytes))

@@ -66,6 +66,84 @@ def test_two_rank_shard_and_reduce_equals_unsharded():
     assert ok
 
 
+def _worker_sharded_fold(rank, world, port, q):
+    """reduce-scatter + local fold + all-gather + root fold (bench.py's N > 1 path) with the oracle as the kernels"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+
+    from oracle import pyoracle as O
+    from spiral_amd import dist as sdist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    po = O.make_params(2, 2, t_gsw=4)
+    s = O.shape_of(po)
+    cl = O.Client(po, seed=5)  # same keys and query on both ranks
+    wl, wr, w, v = cl.pub_params()
+    qy = cl.query(9)
+    db = O.gen_db(po, 3)
+    cv = O.stage_expand(po, qy, wl, wr)
+    cts, gsw = O.stage_convert(po, cv, w, v)
+    G = sdist.fold_ranks(world, s.num_per)
+    j0, j1 = sdist.shard_range(rank, world, s.dim0)
+    dbv = db.reshape(O.N, s.num_per, 2, s.dim0, 2)[:, :, :, j0:j1, :]
+    part = O.multiply_query_by_database(O.reorient_ciphertexts(cts[j0:j1]), np.ascontiguousarray(dbv).reshape(-1), j1 - j0, s.num_per)
+    packed = (part[..., 0, :] | (part[..., 1, :] << np.uint64(32))).astype(np.uint64)  # [ii][3][2][N]
+    perm = np.array([(ii % G) * (s.num_per // G) + ii // G for ii in range(s.num_per)])  # Server.set_fold_ranks layout
+    grouped = np.zeros_like(packed)
+    grouped[perm] = packed
+    acc = torch.from_numpy(grouped.view(np.int64).reshape(-1).copy())
+    chunk = torch.zeros(acc.numel() // G, dtype=torch.int64)
+    sdist.reduce_scatter_accumulators(chunk, acc)
+    L = s.num_per // G
+    tot = chunk.numpy().view(np.uint64).reshape(L, 3, 2, O.N)
+    ntt = np.stack([(tot & np.uint64(0xFFFFFFFF)) % np.uint64(O.P), (tot >> np.uint64(32)) % np.uint64(O.B)], axis=-2)
+    raw = O.from_ntt(ntt)  # fold_local: lift, then nu2 - log2(G) rounds
+
+    def fold_rounds(raw_cts, d0, rounds):
+        x = np.ascontiguousarray(raw_cts).copy()
+        npr = x.shape[0]
+        m2 = s.m2
+        for d in range(d0, d0 + rounds):
+            npr //= 2
+            qraw = O.from_ntt(gsw[d])
+            g2 = O.build_gadget(3, m2)
+            neg = ((g2.astype(object) - qraw.astype(object)) % O.Q).astype(np.uint64)
+            q_re, qn_re = np.zeros(O.N * 3 * m2, dtype=np.uint64), np.zeros(O.N * 3 * m2, dtype=np.uint64)
+            O.lib().orc_reorient_Q(O._p(q_re), O._p(np.ascontiguousarray(gsw[d])), C.c_uint32(m2))
+            O.lib().orc_reorient_Q(O._p(qn_re), O._p(O.to_ntt(neg)), C.c_uint32(m2))
+            O.lib().orc_fold_one_further_dimension(O._p(x), C.c_size_t(npr), O._p(q_re), O._p(qn_re), C.c_uint32(po.t_gsw))
+        return x[0]
+
+    k = int(np.log2(G))
+    ct = torch.from_numpy(fold_rounds(raw, 0, po.nu2 - k).view(np.int64).reshape(-1).copy())
+    gathered = torch.zeros(G * ct.numel(), dtype=torch.int64)
+    sdist.all_gather_cts(gathered, ct)
+    if rank == 0:
+        fin = fold_rounds(gathered.numpy().view(np.uint64).reshape(G, 3, 2, O.N), po.nu2 - k, k)
+        q.put(bool((fin == O.answer(po, qy, wl, wr, w, v, db)).all()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_distributed_fold_equals_single_device():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sharded_fold, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok
+
+
 def test_shard_range_partition():
     from spiral_amd import dist as sdist
 

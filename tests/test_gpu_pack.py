@@ -10,6 +10,10 @@ N = 2048
 
 @pytest.fixture(scope="module")
 def sa():
+    # torch first: it ships its own HIP runtime and the two must not be initialised in the opposite order
+    import torch
+
+    torch.cuda.is_available()
     import spiral_amd
 
     assert spiral_amd.lib().spiral_gpu_device_count() > 0

@@ -11,6 +11,10 @@ N = 2048
 
 @pytest.fixture(scope="module")
 def sa():
+    # torch first: it ships its own HIP runtime and the two must not be initialised in the opposite order
+    import torch
+
+    torch.cuda.is_available()
     import spiral_amd
 
     assert spiral_amd.lib().spiral_gpu_device_count() > 0, "GPU tests need a device"
@@ -315,6 +319,55 @@ def test_sharded_first_dim_sums_to_unsharded(sa, oracle):
     tot[..., 0, :] %= O.P
     tot[..., 1, :] %= O.B
     assert (tot == accs[0]).all()
+
+
+@pytest.mark.parametrize("G", [2, 4, 8])
+def test_distributed_fold_emulated_on_one_gpu(sa, oracle, G):
+    """j-shards + reduce-scatter + local folds + gather + root folds, the ranks emulated by G servers on one device
+    and the two collectives by torch sums/slices: must equal the single-device answer bit for bit"""
+    import torch
+
+    O = oracle
+    kw = dict(t_gsw=4)
+    po, pg = O.make_params(4, 4, **kw), sa.make_params(4, 4, **kw)
+    s = O.shape_of(po)
+    cl = O.Client(po, seed=31)
+    wl, wr, w, v = cl.pub_params()
+    q = cl.query(201)
+    dev = torch.device("cuda", 0)
+    words = s.num_per * 6 * N
+    srvs, accs = [], []
+    for g in range(G):
+        srv = sa.Server(pg, 0, g * s.dim0 // G, (g + 1) * s.dim0 // G)
+        srv.gen_db(77)
+        srv.set_pub_params(wl, wr, w, v)
+        srv.set_query(q)
+        srv.set_fold_ranks(G)
+        acc = torch.zeros(words, dtype=torch.int64, device=dev)
+        srv.set_acc(acc.data_ptr())
+        srv.run_pre()
+        srv.first_dim()
+        srv.sync()
+        srvs.append(srv)
+        accs.append(acc)
+    total = torch.stack(accs).sum(0)  # the reduce part
+    L = words // G
+    cts = []
+    for g in range(G):  # the scatter part + local folds
+        chunk = total[g * L:(g + 1) * L].contiguous()
+        ct = torch.zeros(6 * N, dtype=torch.int64, device=dev)
+        srvs[g].fold_local(chunk.data_ptr(), ct.data_ptr())
+        srvs[g].sync()
+        cts.append(ct)
+    gathered = torch.cat(cts).contiguous()  # the all-gather
+    srvs[0].fold_root(gathered.data_ptr())
+    srvs[0].sync()
+    from spiral_amd import server as SV
+
+    assert_eq(srvs[0].read(SV.BUF_FINAL), O.answer(po, q, wl, wr, w, v, O.gen_db(po, 77)), f"distributed fold G={G}")
+    assert_eq(cl.decode(srvs[0].read(SV.BUF_RESPONSE)), O.db_item(po, 77, 201), "decoded plaintext")
+    for srv in srvs:
+        srv.close()
 
 
 @pytest.mark.slow

@@ -1,5 +1,5 @@
-"""why is the sweep slower inside bench.py than standalone? A/B the candidate causes in one process."""
-import sys, time; sys.path.insert(0, '.')
+"""Where does the in-pipeline sweep lose ~10% vs back-to-back sweeps?  A/B in one process with HIP events."""
+import sys; sys.path.insert(0, '.')
 import numpy as np, torch, spiral_amd as sa
 pg = sa.make_params(8, 7); s = sa.get_shape(pg)
 dev = torch.device('cuda', 0)
@@ -8,21 +8,25 @@ rng = np.random.default_rng(1)
 mk = lambda shape: np.stack([rng.integers(0, m, size=shape + (sa.N,), dtype=np.uint64) for m in (sa.P, sa.B)], axis=-2)
 srv.set_pub_params(mk((s.n_left, 2, pg.t_exp)), mk((s.n_right, 2, pg.t_exp_right)), mk((3, 8)), mk((3, 8)))
 srv.set_query(mk((1, 2)))
-def loop(n, label):
-    us = []
-    for _ in range(n):
-        us.append(srv.answer_resident())
-    print(f"{label:40s} sweep {np.median([u['sweep_kernel_us'] for u in us]):7.1f}  total {np.median([u['total_us'] for u in us]):7.1f}  standalone {srv.time_sweep(10)*1e3:7.1f}")
-loop(3, "own stream, own acc, few")
-loop(30, "own stream, own acc, 30 back-to-back")
-acc = torch.zeros(s.num_per * 6 * sa.N, dtype=torch.int64, device=dev)
-srv.set_acc(acc.data_ptr()); loop(30, "own stream, torch acc")
-st = torch.cuda.Stream(device=dev); srv.set_stream(st.cuda_stream); loop(30, "torch stream, torch acc")
-srv.use_graphs(True); loop(30, "torch stream, torch acc, graphs")
-# bench-style: no sync between steps
-with torch.cuda.stream(st):
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(30)]
-    for k in range(30):
-        srv.run_pre(); ev[k][0].record(st); srv.first_dim(); ev[k][1].record(st); srv.run_post(); ev[k][2].record(st)
-    torch.cuda.synchronize()
-    print("bench-style async: sweep", np.median([e[0].elapsed_time(e[1]) * 1e3 for e in ev]), " post", np.median([e[1].elapsed_time(e[2]) * 1e3 for e in ev]))
+st = torch.cuda.Stream(device=dev); srv.set_stream(st.cuda_stream)
+srv.answer_resident()
+def run(label, before, n=12):
+    ts = []
+    with torch.cuda.stream(st):
+        for _ in range(n):
+            before()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st); srv.first_dim(); e1.record(st)
+            ts.append((e0, e1))
+        torch.cuda.synchronize()
+    v = sorted(a.elapsed_time(b) * 1e3 for a, b in ts[2:])
+    print(f"{label:34s} median {v[len(v)//2]:7.1f}  min {v[0]:7.1f}")
+big = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+for rep in range(2):
+    run("back-to-back", lambda: None)
+    run("after expand+convert", lambda: srv.run_pre())
+    run("after lift+fold+finish", lambda: srv.run_post())
+    run("after expand only", lambda: srv.expand())
+    run("after convert only", lambda: srv.convert())
+    run("after 512MB memset", lambda: big.zero_())
+    run("after pre + sync", lambda: (srv.run_pre(), torch.cuda.synchronize()))
