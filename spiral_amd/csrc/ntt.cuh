@@ -9,6 +9,9 @@
 // Outputs are canonical residues in [0, m).
 #pragma once
 #include "common.h"
+#ifndef TWI
+#define TWI(i) (i)
+#endif
 
 namespace spiral {
 
@@ -58,47 +61,89 @@ __device__ __forceinline__ void gs2(uint32_t* lo, uint32_t* hi, int a, int b, ui
 // three forward stages on 8 register-resident coefficients whose indices differ in the 3 bits the
 // stages consume: distance 4, then 2, then 1 in register numbering
 __device__ __forceinline__ void ct_radix8(uint32_t* lo, uint32_t* hi, const uint4* tw, uint32_t b0, uint32_t b1, uint32_t b2) {
-    uint4 t0 = tw[b0];
+    uint4 t0 = tw[TWI(b0)];
 #pragma unroll
     for (int k = 0; k < 4; k++) ct2(lo, hi, k, k + 4, t0);
-    uint4 t1a = tw[b1], t1b = tw[b1 + 1];
+    uint4 t1a = tw[TWI(b1)], t1b = tw[TWI(b1 + 1)];
     ct2(lo, hi, 0, 2, t1a);
     ct2(lo, hi, 1, 3, t1a);
     ct2(lo, hi, 4, 6, t1b);
     ct2(lo, hi, 5, 7, t1b);
 #pragma unroll
-    for (int q = 0; q < 4; q++) ct2(lo, hi, 2 * q, 2 * q + 1, tw[b2 + q]);
+    for (int q = 0; q < 4; q++) ct2(lo, hi, 2 * q, 2 * q + 1, tw[TWI(b2 + q)]);
 }
 __device__ __forceinline__ void ct_radix4x2(uint32_t* lo, uint32_t* hi, const uint4* tw, uint32_t b1, uint32_t b2) {
-    uint4 t1a = tw[b1], t1b = tw[b1 + 1];
+    uint4 t1a = tw[TWI(b1)], t1b = tw[TWI(b1 + 1)];
     ct2(lo, hi, 0, 2, t1a);
     ct2(lo, hi, 1, 3, t1a);
     ct2(lo, hi, 4, 6, t1b);
     ct2(lo, hi, 5, 7, t1b);
 #pragma unroll
-    for (int q = 0; q < 4; q++) ct2(lo, hi, 2 * q, 2 * q + 1, tw[b2 + q]);
+    for (int q = 0; q < 4; q++) ct2(lo, hi, 2 * q, 2 * q + 1, tw[TWI(b2 + q)]);
 }
 // inverse order: distance 1, 2, 4
 __device__ __forceinline__ void gs_radix8(uint32_t* lo, uint32_t* hi, const uint4* tw, uint32_t b0, uint32_t b1, uint32_t b2) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) gs2(lo, hi, 2 * q, 2 * q + 1, tw[b2 + q]);
-    uint4 t1a = tw[b1], t1b = tw[b1 + 1];
+    for (int q = 0; q < 4; q++) gs2(lo, hi, 2 * q, 2 * q + 1, tw[TWI(b2 + q)]);
+    uint4 t1a = tw[TWI(b1)], t1b = tw[TWI(b1 + 1)];
     gs2(lo, hi, 0, 2, t1a);
     gs2(lo, hi, 1, 3, t1a);
     gs2(lo, hi, 4, 6, t1b);
     gs2(lo, hi, 5, 7, t1b);
-    uint4 t0 = tw[b0];
+    uint4 t0 = tw[TWI(b0)];
 #pragma unroll
     for (int k = 0; k < 4; k++) gs2(lo, hi, k, k + 4, t0);
 }
 __device__ __forceinline__ void gs_radix4x2(uint32_t* lo, uint32_t* hi, const uint4* tw, uint32_t b1, uint32_t b2) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) gs2(lo, hi, 2 * q, 2 * q + 1, tw[b2 + q]);
-    uint4 t1a = tw[b1], t1b = tw[b1 + 1];
+    for (int q = 0; q < 4; q++) gs2(lo, hi, 2 * q, 2 * q + 1, tw[TWI(b2 + q)]);
+    uint4 t1a = tw[TWI(b1)], t1b = tw[TWI(b1 + 1)];
     gs2(lo, hi, 0, 2, t1a);
     gs2(lo, hi, 1, 3, t1a);
     gs2(lo, hi, 4, 6, t1b);
     gs2(lo, hi, 5, 7, t1b);
+}
+
+// the 7 twiddles of a radix-8 pass (6 of a radix-4x2 pass), loaded ahead of the pass so that their latency hides
+// behind the previous pass's arithmetic and the LDS exchange
+struct Tw7 {
+    uint4 t[7];
+};
+__device__ __forceinline__ Tw7 tw_load8(const uint4* tw, uint32_t b0, uint32_t b1, uint32_t b2) {
+    Tw7 r;
+    r.t[0] = tw[TWI(b0)];
+    r.t[1] = tw[TWI(b1)];
+    r.t[2] = tw[TWI(b1 + 1)];
+#pragma unroll
+    for (int q = 0; q < 4; q++) r.t[3 + q] = tw[TWI(b2 + q)];
+    return r;
+}
+__device__ __forceinline__ Tw7 tw_load4x2(const uint4* tw, uint32_t b1, uint32_t b2) {
+    Tw7 r;
+    r.t[0] = make_uint4(0, 0, 0, 0);
+    r.t[1] = tw[TWI(b1)];
+    r.t[2] = tw[TWI(b1 + 1)];
+#pragma unroll
+    for (int q = 0; q < 4; q++) r.t[3 + q] = tw[TWI(b2 + q)];
+    return r;
+}
+__device__ __forceinline__ void ct_radix8_pre(uint32_t* lo, uint32_t* hi, const Tw7& w) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) ct2(lo, hi, k, k + 4, w.t[0]);
+    ct2(lo, hi, 0, 2, w.t[1]);
+    ct2(lo, hi, 1, 3, w.t[1]);
+    ct2(lo, hi, 4, 6, w.t[2]);
+    ct2(lo, hi, 5, 7, w.t[2]);
+#pragma unroll
+    for (int q = 0; q < 4; q++) ct2(lo, hi, 2 * q, 2 * q + 1, w.t[3 + q]);
+}
+__device__ __forceinline__ void ct_radix4x2_pre(uint32_t* lo, uint32_t* hi, const Tw7& w) {
+    ct2(lo, hi, 0, 2, w.t[1]);
+    ct2(lo, hi, 1, 3, w.t[1]);
+    ct2(lo, hi, 4, 6, w.t[2]);
+    ct2(lo, hi, 5, 7, w.t[2]);
+#pragma unroll
+    for (int q = 0; q < 4; q++) ct2(lo, hi, 2 * q, 2 * q + 1, w.t[3 + q]);
 }
 
 // ---- LDS tile -----------------------------------------------------------------------------------
@@ -132,6 +177,29 @@ __device__ __forceinline__ void lds_get(const uint64_t* sh, uint32_t tid, uint32
 // On return (lo,hi)[k] <-> slot ix_d(tid,k) = 8*tid + k, canonical in [0, m).
 // Bounds: < 2m in; +6m per pass: < 14m after passes A and B -> reduced to < 2m; < 12m after C and D.
 __device__ __forceinline__ void ntt_forward_block(uint32_t* lo, uint32_t* hi, uint64_t* sh, const uint4* tw, uint32_t tid) {
+#ifndef NTT_NO_PREFETCH_TW  // twiddles of the next pass are requested before the current pass's arithmetic (-3..4 % on the NTT-bound stages)
+    Tw7 wb = tw_load8(tw, 8 + (tid >> 5), 16 + 2 * (tid >> 5), 32 + 4 * (tid >> 5));
+    ct_radix8(lo, hi, tw, 1, 2, 4);
+    lds_put<ix_a>(sh, tid, lo, hi);
+    __syncthreads();
+    lds_get<ix_b>(sh, tid, lo, hi);
+    Tw7 wc = tw_load8(tw, 64 + (tid >> 2), 128 + 2 * (tid >> 2), 256 + 4 * (tid >> 2));
+    ct_radix8_pre(lo, hi, wb);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        lo[k] = lazy_reduce(lo[k], kP);
+        hi[k] = lazy_reduce(hi[k], kB);
+    }
+    lds_put<ix_b>(sh, tid, lo, hi);
+    __syncthreads();
+    lds_get<ix_c>(sh, tid, lo, hi);
+    Tw7 wd = tw_load4x2(tw, 512 + 2 * tid, 1024 + 4 * tid);
+    ct_radix8_pre(lo, hi, wc);
+    lds_put<ix_c>(sh, tid, lo, hi);
+    __syncthreads();
+    lds_get<ix_d>(sh, tid, lo, hi);
+    ct_radix4x2_pre(lo, hi, wd);
+#else
     ct_radix8(lo, hi, tw, 1, 2, 4);
     lds_put<ix_a>(sh, tid, lo, hi);
     __syncthreads();
@@ -152,6 +220,7 @@ __device__ __forceinline__ void ntt_forward_block(uint32_t* lo, uint32_t* hi, ui
     __syncthreads();
     lds_get<ix_d>(sh, tid, lo, hi);
     ct_radix4x2(lo, hi, tw, 512 + 2 * tid, 1024 + 4 * tid);
+#endif
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         lo[k] = csub(lazy_reduce(lo[k], kP), kP);
