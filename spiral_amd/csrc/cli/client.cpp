@@ -289,4 +289,196 @@ Poly Client::decode(const uint64_t* resp) const {
     return out;
 }
 
+// =====================================================================================================
+// SpiralPack client
+// =====================================================================================================
+namespace {
+Poly from_ntt(const Poly& a) {
+    Poly out(a.size() / 2);
+    ok(spiral_gpu_from_ntt(out.data(), a.data(), a.size() / (2 * N)), "from_ntt");
+    return out;
+}
+Poly const_poly(uint64_t v) {
+    Poly p(N, 0);
+    p[0] = v;
+    return p;
+}
+}  // namespace
+
+Poly pack_db_item(uint64_t seed, uint64_t item, uint64_t total_n, uint32_t out_n, uint64_t p_db) {
+    Poly pt((size_t)out_n * out_n * N);
+    for (uint32_t t = 0; t < out_n * out_n; t++)
+        for (uint32_t z = 0; z < N; z++) pt[(size_t)t * N + z] = splitmix64(seed ^ (((uint64_t)t * total_n + item) * N + z)) % p_db;
+    return pt;
+}
+
+PackClient::PackClient(const spiral_gpu_params& params, uint32_t out_n_, uint64_t seed, bool nonoise_)
+    : p(params), out_n(out_n_), nonoise(nonoise_), rng(seed) {
+    ok(spiral_gpu_pack_get_shape(&p, out_n, &s), "pack_get_shape");
+    double acc = 0;
+    for (int i = -64; i <= 64; i++) {
+        acc += std::exp(-M_PI * (double)i * i / (6.4 * 6.4));
+        cdf.push_back(acc);
+    }
+}
+uint64_t PackClient::sample_noise() {
+    if (nonoise) return 0;
+    double u = std::uniform_real_distribution<double>(0.0, cdf.back())(rng);
+    int64_t v = (int64_t)(std::lower_bound(cdf.begin(), cdf.end(), u) - cdf.begin()) - 64;
+    if (v > 64) v = 64;
+    return (uint64_t)((v + (int64_t)Q) % (int64_t)Q);
+}
+Poly PackClient::noise_polys(size_t n) {
+    Poly a(n * N);
+    for (auto& x : a) x = sample_noise();
+    return a;
+}
+Poly PackClient::uniform_polys(size_t n) {
+    Poly a(n * N);
+    for (auto& x : a) x = rng() % Q;
+    return a;
+}
+void PackClient::keygen() {  // keygen(S, Sp, sr, out_n), src/testing.cpp:907-910
+    sr = noise_polys(1);
+    sp = noise_polys(out_n);
+}
+Poly PackClient::regev_samples(size_t m) {
+    Poly a = uniform_polys(m), e = noise_polys(m);
+    Poly b = add(mul_by_const(to_ntt(sr), to_ntt(a)), to_ntt(e));
+    Poly out = to_ntt(invert(a));
+    out.insert(out.end(), b.begin(), b.end());
+    return out;
+}
+Poly PackClient::encrypt_simple_regev(const Poly& sigma_raw) {
+    Poly c = regev_samples(1);
+    Poly row1(c.begin() + 2 * N, c.end());
+    row1 = add(row1, to_ntt(sigma_raw));
+    std::copy(row1.begin(), row1.end(), c.begin() + 2 * N);
+    return c;
+}
+Poly PackClient::expansion_keys(uint32_t count, uint32_t t_dim) {  // getExpansionKeySwitchingMatrices, src/testing.cpp:21-38
+    Poly g_ntt = to_ntt(build_gadget(1, t_dim)), out;
+    for (uint32_t i = 0; i < count; i++) {
+        Poly mat = mul_by_const(to_ntt(automorph(sr, (N >> i) + 1)), g_ntt);
+        Poly enc = regev_samples(t_dim);
+        Poly row1(enc.begin() + (size_t)t_dim * 2 * N, enc.end());
+        row1 = add(row1, mat);
+        std::copy(row1.begin(), row1.end(), enc.begin() + (size_t)t_dim * 2 * N);
+        out.insert(out.end(), enc.begin(), enc.end());
+    }
+    return out;
+}
+void PackClient::gen_pub_params() {
+    const uint32_t tc = p.t_conv, rows = out_n + 1;
+    offline_bytes = 0;
+    auto account = [&](size_t r, size_t c, size_t count) { offline_bytes += (uint64_t)count * r * c * N * 56 / 8; };
+    Poly s0_ntt = to_ntt(sr), sp_ntt = to_ntt(sp);
+    Poly s0g = mul_by_const(s0_ntt, to_ntt(build_gadget(1, tc)));  // 1 x t_conv
+    v_w.clear();
+    for (uint32_t i = 0; i < out_n; i++) {  // v_W[i] = encryptMatrixArbitrary(AG_i), src/testing.cpp:918-925
+        Poly a = uniform_polys(tc), e = noise_polys((size_t)out_n * tc);
+        Poly a_ntt = to_ntt(a);
+        Poly b = add(to_ntt(e), multiply(sp_ntt, a_ntt, out_n, 1, tc));  // out_n x t_conv
+        Poly row(b.begin() + (size_t)i * tc * 2 * N, b.begin() + (size_t)(i + 1) * tc * 2 * N);
+        row = add(row, s0g);
+        std::copy(row.begin(), row.end(), b.begin() + (size_t)i * tc * 2 * N);
+        Poly w = to_ntt(invert(a));
+        w.insert(w.end(), b.begin(), b.end());
+        v_w.insert(v_w.end(), w.begin(), w.end());
+    }
+    account(rows, tc, out_n);
+    if (!p.direct_upload) {  // src/testing.cpp:926-949
+        w_left = expansion_keys(s.n_left, p.t_exp);
+        w_right = expansion_keys(s.n_right, p.t_exp_right);
+        Poly s0sq = multiply(s0_ntt, s0_ntt, 1, 1, 1);
+        const uint32_t bits = bits_per(tc), cols = 2 * tc;
+        v.assign((size_t)2 * cols * 2 * N, 0);
+        for (uint32_t i = 0; i < cols; i++) {
+            uint64_t sh = (uint64_t)bits * (i / 2);
+            Poly val_ntt = to_ntt(const_poly(sh >= 64 ? 0 : (1ull << sh)));
+            Poly sigma = from_ntt(multiply((i % 2 == 0) ? s0sq : s0_ntt, val_ntt, 1, 1, 1));
+            Poly ct = encrypt_simple_regev(sigma);
+            for (uint32_t r = 0; r < 2; r++) std::copy(ct.begin() + (size_t)r * 2 * N, ct.begin() + (size_t)(r + 1) * 2 * N, v.begin() + ((size_t)r * cols + i) * 2 * N);
+        }
+        account(2, p.t_exp, s.n_left);
+        account(2, p.t_exp_right, s.n_right);
+        account(2, cols, 1);
+    }
+    if (w_left.empty()) w_left.assign(1, 0);
+    if (w_right.empty()) w_right.assign(1, 0);
+    if (v.empty()) v.assign(1, 0);
+}
+Poly PackClient::query(uint64_t idx_target) {
+    const uint64_t idx_dim0 = idx_target / s.num_per, idx_further = idx_target % s.num_per, scale_k = Q / p.p_db;
+    const uint32_t bits = bits_per(s.ell);
+    Poly out;
+    if (p.direct_upload) {  // src/testing.cpp:966-989
+        for (uint32_t i = 0; i < s.dim0; i++) {
+            Poly c = encrypt_simple_regev(const_poly(i == idx_dim0 ? scale_k : 0));
+            out.insert(out.end(), c.begin(), c.end());
+        }
+        Poly s0_ntt = to_ntt(sr);
+        for (uint32_t i = 0; i < p.nu2; i++) {
+            const uint64_t bit = (idx_further >> i) & 1;
+            for (uint32_t j = 0; j < s.ell; j++) {
+                Poly val = const_poly((1ull << (bits * j)) * bit);
+                Poly c_odd = encrypt_simple_regev(val);                                                      // column 2j+1
+                Poly c_even = encrypt_simple_regev(from_ntt(multiply(s0_ntt, to_ntt(val), 1, 1, 1)));        // column 2j
+                out.insert(out.end(), c_even.begin(), c_even.end());
+                out.insert(out.end(), c_odd.begin(), c_odd.end());
+            }
+        }
+        return out;
+    }
+    Poly sigma(N, 0);  // src/testing.cpp:991-1006
+    sigma[2 * idx_dim0] = scale_k;
+    for (uint32_t i = 0; i < p.nu2; i++) {
+        const uint64_t bit = (idx_further >> i) & 1;
+        for (uint32_t j = 0; j < s.ell; j++) sigma[2 * (i * s.ell + j) + 1] = (1ull << (bits * j)) * bit;
+    }
+    const uint64_t inv_first = inv_mod_q(1ull << s.g), inv_rest = inv_mod_q(1ull << (s.stopround + 1));
+    for (uint32_t i = 0; i < N / 2; i++) {
+        sigma[2 * i] = (uint64_t)((u128)sigma[2 * i] * inv_first % Q);
+        sigma[2 * i + 1] = (uint64_t)((u128)sigma[2 * i + 1] * inv_rest % Q);
+    }
+    return encrypt_simple_regev(sigma);
+}
+Poly PackClient::decode(const uint64_t* resp) const {  // src/testing.cpp:1086-1122
+    const uint64_t qp = s.qprime, p_db = p.p_db, q1 = 4 * p_db;
+    Poly spq((size_t)out_n * N), out((size_t)out_n * out_n * N), prod(N);
+    for (size_t i = 0; i < spq.size(); i++) {
+        __int128 a = (__int128)sp[i];
+        if (a >= (__int128)(Q / 2)) a -= Q;
+        spq[i] = (uint64_t)((a + (__int128)((Q / qp) * qp) + (__int128)(2 * qp)) % (__int128)qp);
+    }
+    for (uint32_t r = 0; r < out_n; r++)
+        for (uint32_t col = 0; col < out_n; col++) {
+            std::fill(prod.begin(), prod.end(), 0);
+            const uint64_t* a = &spq[(size_t)r * N];
+            const uint64_t* b = resp + (size_t)col * N;
+            for (uint32_t i = 0; i < N; i++) {
+                if (a[i] == 0) continue;
+                for (uint32_t j = 0; j < N; j++) {
+                    uint64_t pr = (uint64_t)((u128)a[i] * b[j] % qp);
+                    uint32_t k = i + j;
+                    if (k < N) prod[k] = (prod[k] + pr) % qp;
+                    else prod[k - N] = (prod[k - N] + qp - pr) % qp;
+                }
+            }
+            for (uint32_t z = 0; z < N; z++) {
+                int64_t vf = (int64_t)prod[z];
+                if (vf >= (int64_t)(qp / 2)) vf -= (int64_t)qp;
+                int64_t vr = (int64_t)resp[((size_t)(1 + r) * out_n + col) * N + z];
+                if (vr >= (int64_t)(q1 / 2)) vr -= (int64_t)q1;
+                uint64_t denom = qp * (q1 / p_db);
+                int64_t rr = vf * (int64_t)q1 + vr * (int64_t)qp;
+                int64_t sign = rr >= 0 ? 1 : -1;
+                __int128 res = ((__int128)rr + sign * (int64_t)(denom / 2)) / (__int128)denom;
+                res = (res + (__int128)((denom / p_db) * p_db) + (__int128)(2 * p_db)) % (__int128)p_db;
+                out[((size_t)r * out_n + col) * N + z] = (uint64_t)res;
+            }
+        }
+    return out;
+}
+
 }  // namespace spiral_cli

@@ -43,6 +43,35 @@ struct Client {
     Poly encrypt_simple_regev(const Poly& sigma_raw);              // n0 x 1 NTT
 };
 
+// SpiralPack / SpiralStreamPack client (src/testing.cpp:905-1006, 1086-1122): base_dim x 1 Regev secret sr, out_n x 1
+// matrix secret Sp, packing keys v_W, expansion keys, conversion key V.
+struct PackClient {
+    spiral_gpu_params p;
+    spiral_gpu_pack_shape s;
+    uint32_t out_n;
+    bool nonoise = false;
+    std::mt19937_64 rng;
+    std::vector<double> cdf;
+    Poly sr, sp;
+    Poly w_left, w_right, v, v_w;
+    uint64_t offline_bytes = 0;
+
+    PackClient(const spiral_gpu_params& params, uint32_t out_n_, uint64_t seed, bool nonoise_);
+    void keygen();
+    void gen_pub_params();
+    Poly query(uint64_t idx_target);
+    Poly decode(const uint64_t* response) const;  // -> out_n x out_n raw plaintexts
+
+  private:
+    uint64_t sample_noise();
+    Poly noise_polys(size_t n);
+    Poly uniform_polys(size_t n);
+    Poly regev_samples(size_t m);
+    Poly expansion_keys(uint32_t count, uint32_t t_dim);
+    Poly encrypt_simple_regev(const Poly& sigma_raw);
+};
+Poly pack_db_item(uint64_t seed, uint64_t item, uint64_t total_n, uint32_t out_n, uint64_t p_db);
+
 // plaintext item of the seeded explicit database (same generator as spiral_gpu_server_gen_db)
 Poly db_item(uint64_t seed, uint64_t item, uint64_t p_db);
 

@@ -7,7 +7,7 @@
 // select_params.py:337); here the same nine values are read at run time from the environment variables or
 // flags of the same names (TEXP, TEXPRIGHT, TCONV, TGSW, QPBITS, PVALUE, QNUMFIRST, QNUMREST, OUTN), defaulting
 // to the paper's (20, 256) set.  The stdout lines select_params.py scrapes (:386-401) keep their wording.
-// --high-rate (SpiralPack) is not implemented yet and exits with an error rather than computing something else.
+// --high-rate selects SpiralPack / SpiralStreamPack (testHighRate, src/testing.cpp:777) with OUTN as out_n.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -44,6 +44,91 @@ static uint64_t param(int argc, char** argv, const char* name, uint64_t dflt) {
         }                                                                      \
     } while (0)
 
+static size_t bits_to_bytes(size_t bits) { return (size_t)std::llround((double)bits / 8.0); }
+
+// testHighRate (src/testing.cpp:777-1154): SpiralPack / SpiralStreamPack end to end, summary of :626-733
+static int run_high_rate(spiral_gpu_params p, uint32_t out_n, uint64_t idx_target, uint64_t seed, bool nonoise, bool show_diff, uint64_t qnum_first) {
+    cout << "Using n=" << out_n << endl;
+    spiral_gpu_pack_shape s;
+    GPU_OK(spiral_gpu_pack_get_shape(&p, out_n, &s));
+    const uint64_t total_n = (uint64_t)s.dim0 * s.num_per, db_seed = 1234;
+    spiral_gpu_pack_server* srv = nullptr;
+    GPU_OK(spiral_gpu_pack_server_create(&p, out_n, 0, &srv));
+    GPU_OK(spiral_gpu_pack_server_gen_db(srv, db_seed));
+    PackClient cl(p, out_n, seed, nonoise);
+    uint64_t t0 = now_us();
+    cl.keygen();
+    cl.gen_pub_params();
+    const double time_key_gen = (double)(now_us() - t0);
+    cout << "query: (" << idx_target / s.num_per << " ";
+    for (uint32_t i = 0; i < p.nu2; i++) cout << (((idx_target % s.num_per) >> i) & 1) << " ";
+    cout << ")" << endl;
+    t0 = now_us();
+    Poly query = cl.query(idx_target);
+    const double time_query_gen = (double)(now_us() - t0);
+    GPU_OK(spiral_gpu_pack_server_set_pub_params(srv, cl.w_left.data(), cl.w_right.data(), cl.v.data(), cl.v_w.data()));
+    Poly resp((size_t)(out_n + 1) * out_n * N);
+    double us[8];
+    GPU_OK(spiral_gpu_pack_server_answer(srv, query.data(), resp.data(), nullptr, us));  // warm-up
+    GPU_OK(spiral_gpu_pack_server_answer(srv, query.data(), resp.data(), nullptr, us));
+    t0 = now_us();
+    Poly pt = cl.decode(resp.data());
+    const double time_decoding = (double)(now_us() - t0);
+    Poly corr = pack_db_item(db_seed, idx_target, total_n, out_n, p.p_db);
+    const bool is_corr = pt == corr;
+    cout << "Is correct? : " << (is_corr ? 1 : 0) << endl;
+    if (show_diff) {
+        size_t shown = 0;
+        for (size_t i = 0; i < pt.size() && shown < 10; i++)
+            if (pt[i] != corr[i]) {
+                cout << i << ": " << pt[i] << " " << corr[i] << endl;
+                shown++;
+            }
+    }
+    // print_summary_testing (src/testing.cpp:626-733)
+    const size_t logp = (size_t)std::ceil(std::log2((double)p.p_db));
+    size_t total_query_size_b = bits_to_bytes((size_t)(((1ull << p.nu1) + 2ull * p.nu2 * p.t_gsw) * N * 56));
+    if (qnum_first == 1) total_query_size_b = bits_to_bytes((size_t)N * 56);
+    const size_t total_resp_size_b = bits_to_bytes((size_t)out_n * out_n * N * (logp + 2) + (size_t)out_n * N * p.qprime_bits);
+    const size_t item_size_b = bits_to_bytes((size_t)out_n * out_n * N * logp);
+    const double t_exp = us[0], t_conv = us[1], t_fdim = us[2], t_fold = us[3], t_pack = us[4];
+    const double total_time = t_fdim + t_fold + t_pack + t_exp + t_conv;
+    cout << "ScalToMat took (CPU·us): 0" << endl;
+    cout << "RegevToGSW took (CPU·us): 0" << endl;
+    cout << "Expansion took (CPU·us): 0" << endl;
+    cout << std::fixed << std::setprecision(0);
+    cout << "Database" << endl << endl;
+    cout << "                       Number of items: " << total_n << endl;
+    cout << "                             Item size: " << item_size_b << endl;
+    cout << "Communication" << endl << endl;
+    cout << "         Total offline query size (b): " << cl.offline_bytes << endl;
+    cout << "          Total online query size (b): " << total_query_size_b << endl;
+    cout << "                    Response size (b): " << total_resp_size_b << endl;
+    cout << std::fixed << std::setprecision(4);
+    cout << "                                Rate : " << ((double)item_size_b / (double)total_resp_size_b) << endl;
+    cout << std::fixed << std::setprecision(0);
+    cout << endl << endl;
+    cout << "Database-independent computation" << endl << endl;
+    cout << "              Main expansion  (CPU·us): " << t_exp << endl;
+    cout << "                   Conversion (CPU·us): " << t_conv << endl;
+    cout << "                        Total (CPU·us): " << (t_exp + t_conv) << endl << endl;
+    cout << "Database-dependent computation" << endl << endl;
+    cout << "     First dimension multiply (CPU·us): " << t_fdim << endl;
+    cout << "                      Folding (CPU·us): " << t_fold << endl;
+    cout << "                      Packing (CPU·us): " << t_pack << endl;
+    cout << "                        Total (CPU·us): " << (t_fdim + t_fold + t_pack) << endl;
+    cout << "                   Throughput (MB / s): " << ((double)total_n * item_size_b / total_time) << endl << endl;
+    cout << "Client computation" << endl << endl;
+    cout << "               Key generation (CPU·us): " << time_key_gen << endl;
+    cout << "             Query generation (CPU·us): " << time_query_gen << endl;
+    cout << "                     Decoding (CPU·us): " << time_decoding << endl << endl;
+    cout << "GPU extras" << endl << endl;
+    cout << "      Sweep kernels alone (GPU·us): " << us[5] << "  (" << (double)out_n * out_n * spiral_gpu_pack_server_sweep_bytes(srv) / us[5] / 1e3 << " GB/s)" << endl;
+    cout << "      Whole answer, device (GPU·us): " << us[6] << endl;
+    spiral_gpu_pack_server_destroy(srv);
+    return is_corr ? 0 : 2;
+}
+
 int main(int argc, char** argv) {
     if (argc < 4) {
         fprintf(stderr, "usage: %s <nu1> <nu2> <IDX_TARGET> [dbfile|a] [--random-data] [--direct-upload] [--nonoise] [--show-diff] [--seed N]\n", argv[0]);
@@ -61,10 +146,6 @@ int main(int argc, char** argv) {
         if (!strcmp(argv[i], "--show-diff")) { cout << "Showing diff..." << endl; show_diff = true; }
         if (!strcmp(argv[i], "--direct-upload")) { cout << "Direct uploading of query (no compression)" << endl; direct_flag = true; }
         if (!strcmp(argv[i], "--seed") && i + 1 < argc) seed = strtoull(argv[++i], nullptr, 10);
-    }
-    if (high_rate) {
-        fprintf(stderr, "spiral: --high-rate (SpiralPack, src/testing.cpp) is not implemented in this build\n");
-        return 1;
     }
     if (idx_target >= total_n) {
         fprintf(stderr, "spiral: IDX_TARGET %llu out of range (n = %llu)\n", (unsigned long long)idx_target, (unsigned long long)total_n);
@@ -94,6 +175,7 @@ int main(int argc, char** argv) {
         fprintf(stderr, "spiral: no ROCm device found; this build has no CPU path\n");
         return 1;
     }
+    if (high_rate) return run_high_rate(p, (uint32_t)param(argc, argv, "OUTN", 2), idx_target, seed, nonoise, show_diff, qnum_first);
     spiral_gpu_shape s;
     GPU_OK(spiral_gpu_get_shape(&p, &s));
     cout << "dim0: " << s.dim0 << endl;

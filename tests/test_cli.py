@@ -32,8 +32,8 @@ def test_cli_refuses_to_run_without_gpu_or_args():
     assert os.path.exists(BIN), "build() must produce spiral_amd/spiral"
     r = subprocess.run([BIN], capture_output=True, text=True)
     assert r.returncode == 1 and "usage" in r.stderr
-    r = subprocess.run([BIN, "4", "2", "5", "a", "--high-rate"], capture_output=True, text=True)
-    assert r.returncode == 1 and "not implemented" in r.stderr
+    r = subprocess.run([BIN, "4", "2", "999999", "a"], capture_output=True, text=True)
+    assert r.returncode == 1 and "out of range" in r.stderr
 
 
 @pytest.mark.gpu
@@ -52,3 +52,20 @@ def test_cli_end_to_end(args, env):
     assert not missing, (missing, r.stdout)
     assert got["is_corr"].group(1) == "1"
     assert int(got["resp_sz"].group(1)) == int((2 * 2 * 2048 * (8 + 2) + 2 * 2048 * int(env.get("QPBITS", 20))) / 8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args,env", [
+    (["6", "2", "77", "a", "--high-rate", "--seed", "6"], {}),  # the SURVEY 8c probe: ./spiral 6 2 77 a --high-rate
+    (["5", "2", "9", "a", "--high-rate", "--seed", "7"], {"OUTN": "3", "TGSW": "4"}),
+    (["3", "2", "5", "a", "--high-rate", "--direct-upload", "--seed", "8"], {"TEXP": "2", "TGSW": "5", "QPBITS": "19"}),
+])
+def test_cli_high_rate(args, env):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([BIN] + args, capture_output=True, text=True, env=e, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    pack_re = r"\s+Packing.*:\s+([0-9]+)"  # select_params.py:393
+    for k, rx in list(REGEXES.items()) + [("pack_us", pack_re)]:
+        assert re.search(rx, r.stdout), (k, r.stdout)
+    assert re.search(REGEXES["is_corr"], r.stdout).group(1) == "1"
