@@ -39,6 +39,13 @@ __device__ __forceinline__ uint64_t crt_compose(uint32_t x, uint32_t y) {
     return (uint64_t)x + (uint64_t)kP * k;
 }
 
+// Physical position of NTT slot s inside a PK polynomial.  The transforms hold slots 8*tid .. 8*tid+7 in thread tid,
+// so PK buffers are stored "thread-transposed": slot 8*tid + k lives at k*256 + tid.  A wave then reads / writes 512
+// contiguous bytes per instruction instead of 64 scattered 64-byte lines (the strided form made the forward
+// transforms store-bound).  Everything pointwise is oblivious to the order; only the boundary kernels that meet the
+// reference's slot order (ref<->PK conversion, database / query relayout) apply the map.
+__host__ __device__ inline uint32_t pk_pos(uint32_t s) { return ((s & 7u) << 8) | (s >> 3); }
+
 // Device database layout (internal; built at load time).  The nic = 2*num_per output columns ic = ii*2 + c are
 // grouped in blocks of W = min(64, nic) -- one wave of the sweep owns one block -- and a block's words are
 // contiguous over (j, lane, m): word(z, j, ic, m) at (((z*nblk + ic/W)*dim0 + j)*W + ic%W)*2 + m.

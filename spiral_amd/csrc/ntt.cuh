@@ -12,6 +12,11 @@
 #ifndef TWI
 #define TWI(i) (i)
 #endif
+#ifdef NTT_ABLATE_BARRIER
+#define NTT_SYNC() ((void)0)
+#else
+#define NTT_SYNC() __syncthreads()
+#endif
 
 namespace spiral {
 
@@ -34,7 +39,11 @@ __device__ __forceinline__ uint32_t shoup(uint32_t y, uint32_t w, uint32_t ws, u
 __device__ __forceinline__ uint32_t lazy_reduce(uint32_t x, uint32_t m) { return x - (x >> 28) * m; }
 // forward (Cooley-Tukey): bound grows by 2m per stage
 __device__ __forceinline__ void ct_bfly(uint32_t& x, uint32_t& y, uint32_t w, uint32_t ws, uint32_t m) {
+#ifdef NTT_ABLATE_ALU
+    const uint32_t t = y ^ w;
+#else
     const uint32_t t = shoup(y, w, ws, m);
+#endif
     const uint32_t x0 = x;
     x = x0 + t;
     y = x0 + 2 * m - t;
@@ -160,11 +169,17 @@ __device__ __forceinline__ uint32_t ix_d(uint32_t tid, int k) { return 8u * tid 
 
 template <uint32_t (*IX)(uint32_t, int)>
 __device__ __forceinline__ void lds_put(uint64_t* sh, uint32_t tid, const uint32_t* lo, const uint32_t* hi) {
+#ifdef NTT_ABLATE_LDS
+    return;
+#endif
 #pragma unroll
     for (int k = 0; k < 8; k++) sh[lds_ix(IX(tid, k))] = pack(lo[k], hi[k]);
 }
 template <uint32_t (*IX)(uint32_t, int)>
 __device__ __forceinline__ void lds_get(const uint64_t* sh, uint32_t tid, uint32_t* lo, uint32_t* hi) {
+#ifdef NTT_ABLATE_LDS
+    return;
+#endif
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         uint64_t v = sh[lds_ix(IX(tid, k))];
@@ -181,7 +196,7 @@ __device__ __forceinline__ void ntt_forward_block(uint32_t* lo, uint32_t* hi, ui
     Tw7 wb = tw_load8(tw, 8 + (tid >> 5), 16 + 2 * (tid >> 5), 32 + 4 * (tid >> 5));
     ct_radix8(lo, hi, tw, 1, 2, 4);
     lds_put<ix_a>(sh, tid, lo, hi);
-    __syncthreads();
+    NTT_SYNC();
     lds_get<ix_b>(sh, tid, lo, hi);
     Tw7 wc = tw_load8(tw, 64 + (tid >> 2), 128 + 2 * (tid >> 2), 256 + 4 * (tid >> 2));
     ct_radix8_pre(lo, hi, wb);
@@ -191,18 +206,18 @@ __device__ __forceinline__ void ntt_forward_block(uint32_t* lo, uint32_t* hi, ui
         hi[k] = lazy_reduce(hi[k], kB);
     }
     lds_put<ix_b>(sh, tid, lo, hi);
-    __syncthreads();
+    NTT_SYNC();
     lds_get<ix_c>(sh, tid, lo, hi);
     Tw7 wd = tw_load4x2(tw, 512 + 2 * tid, 1024 + 4 * tid);
     ct_radix8_pre(lo, hi, wc);
     lds_put<ix_c>(sh, tid, lo, hi);
-    __syncthreads();
+    NTT_SYNC();
     lds_get<ix_d>(sh, tid, lo, hi);
     ct_radix4x2_pre(lo, hi, wd);
 #else
     ct_radix8(lo, hi, tw, 1, 2, 4);
     lds_put<ix_a>(sh, tid, lo, hi);
-    __syncthreads();
+    NTT_SYNC();
     lds_get<ix_b>(sh, tid, lo, hi);
     uint32_t g = tid >> 5;
     ct_radix8(lo, hi, tw, 8 + g, 16 + 2 * g, 32 + 4 * g);
@@ -212,12 +227,12 @@ __device__ __forceinline__ void ntt_forward_block(uint32_t* lo, uint32_t* hi, ui
         hi[k] = lazy_reduce(hi[k], kB);
     }
     lds_put<ix_b>(sh, tid, lo, hi);
-    __syncthreads();
+    NTT_SYNC();
     lds_get<ix_c>(sh, tid, lo, hi);
     g = tid >> 2;
     ct_radix8(lo, hi, tw, 64 + g, 128 + 2 * g, 256 + 4 * g);
     lds_put<ix_c>(sh, tid, lo, hi);
-    __syncthreads();
+    NTT_SYNC();
     lds_get<ix_d>(sh, tid, lo, hi);
     ct_radix4x2(lo, hi, tw, 512 + 2 * tid, 1024 + 4 * tid);
 #endif

@@ -176,6 +176,9 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
 
     ntt_forward_block(lo, hi, sh, t.fwd, tid);
 
+#ifdef NTT_ABLATE_STORE
+    if (lo[0] != 0x12345u) return;
+#endif
     if constexpr (STORE == ST_PK) {
         uint32_t di;
         if constexpr (LOAD == LD_PDIGIT) {
@@ -197,12 +200,9 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
         } else {
             di = p.dst_map(b);
         }
-        uint64_t* dst = p.dst + (size_t)di * kN + 8u * tid;
+        uint64_t* dst = p.dst + (size_t)di * kN + tid;  // pk_pos(8*tid + r) = r*256 + tid
 #pragma unroll
-        for (int r = 0; r < 8; r += 2) {
-            ulonglong2 v2 = make_ulonglong2(pack(lo[r], hi[r]), pack(lo[r + 1], hi[r + 1]));
-            *reinterpret_cast<ulonglong2*>(dst + r) = v2;
-        }
+        for (int r = 0; r < 8; r++) dst[r * 256] = pack(lo[r], hi[r]);
     } else if constexpr (STORE == ST_REF) {
         uint64_t* dst = p.dst + (size_t)p.dst_map(b) * (2 * kN) + 8u * tid;
 #pragma unroll
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
         const size_t zstride = (size_t)p.dim0_shard * p.num_per;  // words per z slab
         uint64_t* dst = p.dst + db1_word_index(0, j, ii, p.num_per, p.dim0_shard);
 #pragma unroll
-        for (int r = 0; r < 8; r++) dst[(size_t)(8u * tid + r) * zstride] = pack(lo[r], hi[r]);
+        for (int r = 0; r < 8; r++) dst[(size_t)(r * 256u + tid) * zstride] = pack(lo[r], hi[r]);  // slab index = pk_pos(slot)
     } else {  // ST_DB: scatter into the sweep layout
         const uint64_t item = p.item_base + (b >> 2);
         const uint32_t mc = b & 3u, m = mc >> 1, c = mc & 1u;
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
         const size_t zstride = (size_t)p.dim0_shard * nic * 2u;  // words per z slab
         uint64_t* dst = p.dst + db_word_index(0, j - p.j0, ic, m, nic, p.dim0_shard);
 #pragma unroll
-        for (int r = 0; r < 8; r++) dst[(size_t)(8u * tid + r) * zstride] = pack(lo[r], hi[r]);
+        for (int r = 0; r < 8; r++) dst[(size_t)(r * 256u + tid) * zstride] = pack(lo[r], hi[r]);  // slab index = pk_pos(slot)
     }
 }
 
@@ -238,28 +238,23 @@ __global__ __launch_bounds__(256) void ntt_inverse_kernel(Tables t, InvParams p)
         const uint32_t a = b >> 1, row = b & 1u;
         const uint32_t i = a < p.cnt_e ? 2u * a : 2u * (a - p.cnt_e) + 1u;
         if (i >= p.num_in) {  // cv[i] = neg1 * cv[i - num_in], created here and transformed in the same pass
-            const uint64_t* src = p.cv + ((size_t)(i - p.num_in) * 2u + row) * kN + 8u * tid;
-            const uint64_t* ng = p.neg1 + 8u * tid;
-            uint64_t* dstc = p.cv + ((size_t)i * 2u + row) * kN + 8u * tid;
+            const uint64_t* src = p.cv + ((size_t)(i - p.num_in) * 2u + row) * kN + tid;
+            const uint64_t* ng = p.neg1 + tid;
+            uint64_t* dstc = p.cv + ((size_t)i * 2u + row) * kN + tid;
 #pragma unroll
-            for (int r = 0; r < 8; r += 2) {
-                ulonglong2 v2 = *reinterpret_cast<const ulonglong2*>(src + r);
-                ulonglong2 w2 = *reinterpret_cast<const ulonglong2*>(ng + r);
-                lo[r] = mod_p((uint64_t)lo32(v2.x) * lo32(w2.x));
-                hi[r] = mod_b((uint64_t)hi32(v2.x) * hi32(w2.x));
-                lo[r + 1] = mod_p((uint64_t)lo32(v2.y) * lo32(w2.y));
-                hi[r + 1] = mod_b((uint64_t)hi32(v2.y) * hi32(w2.y));
-                *reinterpret_cast<ulonglong2*>(dstc + r) = make_ulonglong2(pack(lo[r], hi[r]), pack(lo[r + 1], hi[r + 1]));
+            for (int r = 0; r < 8; r++) {
+                const uint64_t v = src[r * 256], w = ng[r * 256];
+                lo[r] = mod_p((uint64_t)lo32(v) * lo32(w));
+                hi[r] = mod_b((uint64_t)hi32(v) * hi32(w));
+                dstc[r * 256] = pack(lo[r], hi[r]);
             }
         } else {
-            const uint64_t* src = p.cv + ((size_t)i * 2u + row) * kN + 8u * tid;
+            const uint64_t* src = p.cv + ((size_t)i * 2u + row) * kN + tid;
 #pragma unroll
-            for (int r = 0; r < 8; r += 2) {
-                ulonglong2 v2 = *reinterpret_cast<const ulonglong2*>(src + r);
-                lo[r] = lo32(v2.x);
-                hi[r] = hi32(v2.x);
-                lo[r + 1] = lo32(v2.y);
-                hi[r + 1] = hi32(v2.y);
+            for (int r = 0; r < 8; r++) {
+                const uint64_t v = src[r * 256];
+                lo[r] = lo32(v);
+                hi[r] = hi32(v);
             }
         }
     } else if (p.src_ref) {
@@ -270,14 +265,12 @@ __global__ __launch_bounds__(256) void ntt_inverse_kernel(Tables t, InvParams p)
             hi[r] = (uint32_t)src[kN + r];
         }
     } else {
-        const uint64_t* src = p.src + (size_t)p.src_map(b) * kN + 8u * tid;
+        const uint64_t* src = p.src + (size_t)p.src_map(b) * kN + tid;  // pk_pos(8*tid + r) = r*256 + tid
 #pragma unroll
-        for (int r = 0; r < 8; r += 2) {
-            ulonglong2 v2 = *reinterpret_cast<const ulonglong2*>(src + r);
-            lo[r] = lo32(v2.x);
-            hi[r] = hi32(v2.x);
-            lo[r + 1] = lo32(v2.y);
-            hi[r + 1] = hi32(v2.y);
+        for (int r = 0; r < 8; r++) {
+            const uint64_t v = src[r * 256];
+            lo[r] = lo32(v);
+            hi[r] = hi32(v);
         }
     }
     if (p.pre_reduce) {
@@ -306,12 +299,12 @@ __global__ __launch_bounds__(256) void ref_to_pk_kernel(const uint64_t* ref, uin
     const size_t poly = blockIdx.y;
     const uint32_t z = blockIdx.x * 256u + threadIdx.x;
     const uint64_t* r = ref + poly * (2 * kN);
-    pk[(size_t)pk_map((uint32_t)poly) * kN + z] = pack((uint32_t)(r[z] % kP), (uint32_t)(r[kN + z] % kB));
+    pk[(size_t)pk_map((uint32_t)poly) * kN + pk_pos(z)] = pack((uint32_t)(r[z] % kP), (uint32_t)(r[kN + z] % kB));
 }
 __global__ __launch_bounds__(256) void pk_to_ref_kernel(const uint64_t* pk, uint64_t* ref, IndexMap pk_map) {
     const size_t poly = blockIdx.y;
     const uint32_t z = blockIdx.x * 256u + threadIdx.x;
-    uint64_t v = pk[(size_t)pk_map((uint32_t)poly) * kN + z];
+    uint64_t v = pk[(size_t)pk_map((uint32_t)poly) * kN + pk_pos(z)];
     ref[poly * (2 * kN) + z] = lo32(v);
     ref[poly * (2 * kN) + kN + z] = hi32(v);
 }

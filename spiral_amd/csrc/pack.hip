@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void qs1_from_reoriented_kernel(const uint64_t
     const size_t g = (size_t)blockIdx.x * 256u + threadIdx.x;
     if (g >= (size_t)kN * dim0) return;
     const uint64_t r0 = re[g * 2], r1 = re[g * 2 + 1];
-    reinterpret_cast<uint4*>(qs)[g] = make_uint4(lo32(r0) % kP, lo32(r1) % kP, hi32(r0) % kB, hi32(r1) % kB);
+    const uint32_t z = (uint32_t)(g / dim0), j = (uint32_t)(g - (size_t)z * dim0);  // z in the reference's slot order
+    reinterpret_cast<uint4*>(qs)[(size_t)pk_pos(z) * dim0 + j] = make_uint4(lo32(r0) % kP, lo32(r1) % kP, hi32(r0) % kB, hi32(r1) % kB);
 }
 void launch_qs1_from_reoriented(const uint64_t* re, uint32_t* qs1, uint32_t dim0, hipStream_t s) {
     const size_t n = (size_t)kN * dim0;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void db1_relayout_kernel(const uint64_t* __res
     if (z >= kN) return;
     const size_t rem = o - (size_t)z * per_z;
     const uint32_t ii = (uint32_t)(rem / dim0), j = (uint32_t)(rem % dim0);
-    dev[db1_word_index(z, j, ii, num_per, dim0)] = ref[o];
+    dev[db1_word_index(pk_pos(z), j, ii, num_per, dim0)] = ref[o];
 }
 void launch_db1_relayout(const uint64_t* ref, uint64_t* dev, uint32_t num_per, uint32_t dim0, hipStream_t s) {
     const size_t words = (size_t)kN * num_per * dim0;

@@ -351,9 +351,9 @@ void launch_fold_key(const uint64_t* gsw, uint64_t* key, uint32_t dims, uint32_t
 
 __global__ __launch_bounds__(kTpb) void fold_key_from_reoriented_kernel(const uint64_t* q_re, const uint64_t* qneg_re, uint64_t* key, uint32_t m2) {
     const uint32_t z = blockIdx.x * kTpb + threadIdx.x, rm = blockIdx.y, r = rm / m2, mm = rm - r * m2;
-    const size_t src = (size_t)z * (3 * m2) + rm;
+    const size_t src = (size_t)z * (3 * m2) + rm;  // z in the reference's slot order
     const uint64_t q = q_re[src], qn = qneg_re[src];
-    uint64_t* k = key + (size_t)r * (2 * m2) * kN + z;
+    uint64_t* k = key + (size_t)r * (2 * m2) * kN + pk_pos(z);
     k[(size_t)mm * kN] = pack(lo32(qn) % kP, hi32(qn) % kB);
     k[(size_t)(m2 + mm) * kN] = pack(lo32(q) % kP, hi32(q) % kB);
 }

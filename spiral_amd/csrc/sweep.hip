@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void db_relayout_kernel(const uint64_t* __rest
     rem >>= 1;
     const uint32_t ic = (uint32_t)(rem % nic), jl = (uint32_t)(rem / nic);
     const uint32_t ii = ic >> 1, c = ic & 1u, j = j0 + jl;
-    dev[db_word_index(z, jl, ic, m, nic, dim0_shard)] = ref[(size_t)z * ((size_t)num_per * 2u * dim0 * 2u) + (size_t)ii * (2u * dim0 * 2u) + (size_t)c * (dim0 * 2u) + (size_t)j * 2u + m];
+    dev[db_word_index(pk_pos(z), jl, ic, m, nic, dim0_shard)] = ref[(size_t)z * ((size_t)num_per * 2u * dim0 * 2u) + (size_t)ii * (2u * dim0 * 2u) + (size_t)c * (dim0 * 2u) + (size_t)j * 2u + m];
 }
 void launch_db_relayout(const uint64_t* db_ref, uint64_t* db_dev, uint32_t num_per, uint32_t dim0, uint32_t j0, uint32_t dim0_shard, uint32_t nz,
                         hipStream_t s) {
@@ -131,10 +131,11 @@ void launch_db_relayout(const uint64_t* db_ref, uint64_t* db_dev, uint32_t num_p
 
 // reference reorientCiphertexts layout (src/spiral.cpp:410-433): z*(dim0*2*4) + j*8 + m*4 + r
 __global__ __launch_bounds__(256) void qs_from_reoriented_kernel(const uint64_t* __restrict__ re, uint32_t* __restrict__ qs, uint32_t jm_total) {
-    const size_t g = (size_t)blockIdx.x * 256u + threadIdx.x;  // (z, jm)
+    const size_t g = (size_t)blockIdx.x * 256u + threadIdx.x;  // (z, jm), z in the reference's slot order
     if (g >= (size_t)kN * jm_total) return;
     const uint64_t* src = re + g * 4u;
-    uint32_t* rec = qs + g * 6u;  // (z, j) record = 12 u32, m selects the half
+    const uint32_t z = (uint32_t)(g / jm_total), jm = (uint32_t)(g - (size_t)z * jm_total);
+    uint32_t* rec = qs + ((size_t)pk_pos(z) * jm_total + jm) * 6u;  // (z, j) record = 12 u32, m selects the half
 #pragma unroll
     for (uint32_t r = 0; r < 3; r++) {
         rec[r] = lo32(src[r]) % kP;
