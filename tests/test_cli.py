@@ -69,3 +69,64 @@ def test_cli_high_rate(args, env):
     for k, rx in list(REGEXES.items()) + [("pack_us", pack_re)]:
         assert re.search(rx, r.stdout), (k, r.stdout)
     assert re.search(REGEXES["is_corr"], r.stdout).group(1) == "1"
+
+
+# ---- spiral_amd.scheme: the JSON driver with the reference's keys (select_params.py:376-576) ----
+REF_KEYS = {"exp_us", "exp_specific_us", "conv_us", "scaltomat_us", "regtogsw_us", "fdim_us", "fold_us", "pack_us", "total_us",
+            "query_gen_us", "key_gen_us", "decoding_us", "resp_sz", "query_sz", "param_sz", "is_corr", "item_sz", "dbsize", "params",
+            "tput", "rate", "cost"}
+SMALL = {"nu_1": 4, "nu_2": 2, "p": 256, "q_prime_bits": 20, "t_GSW": 4, "t_conv": 4, "t_exp": 8, "t_exp_right": 56}
+
+
+def test_scheme_analyze_and_derived_columns():
+    from spiral_amd import scheme
+    text = """
+ScalToMat took (CPU·us): 11
+RegevToGSW took (CPU·us): 22
+Expansion took (CPU·us): 3.3e+02
+         Total offline query size (b): 1000
+          Total online query size (b): 28672
+                    Response size (b): 21504
+              Main expansion  (CPU·us): 330
+                   Conversion (CPU·us): 33
+     First dimension multiply (CPU·us): 400
+                      Folding (CPU·us): 500
+               Key generation (CPU·us): 1
+             Query generation (CPU·us): 2
+                     Decoding (CPU·us): 3
+Is correct? : 1
+"""
+    r = scheme.analyze(text, SMALL, factor=3)
+    assert r["exp_specific_us"] == 330 and r["fdim_us"] == 1200 and r["fold_us"] == 1500 and r["pack_us"] == 0
+    assert r["resp_sz"] == 3 * 21504 and r["query_sz"] == 14336 and r["is_corr"] is True
+    assert r["total_us"] == 330 + 33 + 1200 + 1500
+    s = scheme.summarize([r, r], SMALL, item_size=20000, factor=3)
+    assert set(s) >= REF_KEYS
+    assert s["item_sz"] == 3 * 8192 and s["dbsize"] == 3 * 8192 * 64
+    assert s["tput"] == pytest.approx(s["dbsize"] / 2700) and s["rate"] == pytest.approx(20000 / (3 * 21504))
+    assert s["cost"] == pytest.approx(5.41666667e-12 * s["total_us"] + 9e-11 * s["resp_sz"])
+    with pytest.raises(ValueError):
+        scheme.analyze(text, dict(SMALL, n=2))  # a high-rate run must print a Packing line
+
+
+def test_scheme_command_lines():
+    from spiral_amd import scheme
+    argv, env = scheme.command(scheme.PUBLISHED["20,256"]["spiralstream-pack"], 5, corr=False, seed=9)
+    assert argv[1:] == ["10", "3", "5", "a", "--random-data", "--high-rate", "--direct-upload", "--seed", "9"]
+    assert env == {"TEXP": "56", "TEXPRIGHT": "56", "TCONV": "56", "TGSW": "2", "QPBITS": "21", "PVALUE": "1024", "OUTN": "4"}
+    for work in scheme.PUBLISHED.values():
+        for params in work.values():
+            assert {"nu_1", "nu_2", "p", "q_prime_bits", "t_GSW", "t_conv", "t_exp", "t_exp_right"} <= set(params)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("params", [SMALL, dict(SMALL, n=2, nu_1=5)])
+def test_scheme_json(params):
+    import json
+    import sys
+    r = subprocess.run([sys.executable, "-m", "spiral_amd.scheme", "--params", json.dumps(params), "--seed", "1", "--trials", "2"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert set(out) >= REF_KEYS and out["is_corr"] == 1.0
+    assert out["gpu_answer_us"] > 0
