@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--nu2", type=int, default=7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
+    ap.add_argument("--overlap", type=int, default=0, help="1: Regev->GSW conversion on a side stream under the sweep (measured slower: the sweep loses "
+                    "more to the contention, 349 -> 422 us, than the 30 us of conversion it hides); 0: everything in order on one stream")
     ap.add_argument("--root-fold", action="store_true", help="N > 1: plain reduce to rank 0, which lifts and folds alone")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the reduce even with one rank (self-test)")
     args = ap.parse_args()
@@ -128,6 +130,7 @@ def main():
     else:
         sharded_fold = False
     srv.use_graphs(not args.no_graphs)  # expand+convert and lift+fold+finish replay as two hipGraphs
+    srv.set_overlap(bool(args.overlap))
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
 
@@ -172,6 +175,7 @@ def main():
         # untimed: the reference's stage buckets (src/spiral.cpp:246-257) from one eager pass with HIP events
         detail = None
         if world == 1:
+            srv.set_overlap(False)
             srv.use_graphs(False)
             detail = srv.answer_resident()
             detail = srv.answer_resident()
@@ -198,7 +202,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": "configs[1]: Base Spiral 2^20 x 256B (nu1=8, nu2=7, p=256, t_GSW=8, t_conv=4, t_exp=8, t_exp_right=56, q'=2^20), "
                                "explicit DB generated on device, sharded by first-dimension index",
-                   "db_bytes_ntt_form": int(shp.dim0) * int(shp.num_per) * 4 * sa.N * 8, "parallelism": (f"j-shard x{world}, reduce-scatter + distributed fold + all-gather" if sharded_fold else f"j-shard x{world} + 1 reduce")},
+                   "db_bytes_ntt_form": int(shp.dim0) * int(shp.num_per) * 4 * sa.N * 8, "schedule": "GSW conversion overlapped with the sweep (side stream)" if args.overlap else "in order, one stream",
+                   "parallelism": (f"j-shard x{world}, reduce-scatter + distributed fold + all-gather" if sharded_fold else f"j-shard x{world} + 1 reduce")},
         "queries_per_s": round(1e3 / ms_per_step, 2),
         "stages_us": {k: round(v, 1) for k, v in stages.items()},
         "reference_buckets_us_eager": ({k: round(v, 1) for k, v in detail.items() if k != "scaltomat_us"} if detail else None),

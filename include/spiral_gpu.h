@@ -155,6 +155,10 @@ int spiral_gpu_server_sync(spiral_gpu_server *s);
  * server stream (which must not be the default stream) and replayed afterwards. */
 int spiral_gpu_server_use_graphs(spiral_gpu_server *s, int on);
 int spiral_gpu_server_run_pre(spiral_gpu_server *s);
+/* overlap mode: run_pre runs expansion + scalToMat on the server stream and forks the regevToGSW conversion (whose
+ * keys only the folding reads) onto an internal side stream, so that it executes under the HBM-bound first-dimension
+ * sweep; fold / fold_local / fold_root / run_post / sync join it.  Results are identical, only the schedule changes. */
+int spiral_gpu_server_set_overlap(spiral_gpu_server *s, int on);
 int spiral_gpu_server_run_post(spiral_gpu_server *s, int reduce_first);
 /* per-shard first-dimension accumulators: num_per*n1*n2*2048 packed words (p-limb | b-limb << 32, each
  * field < 2^28).  Summing the shards' buffers as uint64 (one RCCL reduce) and calling lift with

@@ -31,7 +31,12 @@ struct spiral_gpu_server {
     // captured stage groups (hipGraph): [0] expand + convert, [1] lift + fold + finish, [2] the same with
     // reduce_first; instantiated lazily, invalidated when a captured pointer or flag changes
     bool use_graphs = false;
-    hipGraphExec_t graph[3] = {nullptr, nullptr, nullptr};
+    hipGraphExec_t graph[4] = {nullptr, nullptr, nullptr, nullptr};  // [3] = Regev->GSW conversion on the side stream
+    // overlap mode: run_pre forks the Regev->GSW conversion (needed only by the folding) onto side_stream so that it
+    // runs under the HBM-bound sweep; the fold entry points join it
+    bool overlap = false, side_pending = false;
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint32_t fold_g_log = 0;  // distributed fold over 2^fold_g_log ranks: the sweep groups its output by ii mod G
 };
 
@@ -88,7 +93,19 @@ void srv_free(spiral_gpu_server* S) {
     for (DevBuf* b : all) b->release();
     for (auto& e : S->ev)
         if (e) (void)hipEventDestroy(e);
+    if (S->ev_fork) (void)hipEventDestroy(S->ev_fork);
+    if (S->ev_join) (void)hipEventDestroy(S->ev_join);
+    if (S->side_stream) (void)hipStreamDestroy(S->side_stream);
     if (S->own_stream) (void)hipStreamDestroy(S->own_stream);
+}
+
+// the fold needs the keys the forked conversion produces
+int srv_join_side(spiral_gpu_server* S) {
+    if (S->side_pending) {
+        HIP_OK(hipStreamWaitEvent(S->stream, S->ev_join, 0));
+        S->side_pending = false;
+    }
+    return 0;
 }
 
 // stage a host buffer through a device staging area and convert reference NTT layout -> PK
@@ -622,13 +639,13 @@ int spiral_gpu_server_expand(spiral_gpu_server* S) {
     return 0;
 }
 
-int spiral_gpu_server_convert(spiral_gpu_server* S) {
-    if (!S) return fail("null server");
+}  // extern "C"
+
+namespace {
+// scalToMat for this shard's first-dimension ciphertexts (src/spiral.cpp:2230-2253)
+int convert_scal2mat(spiral_gpu_server* S, hipStream_t st) {
     const spiral_gpu_params& p = S->p;
-    const spiral_gpu_shape& s = S->s;
-    hipStream_t st = S->stream;
     const uint32_t ps = S->pos_stride;
-    // ---- scalToMat for this shard's first-dimension ciphertexts (src/spiral.cpp:2230-2253)
     {
         InvParams ip{};
         ip.src = S->cv.p;
@@ -656,8 +673,14 @@ int spiral_gpu_server_convert(spiral_gpu_server* S) {
         sp.j_base = 0;
         launch_scal2mat(sp, st);
     }
-    if (!S->use_graphs) HIP_OK(hipEventRecord(S->ev[7], st));  // ScalToMat | RegevToGSW split of the reference summary
-    // ---- regevToGSW for the nu2 further dimensions + fold keys (src/spiral.cpp:2315-2331, 2361-2386)
+    return 0;
+}
+
+// regevToGSW for the nu2 further dimensions + fold keys (src/spiral.cpp:2315-2331, 2361-2386)
+int convert_gsw(spiral_gpu_server* S, hipStream_t st) {
+    const spiral_gpu_params& p = S->p;
+    const spiral_gpu_shape& s = S->s;
+    const uint32_t ps = S->pos_stride;
     if (p.nu2) {
         const uint32_t ngs = p.nu2 * s.ell;
         InvParams ip{};
@@ -686,6 +709,30 @@ int spiral_gpu_server_convert(spiral_gpu_server* S) {
         launch_regev_to_gsw(gp, st);
         launch_fold_key(S->gsw.p, S->key.p, p.nu2, s.ell, st);
     }
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int spiral_gpu_server_convert(spiral_gpu_server* S) {
+    if (!S) return fail("null server");
+    if (convert_scal2mat(S, S->stream)) return -1;
+    if (!S->use_graphs) HIP_OK(hipEventRecord(S->ev[7], S->stream));  // ScalToMat | RegevToGSW split of the reference summary
+    return convert_gsw(S, S->stream);
+}
+
+int spiral_gpu_server_set_overlap(spiral_gpu_server* S, int on) {
+    if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
+    if (on && !S->side_stream) {
+        HIP_OK(hipStreamCreateWithFlags(&S->side_stream, hipStreamNonBlocking));
+        HIP_OK(hipEventCreateWithFlags(&S->ev_fork, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&S->ev_join, hipEventDisableTiming));
+    }
+    if (srv_join_side(S)) return -1;
+    S->overlap = on != 0;
+    srv_drop_graphs(S);
     return 0;
 }
 
@@ -741,6 +788,7 @@ int spiral_gpu_server_finish(spiral_gpu_server* S);
 
 int spiral_gpu_server_fold(spiral_gpu_server* S) {
     if (!S) return fail("null server");
+    if (srv_join_side(S)) return -1;  // no-op inside run_post's capture: run_post joined before capturing
     run_fold_rounds(S, S->s.num_per, 0, S->p.nu2);  // src/spiral.cpp:1622-1626
     return 0;
 }
@@ -756,6 +804,7 @@ int spiral_gpu_server_set_fold_ranks(spiral_gpu_server* S, uint32_t n_ranks) {
 int spiral_gpu_server_fold_local(spiral_gpu_server* S, const void* acc_chunk, void* out_ct) {
     if (!S || !acc_chunk || !out_ct) return fail("null argument");
     const uint32_t L = S->s.num_per >> S->fold_g_log;
+    if (srv_join_side(S)) return -1;
     InvParams ip{};
     ip.src = (const uint64_t*)acc_chunk;
     ip.dst = S->raw.p;
@@ -770,6 +819,7 @@ int spiral_gpu_server_fold_local(spiral_gpu_server* S, const void* acc_chunk, vo
 int spiral_gpu_server_fold_root(spiral_gpu_server* S, const void* gathered_cts) {
     if (!S || !gathered_cts) return fail("null argument");
     const uint32_t G = 1u << S->fold_g_log;
+    if (srv_join_side(S)) return -1;
     HIP_OK(hipMemcpyAsync(S->raw.p, gathered_cts, (size_t)G * 6 * kPolyBytes, hipMemcpyDeviceToDevice, S->stream));
     run_fold_rounds(S, G, S->p.nu2 - S->fold_g_log, S->fold_g_log);
     return spiral_gpu_server_finish(S);
@@ -785,6 +835,7 @@ int spiral_gpu_server_finish(spiral_gpu_server* S) {
 
 int spiral_gpu_server_sync(spiral_gpu_server* S) {
     if (!S) return fail("null server");
+    if (srv_join_side(S)) return -1;
     HIP_OK(hipStreamSynchronize(S->stream));
     HIP_OK(hipGetLastError());
     return 0;
@@ -808,14 +859,14 @@ int spiral_gpu_server_set_acc(spiral_gpu_server* S, void* device_ptr) {
 namespace {
 // run `body` (kernel launches on S->stream) directly, or capture it once into a hipGraph and replay it
 template <class F>
-int run_group(spiral_gpu_server* S, int slot, F body) {
+int run_group(spiral_gpu_server* S, int slot, hipStream_t st, F body) {
     if (!S->use_graphs) return body();
     if (!S->graph[slot]) {
-        if (S->stream == nullptr) return fail("graph capture needs a non-default stream");
-        HIP_OK(hipStreamBeginCapture(S->stream, hipStreamCaptureModeRelaxed));
+        if (st == nullptr) return fail("graph capture needs a non-default stream");
+        HIP_OK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
         int rc = body();
         hipGraph_t g = nullptr;
-        hipError_t e = hipStreamEndCapture(S->stream, &g);
+        hipError_t e = hipStreamEndCapture(st, &g);
         if (rc) {
             if (g) (void)hipGraphDestroy(g);
             return rc;
@@ -825,7 +876,7 @@ int run_group(spiral_gpu_server* S, int slot, F body) {
         (void)hipGraphDestroy(g);
         if (e != hipSuccess) return fail("hipGraphInstantiate failed: %s", hipGetErrorString(e));
     }
-    HIP_OK(hipGraphLaunch(S->graph[slot], S->stream));
+    HIP_OK(hipGraphLaunch(S->graph[slot], st));
     return 0;
 }
 }  // namespace
@@ -835,15 +886,31 @@ extern "C" {
 int spiral_gpu_server_run_pre(spiral_gpu_server* S) {
     if (!S) return fail("null server");
     if (!S->have_query || !S->have_pp) return fail("query and public parameters must be set first");
-    return run_group(S, 0, [&]() {
-        if (spiral_gpu_server_expand(S)) return -1;
-        return spiral_gpu_server_convert(S);
-    });
+    if (!S->overlap)
+        return run_group(S, 0, S->stream, [&]() {
+            if (spiral_gpu_server_expand(S)) return -1;
+            return spiral_gpu_server_convert(S);
+        });
+    // overlap mode: expansion + ScalToMat on the main stream (the sweep needs only these); the Regev->GSW conversion
+    // is forked onto the side stream and joined by the fold
+    if (srv_join_side(S)) return -1;
+    if (run_group(S, 0, S->stream, [&]() {
+            if (spiral_gpu_server_expand(S)) return -1;
+            return convert_scal2mat(S, S->stream);
+        }))
+        return -1;
+    HIP_OK(hipEventRecord(S->ev_fork, S->stream));
+    HIP_OK(hipStreamWaitEvent(S->side_stream, S->ev_fork, 0));
+    if (run_group(S, 3, S->side_stream, [&]() { return convert_gsw(S, S->side_stream); })) return -1;
+    HIP_OK(hipEventRecord(S->ev_join, S->side_stream));
+    S->side_pending = true;
+    return 0;
 }
 
 int spiral_gpu_server_run_post(spiral_gpu_server* S, int reduce_first) {
     if (!S) return fail("null server");
-    return run_group(S, reduce_first ? 2 : 1, [&]() {
+    if (srv_join_side(S)) return -1;
+    return run_group(S, reduce_first ? 2 : 1, S->stream, [&]() {
         if (spiral_gpu_server_lift(S, reduce_first)) return -1;
         if (spiral_gpu_server_fold(S)) return -1;
         return spiral_gpu_server_finish(S);

@@ -83,6 +83,10 @@ class Server:
     def use_graphs(self, on: bool = True):
         check(lib().spiral_gpu_server_use_graphs(self.h, 1 if on else 0))
 
+    def set_overlap(self, on: bool = True):
+        """run the Regev->GSW conversion on a side stream under the sweep (same results, different schedule)"""
+        check(lib().spiral_gpu_server_set_overlap(self.h, 1 if on else 0))
+
     def run_pre(self):
         """expand + convert (one hipGraph replay when graphs are on)"""
         check(lib().spiral_gpu_server_run_pre(self.h))

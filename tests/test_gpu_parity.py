@@ -266,8 +266,10 @@ def test_answer_and_device_db(sa, oracle, nu1, nu2, kw):
     srv.close()
 
 
-def test_graph_replay_matches_eager(sa, oracle):
-    """run_pre / run_post captured into hipGraphs and replayed for several queries == the eager stages"""
+@pytest.mark.parametrize("graphs,overlap", [(True, False), (True, True), (False, True)])
+def test_graph_replay_matches_eager(sa, oracle, graphs, overlap):
+    """run_pre / run_post captured into hipGraphs and replayed for several queries == the eager stages; in overlap
+    mode the Regev->GSW conversion runs on the side stream under the sweep and the fold joins it"""
     O = oracle
     from spiral_amd import server as SV
 
@@ -279,7 +281,8 @@ def test_graph_replay_matches_eager(sa, oracle):
     srv.gen_db(8)
     srv.set_pub_params(wl, wr, w, v)
     db = O.gen_db(po, 8)
-    srv.use_graphs(True)
+    srv.use_graphs(graphs)
+    srv.set_overlap(overlap)
     for idx in (3, 100, 127, 3):
         q = cl.query(idx)
         srv.set_query(q)
