@@ -160,6 +160,9 @@ int spiral_gpu_server_run_pre(spiral_gpu_server *s);
  * sweep; fold / fold_local / fold_root / run_post / sync join it.  Results are identical, only the schedule changes. */
 int spiral_gpu_server_set_overlap(spiral_gpu_server *s, int on);
 int spiral_gpu_server_run_post(spiral_gpu_server *s, int reduce_first);
+/* the whole single-GPU answer (run_pre, first_dim, run_post(0)) as one group: with use_graphs on, one hipGraph launch
+ * per query and no host-visible seam between the stages */
+int spiral_gpu_server_run_query(spiral_gpu_server *s);
 /* per-shard first-dimension accumulators: num_per*n1*n2*2048 packed words (p-limb | b-limb << 32, each
  * field < 2^28).  Summing the shards' buffers as uint64 (one RCCL reduce) and calling lift with
  * reduce_first = 1 gives the unsharded result.  Returns a device pointer. */

@@ -124,8 +124,8 @@ inline int current_tables(DeviceTables* t) {
 
 // ---- expansion on PK buffers, shared by the seam and the resident server ---------------------------------
 struct ExpandWork {
-    uint64_t* raw;  // [2^g][2] RAW
-    uint64_t* g;    // per active ct: t digits + NTT(c'_1), PK
+    uint64_t* raw;  // per active ct a: [2a] = c_0 RAW, [2a + 1] = NTT(automorph(c_1)) PK
+    uint64_t* g;    // per active ct: t digit polynomials, PK
 };
 inline size_t expand_g_polys(uint32_t g, uint32_t t_exp, uint32_t t_exp_right) {
     size_t half = (size_t)1 << (g ? g - 1 : 0);  // at most 2^(g-1) active cts per parity
@@ -142,8 +142,8 @@ inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_
         uint32_t cnt_even = num_in, cnt_odd = num_in;
         if (stopround > 0 && r > stopround) cnt_odd = 0;
         if (stopround > 0 && r == stopround) cnt_odd = std::min(num_in, max_bits_right + 1);
-        // 1) INTT + CRT of every active ct (both parities); cts with i >= num_in are first created as
-        //    neg1 * cv[i - num_in] (:1709) inside the same kernel
+        // 1) INTT + CRT of row 0 and the automorphed row 1 (a slot permutation) of every active ct, both parities;
+        //    cts with i >= num_in are first created as neg1 * cv[i - num_in] (:1709) inside the same kernel
         const uint32_t cnt = cnt_even + cnt_odd;
         InvParams ip{};
         ip.dst = wk.raw;
@@ -152,8 +152,9 @@ inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_
         ip.neg1 = tb.neg1 + (size_t)r * kN;
         ip.num_in = num_in;
         ip.cnt_e = cnt_even;
+        ip.auto_t = t;
         launch_ntt_inverse_expand(tb, ip, 2 * cnt, st);
-        // 2) G^-1(automorph(c)[0]) digits (t_exp / t_exp_right per ct) and NTT(automorph(c)[1]), one launch
+        // 2) G^-1(automorph(c)[0]) digits (t_exp / t_exp_right per ct), one launch
         FwdParams fp{};
         fp.src = wk.raw;
         fp.dst = wk.g;
@@ -163,13 +164,14 @@ inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_
         fp.cnt_e = cnt_even;
         fp.t_e = t_exp;
         fp.t_o = t_exp_right;
-        launch_ntt_forward(tb, fp, LD_EXPAND, ST_PK, cnt_even * (t_exp + 1) + cnt_odd * (t_exp_right + 1), st);
+        launch_ntt_forward(tb, fp, LD_EXPAND, ST_PK, cnt_even * t_exp + cnt_odd * t_exp_right, st);
         // 3) cv[i] += W * digits + (0, NTT(c'_1))
         ExpandMacParams mp{};
         mp.cv = cv;
         mp.w_e = w_left + (size_t)r * 2 * t_exp * kN;
         mp.w_o = w_right + (size_t)r * 2 * t_exp_right * kN;  // never dereferenced when cnt_odd == 0
         mp.g = wk.g;
+        mp.a1 = wk.raw;
         mp.cnt_e = cnt_even;
         mp.cnt_o = cnt_odd;
         mp.t_e = t_exp;

@@ -61,7 +61,7 @@ struct FwdParams {
     // LD_DBGEN1: trial and total item count
     uint32_t trial;
     uint64_t total_n;
-    // LD_EXPAND: active ct a < cnt_e is even (t_e digits), the rest odd (t_o digits); jobs per ct = t + 1
+    // LD_EXPAND: active ct a < cnt_e is even (t_e digits), the rest odd (t_o digits); jobs per ct = t
     uint32_t cnt_e, t_e, t_o;
     // LD_DBGEN / ST_DB
     uint64_t seed, p_db;
@@ -83,12 +83,24 @@ struct InvParams {
     uint32_t src_ref;     // 1: source is reference layout [2][N] u64 instead of PK
     // expansion round (launch_ntt_inverse_expand): block b = (active ct a, row); a < cnt_e -> i = 2a, else
     // i = 2(a - cnt_e) + 1; a ct with i >= num_in is first created as neg1 * cv[i - num_in] (src/spiral.cpp:1709)
+    // Row 0 is transformed to dst[2a]; row 1 is not: its automorphed image, a slot permutation, goes to dst[2a + 1] in PK.
     uint64_t* cv;
     const uint64_t* neg1;
     uint32_t num_in, cnt_e;
+    uint32_t auto_t;  // the round's automorphism x -> x^t
 };
 void launch_ntt_inverse(const DeviceTables& t, const InvParams& p, uint32_t store, uint32_t nblocks, hipStream_t s);
 void launch_ntt_inverse_expand(const DeviceTables& t, const InvParams& p, uint32_t nblocks, hipStream_t s);
+
+// fold chain (ntt.hip): PK polynomials [2*np][3][2] -> inverse transform, CRT lift, balanced digits, forward transforms
+// into the fold operand layout D (as LD_SDIGIT); loop = one workgroup per polynomial, else one per (polynomial, digit)
+struct FoldChainParams {
+    const uint64_t* src;
+    uint64_t* dst;
+    uint32_t ell, bits, fold_np;
+    uint32_t pre_reduce;  // 1: fields are lazy sums (< 2^32), reduce mod m first
+};
+void launch_fold_chain(const DeviceTables& t, const FoldChainParams& p, uint32_t n_src, bool loop, hipStream_t s);
 
 // ---- layout conversion at the C-ABI boundary -------------------------------------------------------
 // reference polynomial b <-> packed polynomial pk_map(b)
@@ -125,12 +137,13 @@ void launch_mul_neg1(uint64_t* cv, const uint64_t* neg1_r, uint32_t src0, uint32
 void launch_expand_mac(uint64_t* cv, const uint64_t* w, const uint64_t* g, const uint64_t* a1, uint32_t t_dim, uint32_t i0, uint32_t step,
                        uint32_t count, hipStream_t s);
 // the same for a whole round in one launch: active ct a < cnt_e even (W_left, t_e digits) else odd (W_right, t_o);
-// g holds t+1 polynomials per ct (digits, then NTT(c'_1)) in LD_EXPAND job order
+// g holds t digit polynomials per ct in LD_EXPAND job order; a1[2a + 1] is NTT(automorph(c_1)) of active ct a
 struct ExpandMacParams {
     uint64_t* cv;
     const uint64_t* w_e;
     const uint64_t* w_o;
     const uint64_t* g;
+    const uint64_t* a1;
     uint32_t cnt_e, cnt_o, t_e, t_o;
 };
 void launch_expand_mac_round(const ExpandMacParams& p, hipStream_t s);

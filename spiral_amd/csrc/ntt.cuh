@@ -155,6 +155,25 @@ __device__ __forceinline__ void ct_radix4x2_pre(uint32_t* lo, uint32_t* hi, cons
     for (int q = 0; q < 4; q++) ct2(lo, hi, 2 * q, 2 * q + 1, w.t[3 + q]);
 }
 
+__device__ __forceinline__ void gs_radix8_pre(uint32_t* lo, uint32_t* hi, const Tw7& w) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) gs2(lo, hi, 2 * q, 2 * q + 1, w.t[3 + q]);
+    gs2(lo, hi, 0, 2, w.t[1]);
+    gs2(lo, hi, 1, 3, w.t[1]);
+    gs2(lo, hi, 4, 6, w.t[2]);
+    gs2(lo, hi, 5, 7, w.t[2]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) gs2(lo, hi, k, k + 4, w.t[0]);
+}
+__device__ __forceinline__ void gs_radix4x2_pre(uint32_t* lo, uint32_t* hi, const Tw7& w) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) gs2(lo, hi, 2 * q, 2 * q + 1, w.t[3 + q]);
+    gs2(lo, hi, 0, 2, w.t[1]);
+    gs2(lo, hi, 1, 3, w.t[1]);
+    gs2(lo, hi, 4, 6, w.t[2]);
+    gs2(lo, hi, 5, 7, w.t[2]);
+}
+
 // ---- LDS tile -----------------------------------------------------------------------------------
 // 2048 packed coefficients; +4 words of padding per 32 keeps the stride-32 and stride-8 access
 // patterns of passes C and D off a single bank
@@ -247,6 +266,31 @@ __device__ __forceinline__ void ntt_forward_block(uint32_t* lo, uint32_t* hi, ui
 // out (lo,hi)[k] <-> coefficient ix_a(tid,k) = tid + 256k, canonical in [0, m).
 // Bounds: sum side < 2m + 11 * m/2 = 7.5m, product side < 2m: every t = u + 8m - v is in (0, 15.5m).
 __device__ __forceinline__ void ntt_inverse_block(uint32_t* lo, uint32_t* hi, uint64_t* sh, const uint4* tw, uint32_t tid) {
+#ifndef NTT_NO_PREFETCH_TW  // as in the forward transform: the next pass's twiddles are in flight during the current pass
+    Tw7 wd = tw_load4x2(tw, 512 + 2 * tid, 1024 + 4 * tid);
+    Tw7 wc = tw_load8(tw, 64 + (tid >> 2), 128 + 2 * (tid >> 2), 256 + 4 * (tid >> 2));
+    gs_radix4x2_pre(lo, hi, wd);
+    lds_put<ix_d>(sh, tid, lo, hi);
+    __syncthreads();
+    lds_get<ix_c>(sh, tid, lo, hi);
+    Tw7 wb = tw_load8(tw, 8 + (tid >> 5), 16 + 2 * (tid >> 5), 32 + 4 * (tid >> 5));
+    gs_radix8_pre(lo, hi, wc);
+    lds_put<ix_c>(sh, tid, lo, hi);
+    __syncthreads();
+    lds_get<ix_b>(sh, tid, lo, hi);
+    Tw7 wa = tw_load8(tw, 1, 2, 4);
+    gs_radix8_pre(lo, hi, wb);
+    lds_put<ix_b>(sh, tid, lo, hi);
+    __syncthreads();
+    lds_get<ix_a>(sh, tid, lo, hi);
+    gs_radix8_pre(lo, hi, wa);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        lo[k] = csub(lazy_reduce(lo[k], kP), kP);
+        hi[k] = csub(lazy_reduce(hi[k], kB), kB);
+    }
+    return;
+#endif
     gs_radix4x2(lo, hi, tw, 512 + 2 * tid, 1024 + 4 * tid);
     lds_put<ix_d>(sh, tid, lo, hi);
     __syncthreads();

@@ -114,36 +114,28 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
             hi[r] = digit_residue(d, kB);
         }
     } else if constexpr (LOAD == LD_EXPAND) {
-        // job b -> (active ct a, k); k < tdim: digit k of automorph(c)[0]; k == tdim: automorph(c)[1] reduced
-        const uint32_t je = p.cnt_e * (p.t_e + 1u);
+        // job b -> (active ct a, digit k of automorph(c)[0])
+        const uint32_t je = p.cnt_e * p.t_e;
         uint32_t a, tdim;
         if (b < je) {
             tdim = p.t_e;
-            a = b / (tdim + 1u);
-            k = b - a * (tdim + 1u);
+            a = b / tdim;
+            k = b - a * tdim;
         } else {
             tdim = p.t_o;
             const uint32_t bb = b - je;
-            a = bb / (tdim + 1u);
-            k = bb - a * (tdim + 1u);
+            a = bb / tdim;
+            k = bb - a * tdim;
             a += p.cnt_e;
         }
-        const bool is_digit = k < tdim;
-        const uint64_t* src = p.src + ((size_t)a * 2u + (is_digit ? 0u : 1u)) * kN;
+        const uint64_t* src = p.src + (size_t)a * 2u * kN;
         const uint32_t bits = get_bits_per(tdim);
         const uint64_t mask = (1ull << bits) - 1;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            uint32_t idx = ix_a(tid, r);
-            uint64_t v = load_raw(src, idx, p.tinv);
-            if (is_digit) {
-                uint32_t d = (uint32_t)digit_of(v, k, bits, mask);
-                lo[r] = digit_residue(d, kP);
-                hi[r] = digit_residue(d, kB);
-            } else {
-                lo[r] = mod_p(v);
-                hi[r] = mod_b(v);
-            }
+            const uint32_t d = (uint32_t)digit_of(load_raw(src, ix_a(tid, r), p.tinv), k, bits, mask);
+            lo[r] = digit_residue(d, kP);
+            hi[r] = digit_residue(d, kB);
         }
         s = b;
     } else if constexpr (LOAD == LD_LIMBS) {
@@ -237,25 +229,44 @@ __global__ __launch_bounds__(256) void ntt_inverse_kernel(Tables t, InvParams p)
     if constexpr (EXPAND) {
         const uint32_t a = b >> 1, row = b & 1u;
         const uint32_t i = a < p.cnt_e ? 2u * a : 2u * (a - p.cnt_e) + 1u;
-        if (i >= p.num_in) {  // cv[i] = neg1 * cv[i - num_in], created here and transformed in the same pass
-            const uint64_t* src = p.cv + ((size_t)(i - p.num_in) * 2u + row) * kN + tid;
+        const bool created = i >= p.num_in;  // cv[i] = neg1 * cv[i - num_in], created here (src/spiral.cpp:1709)
+        const uint64_t* src = p.cv + ((size_t)(created ? i - p.num_in : i) * 2u + row) * kN;
+        if (created) {
             const uint64_t* ng = p.neg1 + tid;
             uint64_t* dstc = p.cv + ((size_t)i * 2u + row) * kN + tid;
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                const uint64_t v = src[r * 256], w = ng[r * 256];
+                const uint64_t v = src[r * 256 + tid], w = ng[r * 256];
                 lo[r] = mod_p((uint64_t)lo32(v) * lo32(w));
                 hi[r] = mod_b((uint64_t)hi32(v) * hi32(w));
                 dstc[r * 256] = pack(lo[r], hi[r]);
             }
-        } else {
-            const uint64_t* src = p.cv + ((size_t)i * 2u + row) * kN + tid;
+        } else if (row == 0) {
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                const uint64_t v = src[r * 256];
+                const uint64_t v = src[r * 256 + tid];
                 lo[r] = lo32(v);
                 hi[r] = hi32(v);
             }
+        }
+        if (row == 1) {
+            // Row 1 only needs NTT(automorph(c_1)), and in the transform domain the automorphism x -> x^t is a slot
+            // permutation: slot s evaluates at psi^(2 brev(s) + 1), so out[s] = in[s'] with 2 brev(s') + 1 =
+            // (2 brev(s) + 1) t mod 2N.  The residues are the same canonical values the reference gets by going
+            // through the coefficient domain (src/spiral.cpp:1713-1720), without the two transforms.
+            uint64_t* out = p.dst + (size_t)b * kN + tid;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t e = ((2u * (__brev(8u * tid + r) >> 21) + 1u) * p.auto_t) & (2u * kN - 1u);
+                const uint32_t pp = pk_pos(__brev(e >> 1) >> 21);
+                uint64_t v = src[pp];
+                if (created) {
+                    const uint64_t w = p.neg1[pp];
+                    v = pack(mod_p((uint64_t)lo32(v) * lo32(w)), mod_b((uint64_t)hi32(v) * hi32(w)));
+                }
+                out[r * 256] = v;
+            }
+            return;
         }
     } else if (p.src_ref) {
         const uint64_t* src = p.src + (size_t)p.src_map(b) * (2 * kN) + 8u * tid;
@@ -292,6 +303,54 @@ __global__ __launch_bounds__(256) void ntt_inverse_kernel(Tables t, InvParams p)
             dst[ix_a(tid, r)] = lo[r];
             dst[kN + ix_a(tid, r)] = hi[r];
         }
+    }
+}
+
+// Fold chain: the inverse transform + CRT lift of a PK polynomial (a first-dimension accumulator, or the previous fold
+// round's product) followed in registers by the balanced digits and forward transforms the next fold round consumes
+// (nttInvAndCrtLiftCiphertexts / from_ntt then split_and_crt, src/spiral.cpp:1349-1410, 270-330).  The inverse leaves
+// coefficient tid + 256k in register k, which is exactly what the forward transform wants, so nothing is exchanged and
+// the raw polynomial never goes to memory.  LOOP: one workgroup per source polynomial, all ell digits in turn (no
+// redundant work: for rounds that fill the chip); otherwise one workgroup per (polynomial, digit), each repeating the
+// inverse transform (the small late rounds, which are latency-bound: one launch less per round).
+template <bool LOOP>
+__global__ __launch_bounds__(256) void fold_chain_kernel(Tables t, FoldChainParams p) {
+    __shared__ uint64_t sh[kLdsWords];
+    const uint32_t tid = threadIdx.x, b = blockIdx.x;
+    const uint32_t s = LOOP ? b : b / p.ell;
+    uint32_t lo[8], hi[8];
+    {
+        const uint64_t* src = p.src + (size_t)s * kN + tid;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint64_t v = src[r * 256];
+            lo[r] = lo32(v);
+            hi[r] = hi32(v);
+        }
+    }
+    if (p.pre_reduce) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            lo[r] %= kP;
+            hi[r] %= kB;
+        }
+    }
+    ntt_inverse_block(lo, hi, sh, t.inv, tid);
+    uint64_t v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = crt_compose(lo[r], hi[r]);
+    // source s = (ct i', r, c) over [2*np][3][2]; operand layout D[i' % np][(i' / np)*m2 + r + 3k][c]  (as LD_SDIGIT)
+    const uint32_t ct = s / 6u, rc = s - ct * 6u, row = rc >> 1, c = rc & 1u;
+    const uint32_t m2 = 3u * p.ell, hi_half = ct / p.fold_np, i = ct - hi_half * p.fold_np;
+    const uint32_t k0 = LOOP ? 0u : b - s * p.ell, k1 = LOOP ? p.ell : k0 + 1u;
+    for (uint32_t k = k0; k < k1; k++) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) sdigit_of(v[r], k, p.bits, p.ell, lo[r], hi[r]);
+        if (LOOP && k > k0) __syncthreads();  // the previous transform's last LDS reads
+        ntt_forward_block(lo, hi, sh, t.fwd, tid);
+        uint64_t* dst = p.dst + (size_t)(((i * 2u + hi_half) * m2 + row + 3u * k) * 2u + c) * kN + tid;
+#pragma unroll
+        for (int r = 0; r < 8; r++) dst[r * 256] = pack(lo[r], hi[r]);
     }
 }
 
@@ -344,6 +403,15 @@ void launch_ntt_inverse(const DeviceTables& t, const InvParams& p, uint32_t stor
         hipLaunchKernelGGL((ntt_inverse_kernel<IST_CRT>), dim3(nblocks), dim3(256), 0, s, tb, p);
     else
         hipLaunchKernelGGL((ntt_inverse_kernel<IST_LIMBS>), dim3(nblocks), dim3(256), 0, s, tb, p);
+}
+
+void launch_fold_chain(const DeviceTables& t, const FoldChainParams& p, uint32_t n_src, bool loop, hipStream_t s) {
+    if (n_src == 0) return;
+    Tables tb{t.fwd, t.inv};
+    if (loop)
+        hipLaunchKernelGGL((fold_chain_kernel<true>), dim3(n_src), dim3(256), 0, s, tb, p);
+    else
+        hipLaunchKernelGGL((fold_chain_kernel<false>), dim3(n_src * p.ell), dim3(256), 0, s, tb, p);
 }
 
 void launch_ref_to_pk(const uint64_t* ref, uint64_t* pk, uint32_t npolys, IndexMap pk_map, hipStream_t s) {

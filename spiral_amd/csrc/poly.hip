@@ -51,7 +51,7 @@ __global__ __launch_bounds__(kTpb) void fold_mac_kernel(FoldMacParams p) {
     const uint64_t* dp = p.d + (size_t)i * p.K * 2 * kN + z;
     const uint64_t* kp = p.key + z;
     Acc2 acc[3][2];
-#pragma unroll 2
+#pragma unroll 4
     for (uint32_t mm = kg; mm < p.K; mm += 4) {
         const uint64_t d0 = dp[(size_t)(2 * mm) * kN], d1 = dp[(size_t)(2 * mm + 1) * kN];
 #pragma unroll
@@ -219,11 +219,11 @@ __global__ __launch_bounds__(kTpb) void expand_mac_round_kernel(ExpandMacParams 
     const bool odd = a >= p.cnt_e;
     const uint32_t tdim = odd ? p.t_o : p.t_e;
     const uint32_t i = odd ? 2u * (a - p.cnt_e) + 1u : 2u * a;
-    const size_t gbase = odd ? (size_t)p.cnt_e * (p.t_e + 1u) + (size_t)(a - p.cnt_e) * (p.t_o + 1u) : (size_t)a * (p.t_e + 1u);
+    const size_t gbase = odd ? (size_t)p.cnt_e * p.t_e + (size_t)(a - p.cnt_e) * p.t_o : (size_t)a * p.t_e;
     const uint64_t* w = (odd ? p.w_o : p.w_e) + z;
     const uint64_t* gp = p.g + gbase * kN + z;
     Acc2 acc0, acc1;
-#pragma unroll 4
+#pragma unroll 7
     for (uint32_t k = kg; k < tdim; k += 4) {
         const uint64_t gv = gp[(size_t)k * kN];
         acc0.mac(w[(size_t)k * kN], gv);
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(kTpb) void expand_mac_round_kernel(ExpandMacParams 
         }
         uint64_t* c = p.cv + (size_t)i * 2 * kN + z;
         c[0] = add_pk(c[0], acc0.reduced());
-        c[kN] = add_pk(add_pk(c[kN], acc1.reduced()), gp[(size_t)tdim * kN]);
+        c[kN] = add_pk(add_pk(c[kN], acc1.reduced()), p.a1[((size_t)a * 2u + 1u) * kN + z]);
     }
 }
 void launch_expand_mac_round(const ExpandMacParams& p, hipStream_t s) {

@@ -31,12 +31,17 @@ struct spiral_gpu_server {
     // captured stage groups (hipGraph): [0] expand + convert, [1] lift + fold + finish, [2] the same with
     // reduce_first; instantiated lazily, invalidated when a captured pointer or flag changes
     bool use_graphs = false;
-    hipGraphExec_t graph[4] = {nullptr, nullptr, nullptr, nullptr};  // [3] = Regev->GSW conversion on the side stream
+    hipGraphExec_t graph[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [3] = Regev->GSW conversion on the side stream, [4] = whole query
     // overlap mode: run_pre forks the Regev->GSW conversion (needed only by the folding) onto side_stream so that it
     // runs under the HBM-bound sweep; the fold entry points join it
     bool overlap = false, side_pending = false;
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // fold chain (fold_chain_kernel): a round with n_src source polynomials runs one workgroup per (polynomial, digit)
+    // when n_src*ell <= fold_dmax, one per polynomial when n_src >= fold_lmin, and the separate lift + digit
+    // transforms otherwise.  SPIRAL_FOLD_CHAIN / SPIRAL_FOLD_DMAX / SPIRAL_FOLD_LMIN override (tuning only).
+    bool fold_chain = true;
+    uint32_t fold_dmax = 1024, fold_lmin = 0xffffffffu;
     uint32_t fold_g_log = 0;  // distributed fold over 2^fold_g_log ranks: the sweep groups its output by ii mod G
 };
 
@@ -491,6 +496,9 @@ int spiral_gpu_server_create(const spiral_gpu_params* p, int device, uint32_t j_
     S->j0 = j_begin;
     S->j1 = j_end;
     S->dim0_shard = j_end - j_begin;
+    if (const char* e = getenv("SPIRAL_FOLD_CHAIN")) S->fold_chain = atoi(e) != 0;
+    if (const char* e = getenv("SPIRAL_FOLD_DMAX")) S->fold_dmax = (uint32_t)strtoul(e, nullptr, 10);
+    if (const char* e = getenv("SPIRAL_FOLD_LMIN")) S->fold_lmin = (uint32_t)strtoul(e, nullptr, 10);
     if (p->direct_upload || s.stopround == 0) {
         S->pos_stride = 1;
         S->pos_first = 0;
@@ -757,28 +765,52 @@ int spiral_gpu_server_lift(spiral_gpu_server* S, int reduce_first) {
 }  // extern "C"
 
 namespace {
-// foldOneFurtherDimension rounds [d0, d0 + rounds) on the np0 ciphertexts at the head of S->raw (src/spiral.cpp:1349-1410)
-void run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t rounds) {
+// foldOneFurtherDimension rounds [d0, d0 + rounds) on np0 ciphertexts (src/spiral.cpp:1349-1410); the result is left
+// CRT-lifted at the head of S->raw.  src_pk == nullptr: the ciphertexts are already lifted in S->raw.  Otherwise they
+// are the PK polynomials [np0][3][2] at src_pk (accumulators, lazy sums when pre_reduce) and the lift is chained into
+// the digit transforms (fold_chain_kernel); later rounds chain from the previous round's product the same way.
+int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t rounds, const uint64_t* src_pk, bool pre_reduce) {
     const spiral_gpu_shape& s = S->s;
     uint32_t np = np0;
-    for (uint32_t d = d0; d < d0 + rounds; d++) {
-        np /= 2;
-        FwdParams fp{};
-        fp.src = S->raw.p;
-        fp.dst = S->fold_d.p;
-        fp.src_map = identity_map();
-        fp.n_digits = s.ell;
-        fp.bits = get_bits_per(s.ell);
-        fp.ell = s.ell;
-        fp.fold_np = np;
-        launch_ntt_forward(S->tb, fp, LD_SDIGIT, ST_PK, 2 * np * 6 * s.ell, S->stream);
-        launch_fold_mac(S->key.p + (size_t)d * 3 * 2 * s.m2 * kN, S->fold_d.p, S->fold_c.p, 2 * s.m2, np, S->stream);
+    auto lift = [&](uint32_t npolys) {
         InvParams ip{};
-        ip.src = S->fold_c.p;
+        ip.src = src_pk;
         ip.dst = S->raw.p;
         ip.src_map = ip.dst_map = identity_map();
-        launch_ntt_inverse(S->tb, ip, IST_CRT, np * 6, S->stream);
+        ip.pre_reduce = pre_reduce ? 1 : 0;
+        launch_ntt_inverse(S->tb, ip, IST_CRT, npolys, S->stream);
+        src_pk = nullptr;
+    };
+    for (uint32_t d = d0; d < d0 + rounds; d++) {
+        np /= 2;
+        const uint32_t n_src = 2 * np * 6;
+        if (src_pk && S->fold_chain && (n_src * s.ell <= S->fold_dmax || n_src >= S->fold_lmin)) {
+            FoldChainParams cp{};
+            cp.src = src_pk;
+            cp.dst = S->fold_d.p;
+            cp.ell = s.ell;
+            cp.bits = get_bits_per(s.ell);
+            cp.fold_np = np;
+            cp.pre_reduce = pre_reduce ? 1 : 0;
+            launch_fold_chain(S->tb, cp, n_src, n_src * s.ell > S->fold_dmax, S->stream);
+        } else {
+            if (src_pk) lift(n_src);
+            FwdParams fp{};
+            fp.src = S->raw.p;
+            fp.dst = S->fold_d.p;
+            fp.src_map = identity_map();
+            fp.n_digits = s.ell;
+            fp.bits = get_bits_per(s.ell);
+            fp.ell = s.ell;
+            fp.fold_np = np;
+            launch_ntt_forward(S->tb, fp, LD_SDIGIT, ST_PK, n_src * s.ell, S->stream);
+        }
+        launch_fold_mac(S->key.p + (size_t)d * 3 * 2 * s.m2 * kN, S->fold_d.p, S->fold_c.p, 2 * s.m2, np, S->stream);
+        src_pk = S->fold_c.p;
+        pre_reduce = false;
     }
+    if (src_pk) lift(np * 6);
+    return 0;
 }
 }  // namespace
 
@@ -789,8 +821,7 @@ int spiral_gpu_server_finish(spiral_gpu_server* S);
 int spiral_gpu_server_fold(spiral_gpu_server* S) {
     if (!S) return fail("null server");
     if (srv_join_side(S)) return -1;  // no-op inside run_post's capture: run_post joined before capturing
-    run_fold_rounds(S, S->s.num_per, 0, S->p.nu2);  // src/spiral.cpp:1622-1626
-    return 0;
+    return run_fold_rounds(S, S->s.num_per, 0, S->p.nu2, nullptr, false);  // src/spiral.cpp:1622-1626
 }
 
 int spiral_gpu_server_set_fold_ranks(spiral_gpu_server* S, uint32_t n_ranks) {
@@ -805,13 +836,7 @@ int spiral_gpu_server_fold_local(spiral_gpu_server* S, const void* acc_chunk, vo
     if (!S || !acc_chunk || !out_ct) return fail("null argument");
     const uint32_t L = S->s.num_per >> S->fold_g_log;
     if (srv_join_side(S)) return -1;
-    InvParams ip{};
-    ip.src = (const uint64_t*)acc_chunk;
-    ip.dst = S->raw.p;
-    ip.src_map = ip.dst_map = identity_map();
-    ip.pre_reduce = 1;
-    launch_ntt_inverse(S->tb, ip, IST_CRT, L * 6, S->stream);
-    run_fold_rounds(S, L, 0, S->p.nu2 - S->fold_g_log);
+    if (run_fold_rounds(S, L, 0, S->p.nu2 - S->fold_g_log, (const uint64_t*)acc_chunk, true)) return -1;
     HIP_OK(hipMemcpyAsync(out_ct, S->raw.p, 6 * kPolyBytes, hipMemcpyDeviceToDevice, S->stream));
     return 0;
 }
@@ -821,7 +846,7 @@ int spiral_gpu_server_fold_root(spiral_gpu_server* S, const void* gathered_cts) 
     const uint32_t G = 1u << S->fold_g_log;
     if (srv_join_side(S)) return -1;
     HIP_OK(hipMemcpyAsync(S->raw.p, gathered_cts, (size_t)G * 6 * kPolyBytes, hipMemcpyDeviceToDevice, S->stream));
-    run_fold_rounds(S, G, S->p.nu2 - S->fold_g_log, S->fold_g_log);
+    if (run_fold_rounds(S, G, S->p.nu2 - S->fold_g_log, S->fold_g_log, nullptr, false)) return -1;
     return spiral_gpu_server_finish(S);
 }
 
@@ -872,6 +897,10 @@ int run_group(spiral_gpu_server* S, int slot, hipStream_t st, F body) {
             return rc;
         }
         if (e != hipSuccess) return fail("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        if (const char* dot = getenv("SPIRAL_GRAPH_DOT")) {  // debugging aid: <prefix>.<slot>.dot
+            const std::string path = std::string(dot) + "." + std::to_string(slot) + ".dot";
+            (void)hipGraphDebugDotPrint(g, path.c_str(), 0);
+        }
         e = hipGraphInstantiate(&S->graph[slot], g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
         if (e != hipSuccess) return fail("hipGraphInstantiate failed: %s", hipGetErrorString(e));
@@ -907,12 +936,25 @@ int spiral_gpu_server_run_pre(spiral_gpu_server* S) {
     return 0;
 }
 
+int spiral_gpu_server_run_query(spiral_gpu_server* S) {
+    if (!S) return fail("null server");
+    if (!S->have_query || !S->have_pp) return fail("query and public parameters must be set first");
+    if (!S->have_db) return fail("no database loaded");
+    if (srv_join_side(S)) return -1;
+    return run_group(S, 4, S->stream, [&]() {
+        if (spiral_gpu_server_expand(S)) return -1;
+        if (spiral_gpu_server_convert(S)) return -1;
+        if (spiral_gpu_server_first_dim(S)) return -1;
+        if (run_fold_rounds(S, S->s.num_per, 0, S->p.nu2, S->acc, false)) return -1;
+        return spiral_gpu_server_finish(S);
+    });
+}
+
 int spiral_gpu_server_run_post(spiral_gpu_server* S, int reduce_first) {
     if (!S) return fail("null server");
     if (srv_join_side(S)) return -1;
     return run_group(S, reduce_first ? 2 : 1, S->stream, [&]() {
-        if (spiral_gpu_server_lift(S, reduce_first)) return -1;
-        if (spiral_gpu_server_fold(S)) return -1;
+        if (run_fold_rounds(S, S->s.num_per, 0, S->p.nu2, S->acc, reduce_first != 0)) return -1;  // lift chained into round 0
         return spiral_gpu_server_finish(S);
     });
 }

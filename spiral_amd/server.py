@@ -91,6 +91,10 @@ class Server:
         """expand + convert (one hipGraph replay when graphs are on)"""
         check(lib().spiral_gpu_server_run_pre(self.h))
 
+    def run_query(self):
+        """run_pre + first_dim + run_post as one group (one hipGraph replay when graphs are on); single GPU only"""
+        check(lib().spiral_gpu_server_run_query(self.h))
+
     def run_post(self, reduce_first: bool = False):
         """lift + fold + finish"""
         check(lib().spiral_gpu_server_run_post(self.h, 1 if reduce_first else 0))

@@ -294,6 +294,12 @@ def test_graph_replay_matches_eager(sa, oracle, graphs, overlap):
         assert_eq(cl.decode(srv.read(SV.BUF_RESPONSE)), O.db_item(po, 8, idx), "decoded plaintext")
     fin, resp, us = srv.answer(cl.query(5))  # answer() through the graphs too
     assert_eq(cl.decode(resp), O.db_item(po, 8, 5), "decoded plaintext via answer()")
+    for idx in (9, 64):  # the whole query as one group
+        q = cl.query(idx)
+        srv.set_query(q)
+        srv.run_query()
+        srv.sync()
+        assert_eq(srv.read(SV.BUF_FINAL), O.answer(po, q, wl, wr, w, v, db), f"run_query idx={idx}")
     srv.close()
 
 

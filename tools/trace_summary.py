@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Summarise a rocprofv3 --kernel-trace CSV: per-kernel totals per query and the timeline of the last query.
-usage: tools/trace_summary.py gpurun_out/<dir>/<name>_kernel_trace.csv [--timeline]"""
+"""Summarise a rocprofv3 --kernel-trace CSV: per-kernel totals and the timeline of one query.
+usage: tools/trace_summary.py gpurun_out/<dir>/<name>_kernel_trace.csv [--timeline] [--query K]
+The default query is the middle one of the trace: a steady-state step of bench.py's timed loop.  (The last two queries
+of a bench.py trace are the eager detail pass, whose hipEventRecords between stages show up as ~6 us gaps.)"""
 import csv
 import sys
 from collections import defaultdict
@@ -9,8 +11,8 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 sweeps = [i for i, r in enumerate(rows) if "sweep_kernel" in r["Kernel_Name"]]
 nq = len(sweeps)
-last = sweeps[-1]
-prev = sweeps[-2] if nq > 1 else 0
+which = int(sys.argv[sys.argv.index("--query") + 1]) if "--query" in sys.argv else nq // 2
+last = sweeps[which]
 # a query = from the kernel after the previous query's last rescale to this query's last rescale
 resc = [i for i, r in enumerate(rows) if "rescale" in r["Kernel_Name"]]
 start = max(i for i in resc if i < last) + 1
@@ -26,7 +28,7 @@ for r in q:
     tot[n][1] += d
     busy += d
 wall = (int(q[-1]["End_Timestamp"]) - t0) / 1e3
-print(f"queries in trace: {nq}; last query: {len(q)} launches, wall {wall:.1f} us, kernel-busy {busy:.1f} us")
+print(f"queries in trace: {nq}; query {which}: {len(q)} launches, wall {wall:.1f} us, kernel-busy {busy:.1f} us")
 for n, (c, d) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
     print(f"  {d:8.1f} us  {c:4d} x  {n}")
 if "--timeline" in sys.argv:
