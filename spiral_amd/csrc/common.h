@@ -56,6 +56,29 @@ __host__ __device__ inline size_t db_word_index(uint32_t z, uint32_t j, uint32_t
     return ((((size_t)z * nblk + ic / w) * dim0 + j) * w + ic % w) * 2u + m;
 }
 
+// response modulus switch of one coefficient (src/poly.cpp:578-601):
+// round(centre(a) * out_mod / inp_mod) mod out_mod with the reference's round-half-away-from-zero and
+// truncating division; the 128-bit quotient is a double estimate corrected exactly.
+__device__ __forceinline__ uint64_t rescale_dev(uint64_t a, uint64_t inp_mod, uint64_t out_mod) {
+    a %= inp_mod;
+    const bool neg = a >= inp_mod / 2;
+    const uint64_t mag = neg ? inp_mod - a : a;
+    const unsigned __int128 x = (unsigned __int128)mag * out_mod + inp_mod / 2;
+    const double xd = (double)(uint64_t)(x >> 64) * 18446744073709551616.0 + (double)(uint64_t)x;
+    uint64_t q = (uint64_t)(xd / (double)inp_mod);
+    __int128 r = (__int128)x - (__int128)((unsigned __int128)q * inp_mod);
+    while (r < 0) {
+        q--;
+        r += inp_mod;
+    }
+    while (r >= (__int128)inp_mod) {
+        q++;
+        r -= inp_mod;
+    }
+    uint64_t res = q % out_mod;
+    return (neg && res != 0) ? out_mod - res : res;
+}
+
 // include/util.h:34-38
 __host__ __device__ inline uint32_t get_bits_per(uint32_t dim) { return dim == 56 ? 1u : 56u / dim + 1u; }
 

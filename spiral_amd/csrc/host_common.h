@@ -124,7 +124,7 @@ inline int current_tables(DeviceTables* t) {
 
 // ---- expansion on PK buffers, shared by the seam and the resident server ---------------------------------
 struct ExpandWork {
-    uint64_t* raw;  // per active ct a: [2a] = c_0 RAW, [2a + 1] = NTT(automorph(c_1)) PK
+    uint64_t* raw;  // per active ct a: [2a] = automorph(c_0) RAW, [2a + 1] = NTT(automorph(c_1)) PK
     uint64_t* g;    // per active ct: t digit polynomials, PK
 };
 inline size_t expand_g_polys(uint32_t g, uint32_t t_exp, uint32_t t_exp_right) {
@@ -137,7 +137,7 @@ inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_
                 const uint64_t* w_right, uint32_t max_bits_right, uint32_t stopround, const ExpandWork& wk, hipStream_t st) {
     for (uint32_t r = 0; r < g; r++) {
         const uint32_t num_in = 1u << r;
-        const uint32_t t = (kN >> r) + 1, tinv = inv_mod_2n(t);
+        const uint32_t t = (kN >> r) + 1;
         // active ciphertexts of this round, by parity (:1701-1702)
         uint32_t cnt_even = num_in, cnt_odd = num_in;
         if (stopround > 0 && r > stopround) cnt_odd = 0;
@@ -150,6 +150,7 @@ inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_
         ip.src_map = ip.dst_map = identity_map();
         ip.cv = cv;
         ip.neg1 = tb.neg1 + (size_t)r * kN;
+        ip.neg1s = tb.neg1s + (size_t)r * kN;
         ip.num_in = num_in;
         ip.cnt_e = cnt_even;
         ip.auto_t = t;
@@ -160,7 +161,6 @@ inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_
         fp.dst = wk.g;
         fp.src_map = fp.dst_map = identity_map();
         fp.n_digits = 1;
-        fp.tinv = tinv;
         fp.cnt_e = cnt_even;
         fp.t_e = t_exp;
         fp.t_o = t_exp_right;

@@ -16,6 +16,7 @@ struct DeviceTables {
     uint4* fwd = nullptr;      // [2048] forward twiddles {W_p, W'_p, W_b, W'_b}
     uint4* inv = nullptr;      // [2048] inverse twiddles (1/2 folded in)
     uint64_t* neg1 = nullptr;  // [11][2048] PK: NTT(-x^(N-2^r))   (src/spiral.cpp:171-190)
+    uint64_t* neg1s = nullptr; // the same words' Shoup companions floor(w * 2^32 / m), PK
 };
 // builds the tables on `device` (host computes psi powers, tables.cpp); idempotent per device
 int tables_get(int device, DeviceTables* out);
@@ -81,11 +82,17 @@ struct InvParams {
     IndexMap src_map, dst_map;
     uint32_t pre_reduce;  // 1: fields are lazy sums (< 2^32), reduce mod m first
     uint32_t src_ref;     // 1: source is reference layout [2][N] u64 instead of PK
+    // IST_CRT, optional: the response modulus switch of the lifted coefficients in the same pass (src/spiral.cpp:1441-1447):
+    // resp[dst] = rescale(v, Q -> b < resp_row0 ? resp_mod0 : resp_mod1)
+    uint64_t* resp;
+    uint64_t resp_mod0, resp_mod1;
+    uint32_t resp_row0;
     // expansion round (launch_ntt_inverse_expand): block b = (active ct a, row); a < cnt_e -> i = 2a, else
     // i = 2(a - cnt_e) + 1; a ct with i >= num_in is first created as neg1 * cv[i - num_in] (src/spiral.cpp:1709)
     // Row 0 is transformed to dst[2a]; row 1 is not: its automorphed image, a slot permutation, goes to dst[2a + 1] in PK.
     uint64_t* cv;
     const uint64_t* neg1;
+    const uint64_t* neg1s;  // Shoup companions of neg1
     uint32_t num_in, cnt_e;
     uint32_t auto_t;  // the round's automorphism x -> x^t
 };
@@ -129,6 +136,7 @@ void launch_invert(const uint64_t* in, uint64_t* out, uint32_t npolys, hipStream
 void launch_gadget_invert(const uint64_t* in, uint64_t* out, uint32_t mx, uint32_t rdim, uint32_t cols, hipStream_t s);
 // response modulus switch (src/poly.cpp:578-601, src/spiral.cpp:1441-1447)
 void launch_rescale(const uint64_t* in, uint64_t* out, uint32_t n, uint64_t inp_mod, uint64_t out_mod, hipStream_t s);
+void launch_rescale2(const uint64_t* in, uint64_t* out, uint32_t n0, uint32_t n, uint64_t inp_mod, uint64_t out_mod0, uint64_t out_mod1, hipStream_t s);
 
 // ---- expansion / conversion / fold specials ----------------------------------------------------------
 // cv[dst0 + step*a] = neg1[r] * cv[src0 + step*a], both rows (src/spiral.cpp:1709)
@@ -167,6 +175,7 @@ struct GswParams {
     const uint64_t* cv;
     IndexMap cv_pos;       // i (over dims*ell) -> ct index
     uint64_t* gsw;         // [dims][3][3*ell] PK, dimension d stored at index (dims-1-d)  (src/spiral.cpp:2324)
+    uint64_t* key;         // optional: the fold key of the same matrices (see launch_fold_key), written in the same pass
     uint32_t t_conv, ell, dims;
 };
 void launch_regev_to_gsw(const GswParams& p, hipStream_t s);

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
         const uint64_t mask = (1ull << bits) - 1;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const uint32_t d = (uint32_t)digit_of(load_raw(src, ix_a(tid, r), p.tinv), k, bits, mask);
+            const uint32_t d = (uint32_t)digit_of(src[ix_a(tid, r)], k, bits, mask);  // already automorphed by the inverse pass
             lo[r] = digit_residue(d, kP);
             hi[r] = digit_residue(d, kB);
         }
@@ -233,12 +233,13 @@ __global__ __launch_bounds__(256) void ntt_inverse_kernel(Tables t, InvParams p)
         const uint64_t* src = p.cv + ((size_t)(created ? i - p.num_in : i) * 2u + row) * kN;
         if (created) {
             const uint64_t* ng = p.neg1 + tid;
+            const uint64_t* ngs = p.neg1s + tid;
             uint64_t* dstc = p.cv + ((size_t)i * 2u + row) * kN + tid;
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                const uint64_t v = src[r * 256 + tid], w = ng[r * 256];
-                lo[r] = mod_p((uint64_t)lo32(v) * lo32(w));
-                hi[r] = mod_b((uint64_t)hi32(v) * hi32(w));
+                const uint64_t v = src[r * 256 + tid], w = ng[r * 256], ws = ngs[r * 256];
+                lo[r] = csub(shoup(lo32(v), lo32(w), lo32(ws), kP), kP);
+                hi[r] = csub(shoup(hi32(v), hi32(w), hi32(ws), kB), kB);
                 dstc[r * 256] = pack(lo[r], hi[r]);
             }
         } else if (row == 0) {
@@ -261,8 +262,8 @@ __global__ __launch_bounds__(256) void ntt_inverse_kernel(Tables t, InvParams p)
                 const uint32_t pp = pk_pos(__brev(e >> 1) >> 21);
                 uint64_t v = src[pp];
                 if (created) {
-                    const uint64_t w = p.neg1[pp];
-                    v = pack(mod_p((uint64_t)lo32(v) * lo32(w)), mod_b((uint64_t)hi32(v) * hi32(w)));
+                    const uint64_t w = p.neg1[pp], ws = p.neg1s[pp];
+                    v = pack(csub(shoup(lo32(v), lo32(w), lo32(ws), kP), kP), csub(shoup(hi32(v), hi32(w), hi32(ws), kB), kB));
                 }
                 out[r * 256] = v;
             }
@@ -292,10 +293,32 @@ __global__ __launch_bounds__(256) void ntt_inverse_kernel(Tables t, InvParams p)
         }
     }
     ntt_inverse_block(lo, hi, sh, t.inv, tid);
-    if constexpr (STORE == IST_CRT) {
-        uint64_t* dst = p.dst + (size_t)p.dst_map(b) * kN;
+    if constexpr (EXPAND) {
+        // store the automorphed polynomial a(x^t) (scatter form of src/poly.cpp:240-261: coefficient i goes to i*t mod N,
+        // negated as Q - a when i*t mod 2N >= N), so that the t_exp .. t_exp_right digit transforms that follow read it
+        // in order instead of each gathering it
+        uint64_t* dst = p.dst + (size_t)b * kN;
 #pragma unroll
-        for (int r = 0; r < 8; r++) dst[ix_a(tid, r)] = crt_compose(lo[r], hi[r]);
+        for (int r = 0; r < 8; r++) {
+            const uint32_t e = (ix_a(tid, r) * p.auto_t) & (2u * kN - 1u);
+            const uint64_t v = crt_compose(lo[r], hi[r]);
+            dst[e & (kN - 1u)] = (e & kN) ? kQ - v : v;
+        }
+    } else if constexpr (STORE == IST_CRT) {
+        const size_t dp = (size_t)p.dst_map(b) * kN;
+        uint64_t* dst = p.dst + dp;
+        if (p.resp) {
+            const uint64_t out_mod = b < p.resp_row0 ? p.resp_mod0 : p.resp_mod1;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint64_t v = crt_compose(lo[r], hi[r]);
+                dst[ix_a(tid, r)] = v;
+                p.resp[dp + ix_a(tid, r)] = rescale_dev(v, kQ, out_mod);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; r++) dst[ix_a(tid, r)] = crt_compose(lo[r], hi[r]);
+        }
     } else {
         uint64_t* dst = p.dst + (size_t)p.dst_map(b) * (2 * kN);
 #pragma unroll

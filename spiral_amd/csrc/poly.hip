@@ -146,31 +146,19 @@ void launch_gadget_invert(const uint64_t* in, uint64_t* out, uint32_t mx, uint32
     hipLaunchKernelGGL(gadget_invert_kernel, dim3(kBpp, rdim * cols), dim3(kTpb), 0, s, in, out, mx, rdim, cols);
 }
 
-// ---- response modulus switch (src/poly.cpp:578-601) ------------------------------------------------------
-// round(centre(a) * out_mod / inp_mod) mod out_mod with the reference's round-half-away-from-zero and
-// truncating division; the 128-bit quotient is a double estimate corrected exactly.
-__device__ __forceinline__ uint64_t rescale_dev(uint64_t a, uint64_t inp_mod, uint64_t out_mod) {
-    a %= inp_mod;
-    const bool neg = a >= inp_mod / 2;
-    const uint64_t mag = neg ? inp_mod - a : a;
-    const unsigned __int128 x = (unsigned __int128)mag * out_mod + inp_mod / 2;
-    const double xd = (double)(uint64_t)(x >> 64) * 18446744073709551616.0 + (double)(uint64_t)x;
-    uint64_t q = (uint64_t)(xd / (double)inp_mod);
-    __int128 r = (__int128)x - (__int128)((unsigned __int128)q * inp_mod);
-    while (r < 0) {
-        q--;
-        r += inp_mod;
-    }
-    while (r >= (__int128)inp_mod) {
-        q++;
-        r -= inp_mod;
-    }
-    uint64_t res = q % out_mod;
-    return (neg && res != 0) ? out_mod - res : res;
-}
+// ---- response modulus switch (src/poly.cpp:578-601): rescale_dev lives in common.h ----------------------------
 __global__ __launch_bounds__(kTpb) void rescale_kernel(const uint64_t* in, uint64_t* out, uint32_t n, uint64_t inp_mod, uint64_t out_mod) {
     const uint32_t i = blockIdx.x * kTpb + threadIdx.x;
     if (i < n) out[i] = rescale_dev(in[i] % kQ, inp_mod, out_mod);
+}
+// the response switch in one launch: elements [0, n0) -> out_mod0 (row 0 -> q'), [n0, n) -> out_mod1 (the rest -> 4p)
+__global__ __launch_bounds__(kTpb) void rescale2_kernel(const uint64_t* in, uint64_t* out, uint32_t n0, uint32_t n, uint64_t inp_mod, uint64_t out_mod0,
+                                                        uint64_t out_mod1) {
+    const uint32_t i = blockIdx.x * kTpb + threadIdx.x;
+    if (i < n) out[i] = rescale_dev(in[i] % kQ, inp_mod, i < n0 ? out_mod0 : out_mod1);
+}
+void launch_rescale2(const uint64_t* in, uint64_t* out, uint32_t n0, uint32_t n, uint64_t inp_mod, uint64_t out_mod0, uint64_t out_mod1, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(rescale2_kernel, dim3((n + kTpb - 1) / kTpb), dim3(kTpb), 0, s, in, out, n0, n, inp_mod, out_mod0, out_mod1);
 }
 void launch_rescale(const uint64_t* in, uint64_t* out, uint32_t n, uint64_t inp_mod, uint64_t out_mod, hipStream_t s) {
     if (n) hipLaunchKernelGGL(rescale_kernel, dim3((n + kTpb - 1) / kTpb), dim3(kTpb), 0, s, in, out, n, inp_mod, out_mod);
@@ -314,11 +302,24 @@ __global__ __launch_bounds__(kTpb) void regev_to_gsw_kernel(GswParams p) {
     }
     const uint32_t cols = 3 * p.ell;
     uint64_t* g = p.gsw + (size_t)(p.dims - 1 - d) * 3 * cols * kN + z;
+    // fold key of the same columns (src/spiral.cpp:2361-2379): key[r][mm] = G2[r][mm] - gsw[r][mm] (= Q_neg; the NTT is
+    // linear and a constant c is c in every slot), key[r][m2 + mm] = gsw[r][mm]; G2[r][3i + c] = 2^(bits*i) iff c == r
+    uint64_t* key = p.key ? p.key + (size_t)(p.dims - 1 - d) * 3 * (2 * cols) * kN + z : nullptr;
+    const uint32_t sh = get_bits_per(p.ell) * i;
+    const uint32_t g2p = sh < 64 ? mod_p(1ull << sh) : 0u, g2b = sh < 64 ? mod_b(1ull << sh) : 0u;
 #pragma unroll
     for (uint32_t r = 0; r < 3; r++) {
-        g[((size_t)r * cols + 3 * i) * kN] = accv[r].reduced();
-        g[((size_t)r * cols + 3 * i + 1) * kN] = s2m[r][0];
-        g[((size_t)r * cols + 3 * i + 2) * kN] = s2m[r][1];
+        const uint64_t col[3] = {accv[r].reduced(), s2m[r][0], s2m[r][1]};
+#pragma unroll
+        for (uint32_t c = 0; c < 3; c++) {
+            const uint64_t q = col[c];
+            g[((size_t)r * cols + 3 * i + c) * kN] = q;
+            if (key) {
+                const uint32_t gp = c == r ? g2p : 0u, gb = c == r ? g2b : 0u;
+                key[((size_t)r * 2 * cols + 3 * i + c) * kN] = pack(csub(gp + kP - lo32(q), kP), csub(gb + kB - hi32(q), kB));
+                key[((size_t)r * 2 * cols + cols + 3 * i + c) * kN] = q;
+            }
+        }
     }
 }
 void launch_regev_to_gsw(const GswParams& p, hipStream_t s) {

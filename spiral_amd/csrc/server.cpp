@@ -714,8 +714,8 @@ int convert_gsw(spiral_gpu_server* S, hipStream_t st) {
         gp.t_conv = p.t_conv;
         gp.ell = s.ell;
         gp.dims = p.nu2;
+        gp.key = S->key.p;  // fold keys in the same pass
         launch_regev_to_gsw(gp, st);
-        launch_fold_key(S->gsw.p, S->key.p, p.nu2, s.ell, st);
     }
     return 0;
 }
@@ -769,15 +769,22 @@ namespace {
 // CRT-lifted at the head of S->raw.  src_pk == nullptr: the ciphertexts are already lifted in S->raw.  Otherwise they
 // are the PK polynomials [np0][3][2] at src_pk (accumulators, lazy sums when pre_reduce) and the lift is chained into
 // the digit transforms (fold_chain_kernel); later rounds chain from the previous round's product the same way.
-int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t rounds, const uint64_t* src_pk, bool pre_reduce) {
+// finish: the folded ciphertext is the answer; its response modulus switch (spiral_gpu_server_finish) rides on the last lift.
+int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t rounds, const uint64_t* src_pk, bool pre_reduce, bool finish = false) {
     const spiral_gpu_shape& s = S->s;
     uint32_t np = np0;
-    auto lift = [&](uint32_t npolys) {
+    auto lift = [&](uint32_t npolys, bool with_response = false) {
         InvParams ip{};
         ip.src = src_pk;
         ip.dst = S->raw.p;
         ip.src_map = ip.dst_map = identity_map();
         ip.pre_reduce = pre_reduce ? 1 : 0;
+        if (with_response) {  // row 0 -> q', rows 1.. -> 4*p_db (src/spiral.cpp:1441-1447)
+            ip.resp = S->resp.p;
+            ip.resp_row0 = 2;
+            ip.resp_mod0 = S->s.qprime;
+            ip.resp_mod1 = 4 * S->p.p_db;
+        }
         launch_ntt_inverse(S->tb, ip, IST_CRT, npolys, S->stream);
         src_pk = nullptr;
     };
@@ -809,7 +816,10 @@ int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t ro
         src_pk = S->fold_c.p;
         pre_reduce = false;
     }
-    if (src_pk) lift(np * 6);
+    if (src_pk)
+        lift(np * 6, finish && np == 1);
+    else if (finish)
+        return spiral_gpu_server_finish(S);
     return 0;
 }
 }  // namespace
@@ -846,15 +856,13 @@ int spiral_gpu_server_fold_root(spiral_gpu_server* S, const void* gathered_cts) 
     const uint32_t G = 1u << S->fold_g_log;
     if (srv_join_side(S)) return -1;
     HIP_OK(hipMemcpyAsync(S->raw.p, gathered_cts, (size_t)G * 6 * kPolyBytes, hipMemcpyDeviceToDevice, S->stream));
-    if (run_fold_rounds(S, G, S->p.nu2 - S->fold_g_log, S->fold_g_log, nullptr, false)) return -1;
-    return spiral_gpu_server_finish(S);
+    return run_fold_rounds(S, G, S->p.nu2 - S->fold_g_log, S->fold_g_log, nullptr, false, true);
 }
 
 int spiral_gpu_server_finish(spiral_gpu_server* S) {
     if (!S) return fail("null server");
     // row 0 -> q', rows 1.. -> 4*p_db (src/spiral.cpp:1441-1447)
-    launch_rescale(S->raw.p, S->resp.p, 2 * kN, kQ, S->s.qprime, S->stream);
-    launch_rescale(S->raw.p + 2 * kN, S->resp.p + 2 * kN, 4 * kN, kQ, 4 * S->p.p_db, S->stream);
+    launch_rescale2(S->raw.p, S->resp.p, 2 * kN, 6 * kN, kQ, S->s.qprime, 4 * S->p.p_db, S->stream);
     return 0;
 }
 
@@ -945,8 +953,7 @@ int spiral_gpu_server_run_query(spiral_gpu_server* S) {
         if (spiral_gpu_server_expand(S)) return -1;
         if (spiral_gpu_server_convert(S)) return -1;
         if (spiral_gpu_server_first_dim(S)) return -1;
-        if (run_fold_rounds(S, S->s.num_per, 0, S->p.nu2, S->acc, false)) return -1;
-        return spiral_gpu_server_finish(S);
+        return run_fold_rounds(S, S->s.num_per, 0, S->p.nu2, S->acc, false, true);
     });
 }
 
@@ -954,8 +961,7 @@ int spiral_gpu_server_run_post(spiral_gpu_server* S, int reduce_first) {
     if (!S) return fail("null server");
     if (srv_join_side(S)) return -1;
     return run_group(S, reduce_first ? 2 : 1, S->stream, [&]() {
-        if (run_fold_rounds(S, S->s.num_per, 0, S->p.nu2, S->acc, reduce_first != 0)) return -1;  // lift chained into round 0
-        return spiral_gpu_server_finish(S);
+        return run_fold_rounds(S, S->s.num_per, 0, S->p.nu2, S->acc, reduce_first != 0, true);  // lift chained into round 0, switch into the last
     });
 }
 

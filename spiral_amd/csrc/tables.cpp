@@ -81,6 +81,12 @@ int tables_get(int device, DeviceTables* out) {
         launch_ntt_forward(t, p, LD_RAW, ST_PK, kLogN, 0);
         if (hipDeviceSynchronize() != hipSuccess) return -1;
         (void)hipFree(d_raw);
+        // Shoup companions floor(w * 2^32 / m) of the same words, so that the expansion multiplies by neg1 without a division
+        std::vector<uint64_t> w((size_t)kLogN * kN);
+        if (hipMemcpy(w.data(), t.neg1, w.size() * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        for (uint64_t& x : w) x = (((x & 0xffffffffull) << 32) / kP) | ((((x >> 32) << 32) / kB) << 32);
+        if (hipMalloc(&t.neg1s, w.size() * sizeof(uint64_t)) != hipSuccess) return -1;
+        if (hipMemcpy(t.neg1s, w.data(), w.size() * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) return -1;
         g_tables[device] = t;
         g_ready[device] = true;
     }
