@@ -135,15 +135,20 @@ inline size_t expand_g_polys(uint32_t g, uint32_t t_exp, uint32_t t_exp_right) {
 // src/spiral.cpp:1664-1743.  cv: 2^g cts (2 PK polys each).
 inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_t t_exp, const uint64_t* w_left, uint32_t t_exp_right,
                 const uint64_t* w_right, uint32_t max_bits_right, uint32_t stopround, const ExpandWork& wk, hipStream_t st) {
+    // active odd-index ciphertexts of round r (:1701-1702); the even ones are all 2^r
+    auto odd_count = [&](uint32_t r) {
+        const uint32_t num_in = 1u << r;
+        if (stopround > 0 && r > stopround) return 0u;
+        if (stopround > 0 && r == stopround) return std::min(num_in, max_bits_right + 1);
+        return num_in;
+    };
     for (uint32_t r = 0; r < g; r++) {
         const uint32_t num_in = 1u << r;
         const uint32_t t = (kN >> r) + 1;
-        // active ciphertexts of this round, by parity (:1701-1702)
-        uint32_t cnt_even = num_in, cnt_odd = num_in;
-        if (stopround > 0 && r > stopround) cnt_odd = 0;
-        if (stopround > 0 && r == stopround) cnt_odd = std::min(num_in, max_bits_right + 1);
+        const uint32_t cnt_even = num_in, cnt_odd = odd_count(r);
         // 1) INTT + CRT of row 0 and the automorphed row 1 (a slot permutation) of every active ct, both parities;
-        //    cts with i >= num_in are first created as neg1 * cv[i - num_in] (:1709) inside the same kernel
+        //    cts with i >= num_in are neg1 * cv[i - num_in] (:1709): created inside this kernel in round 0, by the
+        //    previous round's MAC afterwards
         const uint32_t cnt = cnt_even + cnt_odd;
         InvParams ip{};
         ip.dst = wk.raw;
@@ -154,6 +159,7 @@ inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_
         ip.num_in = num_in;
         ip.cnt_e = cnt_even;
         ip.auto_t = t;
+        ip.create_here = r == 0;
         launch_ntt_inverse_expand(tb, ip, 2 * cnt, st);
         // 2) G^-1(automorph(c)[0]) digits (t_exp / t_exp_right per ct), one launch
         FwdParams fp{};
@@ -176,6 +182,12 @@ inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_
         mp.cnt_o = cnt_odd;
         mp.t_e = t_exp;
         mp.t_o = t_exp_right;
+        if (r + 1 < g) {
+            mp.neg1n = tb.neg1 + (size_t)(r + 1) * kN;
+            mp.neg1ns = tb.neg1s + (size_t)(r + 1) * kN;
+            mp.next_num_in = 2 * num_in;
+            mp.next_cnt_o = odd_count(r + 1);
+        }
         launch_expand_mac_round(mp, st);
     }
 }

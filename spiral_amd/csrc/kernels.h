@@ -82,11 +82,6 @@ struct InvParams {
     IndexMap src_map, dst_map;
     uint32_t pre_reduce;  // 1: fields are lazy sums (< 2^32), reduce mod m first
     uint32_t src_ref;     // 1: source is reference layout [2][N] u64 instead of PK
-    // IST_CRT, optional: the response modulus switch of the lifted coefficients in the same pass (src/spiral.cpp:1441-1447):
-    // resp[dst] = rescale(v, Q -> b < resp_row0 ? resp_mod0 : resp_mod1)
-    uint64_t* resp;
-    uint64_t resp_mod0, resp_mod1;
-    uint32_t resp_row0;
     // expansion round (launch_ntt_inverse_expand): block b = (active ct a, row); a < cnt_e -> i = 2a, else
     // i = 2(a - cnt_e) + 1; a ct with i >= num_in is first created as neg1 * cv[i - num_in] (src/spiral.cpp:1709)
     // Row 0 is transformed to dst[2a]; row 1 is not: its automorphed image, a slot permutation, goes to dst[2a + 1] in PK.
@@ -95,6 +90,7 @@ struct InvParams {
     const uint64_t* neg1s;  // Shoup companions of neg1
     uint32_t num_in, cnt_e;
     uint32_t auto_t;  // the round's automorphism x -> x^t
+    uint32_t create_here;  // 1: cts with i >= num_in do not exist yet (round 0); 0: the previous round's MAC wrote them
 };
 void launch_ntt_inverse(const DeviceTables& t, const InvParams& p, uint32_t store, uint32_t nblocks, hipStream_t s);
 void launch_ntt_inverse_expand(const DeviceTables& t, const InvParams& p, uint32_t nblocks, hipStream_t s);
@@ -153,6 +149,11 @@ struct ExpandMacParams {
     const uint64_t* g;
     const uint64_t* a1;
     uint32_t cnt_e, cnt_o, t_e, t_o;
+    // next round's new ciphertexts cv[i + next_num_in] = neg1 * cv[i] (src/spiral.cpp:1709), written while the updated cv[i]
+    // is in registers: every even i, and odd active ct a' when a' + next_num_in/2 < next_cnt_o.  neg1n == null: none.
+    const uint64_t* neg1n;
+    const uint64_t* neg1ns;  // Shoup companions
+    uint32_t next_num_in, next_cnt_o;
 };
 void launch_expand_mac_round(const ExpandMacParams& p, hipStream_t s);
 // scalToMat product: out[a][r][c] = sum_k W[r][2k+c] * G[a][k] + pad(cv[pos(a)][1])   (src/spiral.cpp:1850-1885)

@@ -229,7 +229,16 @@ __global__ __launch_bounds__(256) void ntt_inverse_kernel(Tables t, InvParams p)
     if constexpr (EXPAND) {
         const uint32_t a = b >> 1, row = b & 1u;
         const uint32_t i = a < p.cnt_e ? 2u * a : 2u * (a - p.cnt_e) + 1u;
-        const bool created = i >= p.num_in;  // cv[i] = neg1 * cv[i - num_in], created here (src/spiral.cpp:1709)
+#ifdef EXP_ABL_NO_ROW1
+        if (row == 1) return;
+#endif
+#ifdef EXP_ABL_NO_CREATE
+        const bool created = false;
+#else
+        // cv[i] = neg1 * cv[i - num_in] (src/spiral.cpp:1709) is created here in round 0 only; later rounds find it already
+        // written by the previous round's MAC, which has the new cv[i - num_in] in registers
+        const bool created = p.create_here && i >= p.num_in;
+#endif
         const uint64_t* src = p.cv + ((size_t)(created ? i - p.num_in : i) * 2u + row) * kN;
         if (created) {
             const uint64_t* ng = p.neg1 + tid;
@@ -300,25 +309,22 @@ __global__ __launch_bounds__(256) void ntt_inverse_kernel(Tables t, InvParams p)
         uint64_t* dst = p.dst + (size_t)b * kN;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
+#ifdef EXP_ABL_PLAIN_STORE
+            const uint32_t e = ix_a(tid, r);
+#else
             const uint32_t e = (ix_a(tid, r) * p.auto_t) & (2u * kN - 1u);
+#endif
+#ifdef EXP_ABL_NO_CRT
+            const uint64_t v = pack(lo[r], hi[r]);
+#else
             const uint64_t v = crt_compose(lo[r], hi[r]);
+#endif
             dst[e & (kN - 1u)] = (e & kN) ? kQ - v : v;
         }
     } else if constexpr (STORE == IST_CRT) {
-        const size_t dp = (size_t)p.dst_map(b) * kN;
-        uint64_t* dst = p.dst + dp;
-        if (p.resp) {
-            const uint64_t out_mod = b < p.resp_row0 ? p.resp_mod0 : p.resp_mod1;
+        uint64_t* dst = p.dst + (size_t)p.dst_map(b) * kN;
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const uint64_t v = crt_compose(lo[r], hi[r]);
-                dst[ix_a(tid, r)] = v;
-                p.resp[dp + ix_a(tid, r)] = rescale_dev(v, kQ, out_mod);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 8; r++) dst[ix_a(tid, r)] = crt_compose(lo[r], hi[r]);
-        }
+        for (int r = 0; r < 8; r++) dst[ix_a(tid, r)] = crt_compose(lo[r], hi[r]);
     } else {
         uint64_t* dst = p.dst + (size_t)p.dst_map(b) * (2 * kN);
 #pragma unroll

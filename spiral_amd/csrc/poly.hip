@@ -6,6 +6,9 @@
 
 namespace spiral {
 
+// w*y mod m in [0, 2m) from the Shoup companion ws = floor(w * 2^32 / m), any y < 2^32 (as ntt.cuh shoup)
+__device__ __forceinline__ uint32_t shoup32(uint32_t y, uint32_t w, uint32_t ws, uint32_t m) { return w * y - __umulhi(y, ws) * m; }
+
 constexpr uint32_t kTpb = 256;
 constexpr uint32_t kBpp = kN / kTpb;  // blocks per polynomial
 
@@ -210,6 +213,14 @@ __global__ __launch_bounds__(kTpb) void expand_mac_round_kernel(ExpandMacParams 
     const size_t gbase = odd ? (size_t)p.cnt_e * p.t_e + (size_t)(a - p.cnt_e) * p.t_o : (size_t)a * p.t_e;
     const uint64_t* w = (odd ? p.w_o : p.w_e) + z;
     const uint64_t* gp = p.g + gbase * kN + z;
+    // next round's neg1 words are cold: request them before the MAC loop
+    const uint32_t ao = a - p.cnt_e;
+    const bool make_next = kg == 0 && p.neg1n != nullptr && (!odd || ao + (p.next_num_in >> 1) < p.next_cnt_o);
+    uint64_t nw = 0, nws = 0;
+    if (make_next) {
+        nw = p.neg1n[z];
+        nws = p.neg1ns[z];
+    }
     Acc2 acc0, acc1;
 #pragma unroll 7
     for (uint32_t k = kg; k < tdim; k += 4) {
@@ -233,8 +244,15 @@ __global__ __launch_bounds__(kTpb) void expand_mac_round_kernel(ExpandMacParams 
             acc1.hi += sh[q][zz][3];
         }
         uint64_t* c = p.cv + (size_t)i * 2 * kN + z;
-        c[0] = add_pk(c[0], acc0.reduced());
-        c[kN] = add_pk(add_pk(c[kN], acc1.reduced()), p.a1[((size_t)a * 2u + 1u) * kN + z]);
+        const uint64_t c0 = add_pk(c[0], acc0.reduced());
+        const uint64_t c1 = add_pk(add_pk(c[kN], acc1.reduced()), p.a1[((size_t)a * 2u + 1u) * kN + z]);
+        c[0] = c0;
+        c[kN] = c1;
+        if (make_next) {
+            uint64_t* n = p.cv + (size_t)(i + p.next_num_in) * 2 * kN + z;
+            n[0] = pack(csub(shoup32(lo32(c0), lo32(nw), lo32(nws), kP), kP), csub(shoup32(hi32(c0), hi32(nw), hi32(nws), kB), kB));
+            n[kN] = pack(csub(shoup32(lo32(c1), lo32(nw), lo32(nws), kP), kP), csub(shoup32(hi32(c1), hi32(nw), hi32(nws), kB), kB));
+        }
     }
 }
 void launch_expand_mac_round(const ExpandMacParams& p, hipStream_t s) {

@@ -769,22 +769,16 @@ namespace {
 // CRT-lifted at the head of S->raw.  src_pk == nullptr: the ciphertexts are already lifted in S->raw.  Otherwise they
 // are the PK polynomials [np0][3][2] at src_pk (accumulators, lazy sums when pre_reduce) and the lift is chained into
 // the digit transforms (fold_chain_kernel); later rounds chain from the previous round's product the same way.
-// finish: the folded ciphertext is the answer; its response modulus switch (spiral_gpu_server_finish) rides on the last lift.
+// finish: the folded ciphertext is the answer; follow with the response modulus switch (spiral_gpu_server_finish).
 int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t rounds, const uint64_t* src_pk, bool pre_reduce, bool finish = false) {
     const spiral_gpu_shape& s = S->s;
     uint32_t np = np0;
-    auto lift = [&](uint32_t npolys, bool with_response = false) {
+    auto lift = [&](uint32_t npolys) {
         InvParams ip{};
         ip.src = src_pk;
         ip.dst = S->raw.p;
         ip.src_map = ip.dst_map = identity_map();
         ip.pre_reduce = pre_reduce ? 1 : 0;
-        if (with_response) {  // row 0 -> q', rows 1.. -> 4*p_db (src/spiral.cpp:1441-1447)
-            ip.resp = S->resp.p;
-            ip.resp_row0 = 2;
-            ip.resp_mod0 = S->s.qprime;
-            ip.resp_mod1 = 4 * S->p.p_db;
-        }
         launch_ntt_inverse(S->tb, ip, IST_CRT, npolys, S->stream);
         src_pk = nullptr;
     };
@@ -816,11 +810,9 @@ int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t ro
         src_pk = S->fold_c.p;
         pre_reduce = false;
     }
-    if (src_pk)
-        lift(np * 6, finish && np == 1);
-    else if (finish)
-        return spiral_gpu_server_finish(S);
-    return 0;
+    if (src_pk) lift(np * 6);
+    // (the switch is its own launch: fused into the 6-workgroup lift it serialises 8 coefficients per thread and is slower)
+    return finish ? spiral_gpu_server_finish(S) : 0;
 }
 }  // namespace
 

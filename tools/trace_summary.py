@@ -13,10 +13,12 @@ sweeps = [i for i, r in enumerate(rows) if "sweep_kernel" in r["Kernel_Name"]]
 nq = len(sweeps)
 which = int(sys.argv[sys.argv.index("--query") + 1]) if "--query" in sys.argv else nq // 2
 last = sweeps[which]
-# a query = from the kernel after the previous query's last rescale to this query's last rescale
-resc = [i for i, r in enumerate(rows) if "rescale" in r["Kernel_Name"]]
-start = max(i for i in resc if i < last) + 1
-end = min(i for i in resc if i > last) + 1
+# a query = from the copy of the query ciphertext into the expansion buffer (the first launch of the answer path) to the
+# launch before the next query's copy
+copies = [i for i, r in enumerate(rows) if "copyBuffer" in r["Kernel_Name"]]
+start = max(i for i in copies if i < last)
+later = [i for i in copies if i > last]
+end = (later[0] if later else len(rows)) - 1
 q = rows[start : end + 1]
 t0 = int(q[0]["Start_Timestamp"])
 tot = defaultdict(lambda: [0, 0.0])
