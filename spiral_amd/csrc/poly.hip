@@ -48,51 +48,65 @@ struct FoldMacParams {
     uint64_t* out;        // [np][3][2]
     uint32_t K;
 };
+// B ciphertexts per workgroup share every key word loaded (the key is common to all ciphertexts of a round)
+template <uint32_t B>
 __global__ __launch_bounds__(kTpb) void fold_mac_kernel(FoldMacParams p) {
-    __shared__ uint64_t sh[3][64][12];
-    const uint32_t zz = threadIdx.x & 63u, kg = threadIdx.x >> 6, z = blockIdx.x * 64u + zz, i = blockIdx.y;
-    const uint64_t* dp = p.d + (size_t)i * p.K * 2 * kN + z;
+    __shared__ uint64_t sh[3][64][12 * B];
+    const uint32_t zz = threadIdx.x & 63u, kg = threadIdx.x >> 6, z = blockIdx.x * 64u + zz, i0 = blockIdx.y * B;
+    const uint64_t* dp = p.d + (size_t)i0 * p.K * 2 * kN + z;
     const uint64_t* kp = p.key + z;
-    Acc2 acc[3][2];
+    Acc2 acc[B][3][2];
 #pragma unroll 4
     for (uint32_t mm = kg; mm < p.K; mm += 4) {
-        const uint64_t d0 = dp[(size_t)(2 * mm) * kN], d1 = dp[(size_t)(2 * mm + 1) * kN];
+        uint64_t kv[3];
 #pragma unroll
-        for (uint32_t r = 0; r < 3; r++) {
-            const uint64_t kv = kp[((size_t)r * p.K + mm) * kN];
-            acc[r][0].mac(kv, d0);
-            acc[r][1].mac(kv, d1);
+        for (uint32_t r = 0; r < 3; r++) kv[r] = kp[((size_t)r * p.K + mm) * kN];
+#pragma unroll
+        for (uint32_t b = 0; b < B; b++) {
+            const uint64_t d0 = dp[((size_t)b * p.K + mm) * 2 * kN], d1 = dp[(((size_t)b * p.K + mm) * 2 + 1) * kN];
+#pragma unroll
+            for (uint32_t r = 0; r < 3; r++) {
+                acc[b][r][0].mac(kv[r], d0);
+                acc[b][r][1].mac(kv[r], d1);
+            }
         }
     }
     if (kg > 0) {
 #pragma unroll
-        for (uint32_t r = 0; r < 3; r++)
+        for (uint32_t b = 0; b < B; b++)
 #pragma unroll
-            for (uint32_t c = 0; c < 2; c++) {
-                sh[kg - 1][zz][(r * 2 + c) * 2] = acc[r][c].lo;
-                sh[kg - 1][zz][(r * 2 + c) * 2 + 1] = acc[r][c].hi;
-            }
+            for (uint32_t r = 0; r < 3; r++)
+#pragma unroll
+                for (uint32_t c = 0; c < 2; c++) {
+                    sh[kg - 1][zz][b * 12 + (r * 2 + c) * 2] = acc[b][r][c].lo;
+                    sh[kg - 1][zz][b * 12 + (r * 2 + c) * 2 + 1] = acc[b][r][c].hi;
+                }
     }
     __syncthreads();
     if (kg == 0) {
 #pragma unroll
-        for (uint32_t r = 0; r < 3; r++)
+        for (uint32_t b = 0; b < B; b++)
 #pragma unroll
-            for (uint32_t c = 0; c < 2; c++) {
-                Acc2 a = acc[r][c];
+            for (uint32_t r = 0; r < 3; r++)
 #pragma unroll
-                for (int q = 0; q < 3; q++) {  // K <= 256 terms in total (m2 * q fits u64, src/spiral.cpp:465)
-                    a.lo += sh[q][zz][(r * 2 + c) * 2];
-                    a.hi += sh[q][zz][(r * 2 + c) * 2 + 1];
+                for (uint32_t c = 0; c < 2; c++) {
+                    Acc2 a = acc[b][r][c];
+#pragma unroll
+                    for (int q = 0; q < 3; q++) {  // K <= 256 terms in total (m2 * q fits u64, src/spiral.cpp:465)
+                        a.lo += sh[q][zz][b * 12 + (r * 2 + c) * 2];
+                        a.hi += sh[q][zz][b * 12 + (r * 2 + c) * 2 + 1];
+                    }
+                    p.out[((size_t)(i0 + b) * 6 + r * 2 + c) * kN + z] = a.reduced();
                 }
-                p.out[((size_t)i * 6 + r * 2 + c) * kN + z] = a.reduced();
-            }
     }
 }
 void launch_fold_mac(const uint64_t* key, const uint64_t* d, uint64_t* out, uint32_t K, uint32_t np, hipStream_t s) {
     if (np == 0) return;
     FoldMacParams p{key, d, out, K};
-    hipLaunchKernelGGL(fold_mac_kernel, dim3(kN / 64, np), dim3(kTpb), 0, s, p);
+    if (np >= 16 && np % 2 == 0)  // wide rounds: 2 ciphertexts per workgroup
+        hipLaunchKernelGGL(fold_mac_kernel<2>, dim3(kN / 64, np / 2), dim3(kTpb), 0, s, p);
+    else
+        hipLaunchKernelGGL(fold_mac_kernel<1>, dim3(kN / 64, np), dim3(kTpb), 0, s, p);
 }
 
 // ---- add / mul_by_const (src/poly.cpp:138-155, 190-211) ----------------------------------------------

@@ -266,6 +266,39 @@ def test_answer_and_device_db(sa, oracle, nu1, nu2, kw):
     srv.close()
 
 
+@pytest.mark.parametrize("env", [
+    {"SPIRAL_FOLD_CHAIN": "0"},                                  # separate lift + digit transforms every round
+    {"SPIRAL_FOLD_DMAX": "0", "SPIRAL_FOLD_LMIN": "0"},          # fold_chain_kernel<LOOP> every round
+    {"SPIRAL_FOLD_DMAX": "100000", "SPIRAL_FOLD_LMIN": "0"},     # fold_chain_kernel per (polynomial, digit) every round
+    {"SPIRAL_FOLD_DMAX": "96", "SPIRAL_FOLD_LMIN": "384"},       # all three in one fold
+])
+def test_fold_chain_schedules(sa, oracle, env, monkeypatch):
+    """the fold's schedule variants (read from the environment when the server is created) all give the oracle's answer"""
+    O = oracle
+    for k, val in env.items():
+        monkeypatch.setenv(k, val)
+    kw = dict(t_gsw=8)  # (t_gsw = 4 is bit-exact too but too noisy to decode at nu2 = 6)
+    po, pg = O.make_params(3, 6, **kw), sa.make_params(3, 6, **kw)
+    cl = O.Client(po, seed=17)
+    wl, wr, w, v = cl.pub_params()
+    srv = sa.Server(pg)
+    srv.gen_db(5)
+    srv.set_pub_params(wl, wr, w, v)
+    db = O.gen_db(po, 5)
+    q = cl.query(301)
+    want = O.answer(po, q, wl, wr, w, v, db)
+    fin, resp, _ = srv.answer(q)                  # stage API: lift, then fold from the lifted ciphertexts
+    assert_eq(fin, want, f"answer {env}")
+    srv.use_graphs(True)
+    srv.set_query(q)
+    srv.run_query()                               # lift chained into round 0
+    srv.sync()
+    from spiral_amd import server as SV
+    assert_eq(srv.read(SV.BUF_FINAL), want, f"run_query {env}")
+    assert_eq(cl.decode(srv.read(SV.BUF_RESPONSE)), O.db_item(po, 5, 301), "decoded plaintext")
+    srv.close()
+
+
 @pytest.mark.parametrize("graphs,overlap", [(True, False), (True, True), (False, True)])
 def test_graph_replay_matches_eager(sa, oracle, graphs, overlap):
     """run_pre / run_post captured into hipGraphs and replayed for several queries == the eager stages; in overlap
