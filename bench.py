@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     ap.add_argument("--overlap", type=int, default=0, help="1: Regev->GSW conversion on a side stream under the sweep (measured slower: the sweep loses "
                     "more to the contention, 349 -> 422 us, than the 30 us of conversion it hides); 0: everything in order on one stream")
-    ap.add_argument("--event-every", type=int, default=4, help="single GPU: bracket the stages with HIP events on every n-th timed step only (1 = every step)")
+    ap.add_argument("--event-every", type=int, default=4, help="bracket the stages with HIP events on every n-th timed step only (1 = every step)")
     ap.add_argument("--root-fold", action="store_true", help="N > 1: plain reduce to rank 0, which lifts and folds alone")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the reduce even with one rank (self-test)")
     args = ap.parse_args()
@@ -134,8 +134,9 @@ def main():
     srv.set_overlap(bool(args.overlap))
 
     # HIP events bracket the stages (and give the sweep's launch duration for the roofline) on every event_every-th timed
-    # step; an event record costs the stream ~6 us, so the other steps of a single-GPU run replay the whole query as one graph
-    sampled = [k for k in range(args.steps) if k % max(1, args.event_every) == 0] if (world == 1 and not use_dist) else list(range(args.steps))
+    # step; an event record costs the stream ~6 us, so the other steps replay the whole query (one GPU) or everything before
+    # the collective (N GPUs) as one graph
+    sampled = [k for k in range(args.steps) if k % max(1, args.event_every) == 0]
     ev = {k: [torch.cuda.Event(enable_timing=True) for _ in range(4)] for k in sampled}
 
     whole = world == 1 and not use_dist and not args.no_graphs and not args.overlap and args.event_every > 1
@@ -145,11 +146,14 @@ def main():
         if e is None and whole:
             srv.run_query()  # the same kernels as below, replayed as ONE hipGraph: no event / launch seams around the sweep
             return
-        if e: e[0].record(stream)
-        srv.run_pre()
-        if e: e[1].record(stream)
-        srv.first_dim()
-        if e: e[2].record(stream)
+        if e:
+            e[0].record(stream)
+            srv.run_pre()
+            e[1].record(stream)
+            srv.first_dim()
+            e[2].record(stream)
+        else:
+            srv.run_pre_sweep()  # one graph for everything before the collective
         if sharded_fold:
             sdist.reduce_scatter_accumulators(chunk, acc)
             srv.fold_local(chunk.data_ptr(), ct.data_ptr())

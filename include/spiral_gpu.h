@@ -163,6 +163,8 @@ int spiral_gpu_server_run_post(spiral_gpu_server *s, int reduce_first);
 /* the whole single-GPU answer (run_pre, first_dim, run_post(0)) as one group: with use_graphs on, one hipGraph launch
  * per query and no host-visible seam between the stages */
 int spiral_gpu_server_run_query(spiral_gpu_server *s);
+/* run_pre + first_dim as one group: everything a rank does before the reduce of a sharded answer */
+int spiral_gpu_server_run_pre_sweep(spiral_gpu_server *s);
 /* per-shard first-dimension accumulators: num_per*n1*n2*2048 packed words (p-limb | b-limb << 32, each
  * field < 2^28).  Summing the shards' buffers as uint64 (one RCCL reduce) and calling lift with
  * reduce_first = 1 gives the unsharded result.  Returns a device pointer. */

@@ -96,6 +96,7 @@ PROTOTYPES = {
     "spiral_gpu_server_use_graphs": (C.c_int, [C.c_void_p, C.c_int]),
     "spiral_gpu_server_set_overlap": (C.c_int, [C.c_void_p, C.c_int]),
     "spiral_gpu_server_run_query": (C.c_int, [C.c_void_p]),
+    "spiral_gpu_server_run_pre_sweep": (C.c_int, [C.c_void_p]),
     "spiral_gpu_server_run_pre": (C.c_int, [C.c_void_p]),
     "spiral_gpu_server_run_post": (C.c_int, [C.c_void_p, C.c_int]),
     "spiral_gpu_server_set_fold_ranks": (C.c_int, [C.c_void_p, C.c_uint32]),

@@ -31,7 +31,10 @@ struct spiral_gpu_server {
     // captured stage groups (hipGraph): [0] expand + convert, [1] lift + fold + finish, [2] the same with
     // reduce_first; instantiated lazily, invalidated when a captured pointer or flag changes
     bool use_graphs = false;
-    hipGraphExec_t graph[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [3] = Regev->GSW conversion on the side stream, [4] = whole query
+    // [3] = Regev->GSW conversion on the side stream, [4] = whole query, [5] = fold_local, [6] = fold_root, [7] = run_pre + sweep
+    hipGraphExec_t graph[8] = {};
+    const void *cap_chunk = nullptr, *cap_gathered = nullptr;
+    void* cap_ct = nullptr;  // the caller's buffers captured into graphs 5 and 6
     // overlap mode: run_pre forks the Regev->GSW conversion (needed only by the folding) onto side_stream so that it
     // runs under the HBM-bound sweep; the fold entry points join it
     bool overlap = false, side_pending = false;
@@ -834,23 +837,6 @@ int spiral_gpu_server_set_fold_ranks(spiral_gpu_server* S, uint32_t n_ranks) {
     return 0;
 }
 
-int spiral_gpu_server_fold_local(spiral_gpu_server* S, const void* acc_chunk, void* out_ct) {
-    if (!S || !acc_chunk || !out_ct) return fail("null argument");
-    const uint32_t L = S->s.num_per >> S->fold_g_log;
-    if (srv_join_side(S)) return -1;
-    if (run_fold_rounds(S, L, 0, S->p.nu2 - S->fold_g_log, (const uint64_t*)acc_chunk, true)) return -1;
-    HIP_OK(hipMemcpyAsync(out_ct, S->raw.p, 6 * kPolyBytes, hipMemcpyDeviceToDevice, S->stream));
-    return 0;
-}
-
-int spiral_gpu_server_fold_root(spiral_gpu_server* S, const void* gathered_cts) {
-    if (!S || !gathered_cts) return fail("null argument");
-    const uint32_t G = 1u << S->fold_g_log;
-    if (srv_join_side(S)) return -1;
-    HIP_OK(hipMemcpyAsync(S->raw.p, gathered_cts, (size_t)G * 6 * kPolyBytes, hipMemcpyDeviceToDevice, S->stream));
-    return run_fold_rounds(S, G, S->p.nu2 - S->fold_g_log, S->fold_g_log, nullptr, false, true);
-}
-
 int spiral_gpu_server_finish(spiral_gpu_server* S) {
     if (!S) return fail("null server");
     // row 0 -> q', rows 1.. -> 4*p_db (src/spiral.cpp:1441-1447)
@@ -946,6 +932,56 @@ int spiral_gpu_server_run_query(spiral_gpu_server* S) {
         if (spiral_gpu_server_convert(S)) return -1;
         if (spiral_gpu_server_first_dim(S)) return -1;
         return run_fold_rounds(S, S->s.num_per, 0, S->p.nu2, S->acc, false, true);
+    });
+}
+
+// The two halves of a distributed fold.  With use_graphs on they replay as hipGraphs too; the buffers the caller hands
+// in are baked into the capture, so a graph is dropped when a different pointer arrives.
+int spiral_gpu_server_fold_local(spiral_gpu_server* S, const void* acc_chunk, void* out_ct) {
+    if (!S || !acc_chunk || !out_ct) return fail("null argument");
+    const uint32_t L = S->s.num_per >> S->fold_g_log;
+    if (srv_join_side(S)) return -1;
+    if (S->graph[5] && (S->cap_chunk != acc_chunk || S->cap_ct != out_ct)) {
+        (void)hipGraphExecDestroy(S->graph[5]);
+        S->graph[5] = nullptr;
+    }
+    S->cap_chunk = acc_chunk;
+    S->cap_ct = out_ct;
+    return run_group(S, 5, S->stream, [&]() {
+        if (run_fold_rounds(S, L, 0, S->p.nu2 - S->fold_g_log, (const uint64_t*)acc_chunk, true)) return -1;
+        HIP_OK(hipMemcpyAsync(out_ct, S->raw.p, 6 * kPolyBytes, hipMemcpyDeviceToDevice, S->stream));
+        return 0;
+    });
+}
+
+int spiral_gpu_server_fold_root(spiral_gpu_server* S, const void* gathered_cts) {
+    if (!S || !gathered_cts) return fail("null argument");
+    const uint32_t G = 1u << S->fold_g_log;
+    if (srv_join_side(S)) return -1;
+    if (S->graph[6] && S->cap_gathered != gathered_cts) {
+        (void)hipGraphExecDestroy(S->graph[6]);
+        S->graph[6] = nullptr;
+    }
+    S->cap_gathered = gathered_cts;
+    return run_group(S, 6, S->stream, [&]() {
+        HIP_OK(hipMemcpyAsync(S->raw.p, gathered_cts, (size_t)G * 6 * kPolyBytes, hipMemcpyDeviceToDevice, S->stream));
+        return run_fold_rounds(S, G, S->p.nu2 - S->fold_g_log, S->fold_g_log, nullptr, false, true);
+    });
+}
+
+// run_pre + first_dim as one group: what a rank does before the collective
+int spiral_gpu_server_run_pre_sweep(spiral_gpu_server* S) {
+    if (!S) return fail("null server");
+    if (!S->have_query || !S->have_pp) return fail("query and public parameters must be set first");
+    if (!S->have_db) return fail("no database loaded");
+    if (S->overlap) {
+        if (spiral_gpu_server_run_pre(S)) return -1;
+        return spiral_gpu_server_first_dim(S);
+    }
+    return run_group(S, 7, S->stream, [&]() {
+        if (spiral_gpu_server_expand(S)) return -1;
+        if (spiral_gpu_server_convert(S)) return -1;
+        return spiral_gpu_server_first_dim(S);
     });
 }
 

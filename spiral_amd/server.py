@@ -95,6 +95,10 @@ class Server:
         """run_pre + first_dim + run_post as one group (one hipGraph replay when graphs are on); single GPU only"""
         check(lib().spiral_gpu_server_run_query(self.h))
 
+    def run_pre_sweep(self):
+        """run_pre + first_dim as one group: what a rank does before the collective of a sharded answer"""
+        check(lib().spiral_gpu_server_run_pre_sweep(self.h))
+
     def run_post(self, reduce_first: bool = False):
         """lift + fold + finish"""
         check(lib().spiral_gpu_server_run_post(self.h, 1 if reduce_first else 0))

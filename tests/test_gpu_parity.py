@@ -363,11 +363,13 @@ def test_sharded_first_dim_sums_to_unsharded(sa, oracle):
     assert (tot == accs[0]).all()
 
 
-@pytest.mark.parametrize("G", [2, 4, 8])
-def test_distributed_fold_emulated_on_one_gpu(sa, oracle, G):
+@pytest.mark.parametrize("G,graphs", [(2, False), (4, False), (8, False), (4, True)])
+def test_distributed_fold_emulated_on_one_gpu(sa, oracle, G, graphs):
     """j-shards + reduce-scatter + local folds + gather + root folds, the ranks emulated by G servers on one device
-    and the two collectives by torch sums/slices: must equal the single-device answer bit for bit"""
+    and the two collectives by torch sums/slices: must equal the single-device answer bit for bit.  With graphs on,
+    run_pre_sweep / fold_local / fold_root replay as hipGraphs across several queries (fixed buffers, as bench.py)."""
     import torch
+    from spiral_amd import server as SV
 
     O = oracle
     kw = dict(t_gsw=4)
@@ -375,39 +377,45 @@ def test_distributed_fold_emulated_on_one_gpu(sa, oracle, G):
     s = O.shape_of(po)
     cl = O.Client(po, seed=31)
     wl, wr, w, v = cl.pub_params()
-    q = cl.query(201)
+    db = O.gen_db(po, 77)
     dev = torch.device("cuda", 0)
     words = s.num_per * 6 * N
-    srvs, accs = [], []
+    L = words // G
+    srvs, accs, chunks, cts = [], [], [], []
     for g in range(G):
         srv = sa.Server(pg, 0, g * s.dim0 // G, (g + 1) * s.dim0 // G)
         srv.gen_db(77)
         srv.set_pub_params(wl, wr, w, v)
-        srv.set_query(q)
         srv.set_fold_ranks(G)
-        acc = torch.zeros(words, dtype=torch.int64, device=dev)
-        srv.set_acc(acc.data_ptr())
-        srv.run_pre()
-        srv.first_dim()
-        srv.sync()
+        accs.append(torch.zeros(words, dtype=torch.int64, device=dev))
+        chunks.append(torch.zeros(L, dtype=torch.int64, device=dev))
+        cts.append(torch.zeros(6 * N, dtype=torch.int64, device=dev))
+        srv.set_acc(accs[g].data_ptr())
+        srv.use_graphs(graphs)
         srvs.append(srv)
-        accs.append(acc)
-    total = torch.stack(accs).sum(0)  # the reduce part
-    L = words // G
-    cts = []
-    for g in range(G):  # the scatter part + local folds
-        chunk = total[g * L:(g + 1) * L].contiguous()
-        ct = torch.zeros(6 * N, dtype=torch.int64, device=dev)
-        srvs[g].fold_local(chunk.data_ptr(), ct.data_ptr())
-        srvs[g].sync()
-        cts.append(ct)
-    gathered = torch.cat(cts).contiguous()  # the all-gather
-    srvs[0].fold_root(gathered.data_ptr())
-    srvs[0].sync()
-    from spiral_amd import server as SV
-
-    assert_eq(srvs[0].read(SV.BUF_FINAL), O.answer(po, q, wl, wr, w, v, O.gen_db(po, 77)), f"distributed fold G={G}")
-    assert_eq(cl.decode(srvs[0].read(SV.BUF_RESPONSE)), O.db_item(po, 77, 201), "decoded plaintext")
+    gathered = torch.zeros(G * 6 * N, dtype=torch.int64, device=dev)
+    for idx in ((201, 7, 255) if graphs else (201,)):
+        q = cl.query(idx)
+        for g in range(G):
+            srvs[g].set_query(q)
+            if graphs:
+                srvs[g].run_pre_sweep()
+            else:
+                srvs[g].run_pre()
+                srvs[g].first_dim()
+            srvs[g].sync()
+        total = torch.stack(accs).sum(0)  # the reduce part
+        for g in range(G):  # the scatter part + local folds
+            chunks[g].copy_(total[g * L:(g + 1) * L])
+            torch.cuda.synchronize()
+            srvs[g].fold_local(chunks[g].data_ptr(), cts[g].data_ptr())
+            srvs[g].sync()
+        gathered.copy_(torch.cat(cts))  # the all-gather
+        torch.cuda.synchronize()
+        srvs[0].fold_root(gathered.data_ptr())
+        srvs[0].sync()
+        assert_eq(srvs[0].read(SV.BUF_FINAL), O.answer(po, q, wl, wr, w, v, db), f"distributed fold G={G} idx={idx}")
+        assert_eq(cl.decode(srvs[0].read(SV.BUF_RESPONSE)), O.db_item(po, 77, idx), "decoded plaintext")
     for srv in srvs:
         srv.close()
 
