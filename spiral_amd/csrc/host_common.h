@@ -134,7 +134,8 @@ inline size_t expand_g_polys(uint32_t g, uint32_t t_exp, uint32_t t_exp_right) {
 
 // src/spiral.cpp:1664-1743.  cv: 2^g cts (2 PK polys each).
 inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_t t_exp, const uint64_t* w_left, uint32_t t_exp_right,
-                const uint64_t* w_right, uint32_t max_bits_right, uint32_t stopround, const ExpandWork& wk, hipStream_t st) {
+                const uint64_t* w_right, uint32_t max_bits_right, uint32_t stopround, const ExpandWork& wk, hipStream_t st,
+                const uint64_t* query = nullptr) {  // query: the packed query ciphertext when cv[0] does not hold it yet
     // active odd-index ciphertexts of round r (:1701-1702); the even ones are all 2^r
     auto odd_count = [&](uint32_t r) {
         const uint32_t num_in = 1u << r;
@@ -160,6 +161,7 @@ inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_
         ip.cnt_e = cnt_even;
         ip.auto_t = t;
         ip.create_here = r == 0;
+        ip.query = query;
         launch_ntt_inverse_expand(tb, ip, 2 * cnt, st);
         // 2) G^-1(automorph(c)[0]) digits (t_exp / t_exp_right per ct), one launch
         FwdParams fp{};

@@ -91,6 +91,7 @@ struct InvParams {
     uint32_t num_in, cnt_e;
     uint32_t auto_t;  // the round's automorphism x -> x^t
     uint32_t create_here;  // 1: cts with i >= num_in do not exist yet (round 0); 0: the previous round's MAC wrote them
+    const uint64_t* query;  // create_here only, optional: cv[0] is read from here (and written to cv) instead of from cv
 };
 void launch_ntt_inverse(const DeviceTables& t, const InvParams& p, uint32_t store, uint32_t nblocks, hipStream_t s);
 void launch_ntt_inverse_expand(const DeviceTables& t, const InvParams& p, uint32_t nblocks, hipStream_t s);

@@ -239,7 +239,14 @@ __global__ __launch_bounds__(256) void ntt_inverse_kernel(Tables t, InvParams p)
         // written by the previous round's MAC, which has the new cv[i - num_in] in registers
         const bool created = p.create_here && i >= p.num_in;
 #endif
-        const uint64_t* src = p.cv + ((size_t)(created ? i - p.num_in : i) * 2u + row) * kN;
+        // round 0 may take the query ciphertext from its own buffer; cv[0] is then written here as well
+        const bool from_query = p.create_here && p.query != nullptr;
+        const uint64_t* src = (from_query ? p.query : p.cv) + ((size_t)(created ? i - p.num_in : i) * 2u + row) * kN;
+        if (from_query && !created) {
+            uint64_t* dstc = p.cv + ((size_t)i * 2u + row) * kN + tid;
+#pragma unroll
+            for (int r = 0; r < 8; r++) dstc[r * 256] = src[r * 256 + tid];
+        }
         if (created) {
             const uint64_t* ng = p.neg1 + tid;
             const uint64_t* ngs = p.neg1s + tid;

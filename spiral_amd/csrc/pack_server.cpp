@@ -289,9 +289,10 @@ int spiral_gpu_pack_server_answer(spiral_gpu_pack_server* S, const uint64_t* que
     HIP_OK(hipEventRecord(S->ev[0], st));
     // ---- coefficientExpansion + reorientCiphertextsDim1 (src/testing.cpp:1009-1020)
     if (!p.direct_upload) {
-        HIP_OK(hipMemcpyAsync(S->cv.p, S->query.p, 2 * kPolyBytes, hipMemcpyDeviceToDevice, st));
         ExpandWork wk{S->ex_raw.p, S->ex_g.p};
-        run_expand(S->tb, S->cv.p, s.g, p.t_exp, S->w_left.p, p.t_exp_right, S->w_right.p, ell * p.nu2, s.stopround, wk, st);
+        run_expand(S->tb, S->cv.p, s.g, p.t_exp, S->w_left.p, p.t_exp_right, S->w_right.p, ell * p.nu2, s.stopround, wk, st,
+                   s.g ? S->query.p : nullptr);
+        if (s.g == 0) HIP_OK(hipMemcpyAsync(S->cv.p, S->query.p, 2 * kPolyBytes, hipMemcpyDeviceToDevice, st));
         launch_qs1_from_cv(S->cv.p, (uint32_t*)S->qs1.p, s.dim0, 2, st);
     } else {
         launch_qs1_from_cv(S->query.p, (uint32_t*)S->qs1.p, s.dim0, 1, st);

@@ -314,7 +314,35 @@ __global__ __launch_bounds__(kTpb) void scal2mat_kernel(Scal2MatParams p) {
         rec[2] = make_uint4(lo32(out[2][1]), hi32(out[0][1]), hi32(out[1][1]), hi32(out[2][1]));
     }
 }
+// the same product for 16 ciphertexts x 16 slots per workgroup, records only: the 48-byte sweep records of one slot and
+// consecutive j are adjacent in memory, so the workgroup transposes its results through LDS and writes 768-byte runs
+// (one thread per slot and ciphertext writes 16-byte pieces 12 KiB apart instead)
+__global__ __launch_bounds__(kTpb) void scal2mat_rec_kernel(Scal2MatParams p) {
+    __shared__ uint4 sh[16][16][3];  // [slot][ct][piece]
+    const uint32_t zl = threadIdx.x & 15u, al = threadIdx.x >> 4, z0 = blockIdx.x * 16u, a0 = blockIdx.y * 16u;
+    {
+        const uint32_t z = z0 + zl, a = a0 + al;
+        const uint64_t cv1 = p.cv[((size_t)p.cv_pos(a) * 2 + 1) * kN + z];
+        uint64_t out[3][2];
+        scal2mat_slot(p.w, p.g + (size_t)a * p.t_conv * kN + z, p.t_conv, cv1, z, out);
+        sh[zl][al][0] = make_uint4(lo32(out[0][0]), lo32(out[1][0]), lo32(out[2][0]), hi32(out[0][0]));
+        sh[zl][al][1] = make_uint4(hi32(out[1][0]), hi32(out[2][0]), lo32(out[0][1]), lo32(out[1][1]));
+        sh[zl][al][2] = make_uint4(lo32(out[2][1]), hi32(out[0][1]), hi32(out[1][1]), hi32(out[2][1]));
+    }
+    __syncthreads();
+    const uint4* flat = &sh[0][0][0];
+#pragma unroll
+    for (uint32_t m = 0; m < 3; m++) {
+        const uint32_t q = threadIdx.x + 256u * m, zz = q / 48u, within = q - zz * 48u;  // 48 pieces per slot
+        uint4* rec = reinterpret_cast<uint4*>(p.qs + ((size_t)(z0 + zz) * (p.jm_total / 2) + p.j_base + a0) * 12);
+        rec[within] = flat[q];
+    }
+}
 void launch_scal2mat(const Scal2MatParams& p, hipStream_t s) {
+    if (p.count && p.count % 16 == 0 && p.qs && !p.out) {
+        hipLaunchKernelGGL(scal2mat_rec_kernel, dim3(kN / 16, p.count / 16), dim3(kTpb), 0, s, p);
+        return;
+    }
     if (p.count) hipLaunchKernelGGL(scal2mat_kernel, dim3(kBpp, p.count), dim3(kTpb), 0, s, p);
 }
 

@@ -644,9 +644,10 @@ int spiral_gpu_server_expand(spiral_gpu_server* S) {
         HIP_OK(hipMemcpyAsync(S->cv.p, S->query.p, (size_t)S->s.n_bits * 2 * kPolyBytes, hipMemcpyDeviceToDevice, S->stream));
         return 0;
     }
-    HIP_OK(hipMemcpyAsync(S->cv.p, S->query.p, 2 * kPolyBytes, hipMemcpyDeviceToDevice, S->stream));
     ExpandWork wk{S->ex_raw.p, S->ex_g.p};
-    run_expand(S->tb, S->cv.p, S->s.g, p.t_exp, S->w_left.p, p.t_exp_right, S->w_right.p, S->s.ell * p.nu2, S->s.stopround, wk, S->stream);
+    run_expand(S->tb, S->cv.p, S->s.g, p.t_exp, S->w_left.p, p.t_exp_right, S->w_right.p, S->s.ell * p.nu2, S->s.stopround, wk, S->stream,
+               S->s.g ? S->query.p : nullptr);
+    if (S->s.g == 0) HIP_OK(hipMemcpyAsync(S->cv.p, S->query.p, 2 * kPolyBytes, hipMemcpyDeviceToDevice, S->stream));
     return 0;
 }
 

@@ -13,12 +13,10 @@ sweeps = [i for i, r in enumerate(rows) if "sweep_kernel" in r["Kernel_Name"]]
 nq = len(sweeps)
 which = int(sys.argv[sys.argv.index("--query") + 1]) if "--query" in sys.argv else nq // 2
 last = sweeps[which]
-# a query = from the copy of the query ciphertext into the expansion buffer (the first launch of the answer path) to the
-# launch before the next query's copy
-copies = [i for i, r in enumerate(rows) if "copyBuffer" in r["Kernel_Name"]]
-start = max(i for i in copies if i < last)
-later = [i for i in copies if i > last]
-end = (later[0] if later else len(rows)) - 1
+# a query = the launches after the previous response switch up to and including this one's
+ends = [i for i, r in enumerate(rows) if "rescale" in r["Kernel_Name"]]
+start = max([i for i in ends if i < last], default=-1) + 1
+end = min([i for i in ends if i > last], default=len(rows) - 1)
 q = rows[start : end + 1]
 t0 = int(q[0]["Start_Timestamp"])
 tot = defaultdict(lambda: [0, 0.0])
