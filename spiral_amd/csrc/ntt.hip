@@ -30,24 +30,42 @@ __device__ __forceinline__ uint64_t digit_of(uint64_t v, uint32_t k, uint32_t bi
 // values < 2^29); the forward transform wants its inputs below 2m
 __device__ __forceinline__ uint32_t digit_residue(uint32_t d, uint32_t m) { return d < (1u << 28) ? d : d % m; }
 
-// balanced digit k of v under split_and_crt's two carry chains (src/spiral.cpp:283-292, 313-322),
+// balanced digit k of v under split_and_crt's two carry chains (src/spiral.cpp:283-292, 313-322): digits 0..ell/2-1 and
+// ell/2..ell-1 each propagate a carry (piece > 2^bits/2 borrows 2^bits from the next digit), the first chain's last digit
+// never borrows.  The reference walks the chain; the carry into position j of a chain is a pure function of the chain's
+// low j digits L:  carry_1 = [d_0 > B/2],  carry_{j+1} = [d_j > B/2] or [d_j == B/2 and carry_j]  ==  [L_{j+1} > T_{j+1}]
+// with T_j = (B/2)(1 + B + ... + B^(j-1)), so one mask-and-compare replaces the walk.
+struct SDigit {
+    uint32_t sh_chain, sh_digit;  // bit offsets of the chain start and of digit k
+    uint64_t low_mask, thresh_in; // L = (v >> sh_chain) & low_mask ; carry-in = L > thresh_in (j > 0)
+    uint64_t mask, base, thresh;
+    bool has_in, may;
+};
+__device__ __forceinline__ SDigit sdigit_setup(uint32_t k, uint32_t bits, uint32_t ell) {
+    SDigit d;
+    const uint32_t half = ell >> 1, start = k < half ? 0u : half, j = k - start;
+    d.base = 1ull << bits;
+    d.mask = d.base - 1;
+    d.thresh = d.base >> 1;
+    d.sh_chain = start * bits;
+    d.sh_digit = k * bits;
+    d.has_in = j > 0;
+    d.low_mask = (bits * j >= 64) ? ~0ull : ((1ull << (bits * j)) - 1);
+    uint64_t t = 0;
+    for (uint32_t i = 0; i < j; i++) t = (t << bits) + d.thresh;
+    d.thresh_in = t;
+    d.may = k < half ? (k + 1 < half) : true;
+    return d;
+}
 // returned as residues (mod p, mod b); a borrowed digit is piece + Q - 2^bits == piece - 2^bits (mod m)
-__device__ __forceinline__ void sdigit_of(uint64_t v, uint32_t k, uint32_t bits, uint32_t ell, uint32_t& rp, uint32_t& rb) {
-    const uint64_t mask = (1ull << bits) - 1, base = 1ull << bits, thresh = base >> 1;
-    const uint32_t half = ell >> 1;
-    uint32_t kk = k < half ? 0u : half;
-    uint64_t carry = 0, piece = 0;
-    bool borrowed = false;
-    for (; kk <= k; kk++) {
-        piece = digit_of(v, kk, bits, mask) + carry;
-        bool may = (kk < half) ? (kk + 1 < half) : true;
-        borrowed = (piece > thresh) && may;
-        carry = borrowed ? 1 : 0;
-    }
-    if (borrowed) {
-        uint32_t d = (uint32_t)(base - piece);  // in [0, 2^bits/2)
-        rp = kP - d;
-        rb = kB - d;
+__device__ __forceinline__ void sdigit_of(uint64_t v, const SDigit& d, uint32_t& rp, uint32_t& rb) {
+    const uint64_t dig = d.sh_digit >= 64 ? 0ull : ((v >> d.sh_digit) & d.mask);  // shift counts >= 64: 0, as digit_of
+    const uint64_t low = d.sh_chain >= 64 ? 0ull : ((v >> d.sh_chain) & d.low_mask);
+    const uint64_t piece = dig + ((d.has_in && low > d.thresh_in) ? 1u : 0u);
+    if (piece > d.thresh && d.may) {
+        const uint32_t x = (uint32_t)(d.base - piece);  // in [0, 2^bits/2)
+        rp = kP - x;
+        rb = kB - x;
     } else {
         rp = digit_residue((uint32_t)piece, kP);
         rb = digit_residue((uint32_t)piece, kB);
@@ -149,6 +167,8 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
     } else {
         const uint64_t* src = p.src + (size_t)p.src_map(s) * kN;
         const uint64_t mask = (1ull << p.bits) - 1;
+        SDigit sd{};
+        if constexpr (LOAD == LD_SDIGIT) sd = sdigit_setup(k, p.bits, p.ell);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             uint32_t idx = ix_a(tid, r);
@@ -161,7 +181,7 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
                 lo[r] = digit_residue(d, kP);
                 hi[r] = digit_residue(d, kB);
             } else {
-                sdigit_of(v, k, p.bits, p.ell, lo[r], hi[r]);
+                sdigit_of(v, sd, lo[r], hi[r]);
             }
         }
     }
@@ -380,8 +400,9 @@ __global__ __launch_bounds__(256) void fold_chain_kernel(Tables t, FoldChainPara
     const uint32_t m2 = 3u * p.ell, hi_half = ct / p.fold_np, i = ct - hi_half * p.fold_np;
     const uint32_t k0 = LOOP ? 0u : b - s * p.ell, k1 = LOOP ? p.ell : k0 + 1u;
     for (uint32_t k = k0; k < k1; k++) {
+        const SDigit sd = sdigit_setup(k, p.bits, p.ell);
 #pragma unroll
-        for (int r = 0; r < 8; r++) sdigit_of(v[r], k, p.bits, p.ell, lo[r], hi[r]);
+        for (int r = 0; r < 8; r++) sdigit_of(v[r], sd, lo[r], hi[r]);
         if (LOOP && k > k0) __syncthreads();  // the previous transform's last LDS reads
         ntt_forward_block(lo, hi, sh, t.fwd, tid);
         uint64_t* dst = p.dst + (size_t)(((i * 2u + hi_half) * m2 + row + 3u * k) * 2u + c) * kN + tid;
