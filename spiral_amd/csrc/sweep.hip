@@ -54,16 +54,29 @@ __device__ __forceinline__ void store_acc(uint64_t* acc, const uint64_t (&a)[6],
     for (uint32_t r = 0; r < 3; r++) acc[((size_t)(6u * ii + 2u * r + c)) * kN + z] = pack((uint32_t)a[r], (uint32_t)a[3 + r]);
 }
 
-// fast path: nic >= 64.  One wave per (z, block of 64 output columns); 2 waves per workgroup and 8 database
-// loads in flight per wave (tools/sweep_tune.hip: 348 us vs 390 us for 4 waves x unroll 4 at config 2).
-constexpr uint32_t kSweepWaves = 2;
-__global__ __launch_bounds__(kSweepWaves * 64) void sweep_kernel(const uint64_t* __restrict__ db, const uint32_t* __restrict__ qs, uint64_t* __restrict__ acc,
-                                                    uint32_t nic, uint32_t dim0, uint32_t g_log) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * kSweepWaves + (threadIdx.x >> 6));
-    const uint32_t wpz = nic >> 6;  // waves per z
-    const uint32_t z = wave / wpz, ic = (wave - z * wpz) * 64u + lane;
-    const u64x2* dbp = reinterpret_cast<const u64x2*>(db) + (size_t)wave * dim0 * 64u + lane;  // block (z, icb) = wave
+// fast path: nic >= 64.  One wave per (z, block of 64 output columns), 8 database loads in flight per wave
+// (tools/sweep_tune.hip).  A workgroup is kSweepZ waves on CONSECUTIVE z of the same column block: a lane's three results
+// belong to three different accumulator polynomials, 16 KiB apart; the waves of a workgroup trade results through LDS and
+// write full 128-byte lines instead of 1.5 M scattered 8-byte words per launch.
+// What the probes in tools/sweep_tune.hip say about this kernel (config 2, one MI355X): streaming the database alone takes
+// 311-316 us (7.0 TB/s); the MACs, scalar query loads and reductions add nothing to that (315 us); writing the 12.6 MB of
+// results costs 22-40 us whatever their pattern and whenever they are issued (quarter of the bytes: quarter of the cost) --
+// writes interleaved into a saturated HBM read stream are expensive per burst -- 25 us as 128-byte lines (this kernel,
+// 338-342 us), 30-35 us as 64-byte runs or scattered words.  Fewer, fatter waves (persistent, 2 or 4 tiles per wave) lose
+// far more to the lower load concurrency (400-610 us).
+#ifndef SPIRAL_SWEEP_Z
+#define SPIRAL_SWEEP_Z 16
+#endif
+constexpr uint32_t kSweepZ = SPIRAL_SWEEP_Z;  // tools/build_variants.sh can override for A/B runs
+constexpr uint32_t kSweepRow = 64 * 3 + 1;  // packed results per z in LDS, +1 word of padding against bank conflicts
+__global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __restrict__ db, const uint32_t* __restrict__ qs, uint64_t* __restrict__ acc,
+                                                             uint32_t nic, uint32_t dim0, uint32_t g_log) {
+    __shared__ uint64_t sh[kSweepZ * kSweepRow];
+    const uint32_t lane = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t wpz = nic >> 6;  // column blocks (= waves) per z
+    const uint32_t zg = blockIdx.x / wpz, icb = blockIdx.x - zg * wpz;
+    const uint32_t z = zg * kSweepZ + wv, tile = z * wpz + icb;
+    const u64x2* dbp = reinterpret_cast<const u64x2*>(db) + (size_t)tile * dim0 * 64u + lane;  // block (z, icb)
     const uint4* q = reinterpret_cast<const uint4*>(qs) + (size_t)z * dim0 * 3u;  // wave-uniform, 3 x uint4 per j
     uint64_t a[6] = {0, 0, 0, 0, 0, 0};
     for (uint32_t j0 = 0; j0 < dim0; j0 += 128) {  // 128 j = 256 terms per accumulator between reductions
@@ -75,7 +88,21 @@ __global__ __launch_bounds__(kSweepWaves * 64) void sweep_kernel(const uint64_t*
         }
         reduce6(a);
     }
-    store_acc(acc, a, ic, z, nic >> 1, g_log);
+#pragma unroll
+    for (uint32_t r = 0; r < 3; r++) sh[wv * kSweepRow + lane * 3u + r] = pack((uint32_t)a[r], (uint32_t)a[3 + r]);
+    __syncthreads();
+    // 192 (column, row) results x kSweepZ consecutive z: thread -> (result, z) with z fastest.
+    // acc[perm(ii)][r][c][z], ic = ii*2 + c -> polynomial 6*perm(ii) + 2*r + c; perm groups the ciphertexts by ii mod G
+    // (G = 2^g_log ranks of a distributed fold: rank g then owns the contiguous chunk ii = g + G*k, which is what one
+    // reduce-scatter hands it); G = 1 is the identity.
+    const uint32_t num_per = nic >> 1;
+#pragma unroll
+    for (uint32_t m = 0; m < 3; m++) {
+        const uint32_t idx = threadIdx.x + kSweepZ * 64u * m, res = idx / kSweepZ, zz = idx - res * kSweepZ;
+        const uint32_t col = res / 3u, r = res - col * 3u, ic = icb * 64u + col, i0 = ic >> 1, c = ic & 1u;
+        const uint32_t ii = (i0 & ((1u << g_log) - 1u)) * (num_per >> g_log) + (i0 >> g_log);
+        acc[((size_t)(6u * ii + 2u * r + c)) * kN + zg * kSweepZ + zz] = sh[zz * kSweepRow + res];
+    }
 }
 
 // small-geometry path (nic < 64, test sizes only): one thread per (z, ic), no wave-uniform query
@@ -100,8 +127,7 @@ void launch_sweep(const uint64_t* db, const uint32_t* qs, uint64_t* acc, uint32_
     const uint32_t nic = 2 * num_per, dim0 = jm_total / 2;
     if (dim0 == 0) return;
     if (nic >= 64) {
-        const uint32_t waves = kN * (nic >> 6);
-        hipLaunchKernelGGL(sweep_kernel, dim3(waves / kSweepWaves), dim3(kSweepWaves * 64), 0, s, db, qs, acc, nic, dim0, g_log);
+        hipLaunchKernelGGL(sweep_kernel, dim3((kN / kSweepZ) * (nic >> 6)), dim3(kSweepZ * 64), 0, s, db, qs, acc, nic, dim0, g_log);
     } else {
         const uint32_t threads = kN * nic;
         hipLaunchKernelGGL(sweep_small_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, db, qs, acc, nic, dim0, g_log);

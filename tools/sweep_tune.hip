@@ -54,6 +54,169 @@ __device__ __forceinline__ void do_tile(const uint64_t* __restrict__ db, const u
     store_acc(acc, a, ic, z);
 }
 
+// rotated start: wave `tile` begins its j loop at rot(tile) instead of 0, so that concurrently running waves are at
+// different offsets inside their 256 KiB streams (the sum is order independent)
+template <int UNROLL, int MODE>
+__device__ __forceinline__ void do_tile_rot(const uint64_t* __restrict__ db, const uint32_t* __restrict__ qs, uint64_t* __restrict__ acc, uint32_t nic,
+                                            uint32_t dim0, uint32_t tile, uint32_t lane) {
+    const uint32_t wpz = nic >> 6;
+    const uint32_t z = tile / wpz, ic = (tile - z * wpz) * 64u + lane;
+    const u64x2* dbp = reinterpret_cast<const u64x2*>(db) + (size_t)tile * dim0 * 64u + lane;
+    const uint4* q = reinterpret_cast<const uint4*>(qs) + (size_t)z * dim0 * 3u;
+    uint32_t rot;
+    if (MODE == 0) rot = (tile * 8u) & (dim0 - 1u);            // consecutive tiles 8 KiB apart in phase
+    else if (MODE == 1) rot = (tile * 40u) & (dim0 - 1u) & ~7u; // 40 KiB
+    else rot = ((tile * 2654435761u) >> 16) & (dim0 - 1u) & ~7u; // hashed
+    uint64_t a[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t j0 = 0; j0 < dim0; j0 += 128) {
+#pragma unroll UNROLL
+        for (uint32_t jj = j0; jj < j0 + 128u; jj++) {
+            const uint32_t j = (jj + rot) & (dim0 - 1u);
+            const u64x2 w = __builtin_nontemporal_load(dbp + (size_t)j * 64u);
+            mac_j(a, q + j * 3u, w.x, w.y);
+        }
+        reduce6(a);
+    }
+    store_acc(acc, a, ic, z);
+}
+template <int UNROLL, int MODE, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void sweep_rot(const uint64_t* __restrict__ db, const uint32_t* __restrict__ qs, uint64_t* __restrict__ acc,
+                                                        uint32_t nic, uint32_t dim0) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tile = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + (threadIdx.x >> 6));
+    do_tile_rot<UNROLL, MODE>(db, qs, acc, nic, dim0, tile, lane);
+}
+// sensitivity probes on the product kernel's structure: ABL 1 = p-limb MACs only, 2 = query operands from registers (no scalar loads),
+// 3 = both
+template <int UNROLL, int ABL, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void sweep_abl(const uint64_t* __restrict__ db, const uint32_t* __restrict__ qs, uint64_t* __restrict__ acc,
+                                                        uint32_t nic, uint32_t dim0) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tile = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + (threadIdx.x >> 6));
+    const uint32_t wpz = nic >> 6;
+    const uint32_t z = tile / wpz, ic = (tile - z * wpz) * 64u + lane;
+    const u64x2* dbp = reinterpret_cast<const u64x2*>(db) + (size_t)tile * dim0 * 64u + lane;
+    const uint4* q = reinterpret_cast<const uint4*>(qs) + (size_t)z * dim0 * 3u;
+    const uint4 c0 = q[0], c1 = q[1], c2 = q[2];
+    uint64_t a[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t j0 = 0; j0 < dim0; j0 += 128) {
+#pragma unroll UNROLL
+        for (uint32_t j = j0; j < j0 + 128u; j++) {
+            const u64x2 w = __builtin_nontemporal_load(dbp + (size_t)j * 64u);
+            uint4 qa, qb, qc;
+            if (ABL & 2) { qa = c0; qb = c1; qc = c2; } else { qa = q[j * 3u]; qb = q[j * 3u + 1]; qc = q[j * 3u + 2]; }
+            if (ABL & 1) {
+                a[0] += (uint64_t)qa.x * lo32(w.x); a[1] += (uint64_t)qa.y * lo32(w.x); a[2] += (uint64_t)qa.z * lo32(w.x);
+                a[3] += (uint64_t)qb.z * lo32(w.y); a[4] += (uint64_t)qb.w * lo32(w.y); a[5] += (uint64_t)qc.x * lo32(w.y);
+                a[0] ^= hi32(w.x) ^ hi32(w.y);
+            } else {
+                mac6(a, qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, w.x);
+                mac6(a, qb.z, qb.w, qc.x, qc.y, qc.z, qc.w, w.y);
+            }
+        }
+        reduce6(a);
+    }
+    store_acc(acc, a, ic, z);
+}
+// bisect between the read-only probe and the product: FEAT bit 0 = 6 MACs per 16 B with constant operands, bit 1 = 12 MACs,
+// bit 2 = reduce every 128 j, bit 3 = store the result, bit 4 = xor-fold instead of MACs but into 6 accumulators
+template <int UNROLL, int FEAT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void read_bisect(const uint64_t* __restrict__ db, const uint32_t* __restrict__ qs, uint64_t* __restrict__ acc,
+                                                          uint32_t nic, uint32_t dim0) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tile = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + (threadIdx.x >> 6));
+    const uint32_t wpz = nic >> 6;
+    const uint32_t z = tile / wpz, ic = (tile - z * wpz) * 64u + lane;
+    const u64x2* dbp = reinterpret_cast<const u64x2*>(db) + (size_t)tile * dim0 * 64u + lane;
+    const uint4 c0 = reinterpret_cast<const uint4*>(qs)[z * 3u], c1 = reinterpret_cast<const uint4*>(qs)[z * 3u + 1];
+    uint64_t a[6] = {0, 0, 0, 0, 0, 0};
+    if (FEAT & 128) {  // the same 12.6 MB of wave-contiguous stores, but issued BEFORE the stream
+#pragma unroll
+        for (uint32_t r = 0; r < 3; r++) acc[((size_t)tile * 3u + r) * 64u + lane] = pack(c0.x + r, c0.y + lane);
+    }
+    if (FEAT & 256) {  // a quarter of the footprint at the end
+        if ((tile & 3u) == 0)
+#pragma unroll
+            for (uint32_t r = 0; r < 3; r++) acc[((size_t)tile * 3u + r) * 64u + lane] = pack(c0.x + r, c0.y + lane);
+    }
+    for (uint32_t j0 = 0; j0 < dim0; j0 += 128) {
+#pragma unroll UNROLL
+        for (uint32_t j = j0; j < j0 + 128u; j++) {
+            const u64x2 w = __builtin_nontemporal_load(dbp + (size_t)j * 64u);
+            if (FEAT & 2) {
+                mac6(a, c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, w.x);
+                mac6(a, c1.z, c1.w, c0.x, c0.y, c0.z, c0.w, w.y);
+            } else if (FEAT & 1) {
+                mac6(a, c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, w.x ^ w.y);
+            } else if (FEAT & 16) {
+                a[0] ^= w.x; a[1] ^= w.y; a[2] += w.x; a[3] += w.y; a[4] ^= w.x >> 1; a[5] ^= w.y >> 1;
+            } else {
+                a[0] ^= w.x;
+                a[1] ^= w.y;
+            }
+        }
+        if (FEAT & 4) reduce6(a);
+    }
+    if (FEAT & 32) {  // store into a small region (every wave overwrites the same 3 x 512 B x 64 tiles)
+#pragma unroll
+        for (uint32_t r = 0; r < 3; r++) acc[((tile & 63u) * 3u + r) * 64u + lane] = pack((uint32_t)a[r], (uint32_t)a[3 + r]);
+    } else if (FEAT & 64) {  // store wave-contiguous: 3 x 512-byte runs per wave, 12.6 MB in total, no sharing of lines between waves
+#pragma unroll
+        for (uint32_t r = 0; r < 3; r++) acc[((size_t)tile * 3u + r) * 64u + lane] = pack((uint32_t)a[r], (uint32_t)a[3 + r]);
+    } else if (FEAT & 8) store_acc(acc, a, ic, z);
+    else if ((a[0] ^ a[1] ^ a[2] ^ a[3] ^ a[4] ^ a[5]) == 0x1234567ull) acc[tile * 64 + lane] = a[0];
+}
+// ZW waves of a workgroup on consecutive z of one column block; results traded through LDS and written as ZW*8-byte runs
+template <int UNROLL, int ZW, int NTS = 0>
+__global__ __launch_bounds__(ZW * 64) void sweep_zl(const uint64_t* __restrict__ db, const uint32_t* __restrict__ qs, uint64_t* __restrict__ acc,
+                                                    uint32_t nic, uint32_t dim0) {
+    constexpr uint32_t ROW = 64 * 3 + 1;
+    __shared__ uint64_t sh[ZW * ROW];
+    const uint32_t lane = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t wpz = nic >> 6;
+    const uint32_t zg = blockIdx.x / wpz, icb = blockIdx.x - zg * wpz;
+    const uint32_t z = zg * ZW + wv, tile = z * wpz + icb;
+    const u64x2* dbp = reinterpret_cast<const u64x2*>(db) + (size_t)tile * dim0 * 64u + lane;
+    const uint4* q = reinterpret_cast<const uint4*>(qs) + (size_t)z * dim0 * 3u;
+    uint64_t a[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t j0 = 0; j0 < dim0; j0 += 128) {
+#pragma unroll UNROLL
+        for (uint32_t j = j0; j < j0 + 128u; j++) {
+            const u64x2 w = __builtin_nontemporal_load(dbp + (size_t)j * 64u);
+            mac_j(a, q + j * 3u, w.x, w.y);
+        }
+        reduce6(a);
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < 3; r++) sh[wv * ROW + lane * 3u + r] = pack((uint32_t)a[r], (uint32_t)a[3 + r]);
+    __syncthreads();
+#pragma unroll
+    for (uint32_t m = 0; m < 3; m++) {
+        const uint32_t idx = threadIdx.x + ZW * 64u * m, res = idx / ZW, zz = idx - res * ZW;
+        const uint32_t col = res / 3u, r = res - col * 3u, ic = icb * 64u + col, ii = ic >> 1, c = ic & 1u;
+        uint64_t* dst = acc + ((size_t)(6u * ii + 2u * r + c)) * kN + zg * ZW + zz;
+        if (NTS == 1) __builtin_nontemporal_store(sh[zz * ROW + res], dst);
+        else if (NTS == 2) __hip_atomic_store(dst, sh[zz * ROW + res], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else *dst = sh[zz * ROW + res];
+    }
+}
+// read-only probes (no arithmetic beyond an xor, no query): the HBM read ceiling for a given access pattern.
+// PATTERN 0: the sweep's (each wave streams its own contiguous dim0 KiB); 1: grid-interleaved (at step t wave w reads KiB t*nwaves + w)
+template <int UNROLL, int PATTERN, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void read_probe(const uint64_t* __restrict__ db, uint64_t* __restrict__ acc, uint32_t dim0, uint32_t nwaves) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + (threadIdx.x >> 6));
+    const u64x2* base = reinterpret_cast<const u64x2*>(db) + lane;
+    u64x2 x = {0, 0};
+#pragma unroll UNROLL
+    for (uint32_t j = 0; j < dim0; j++) {
+        const size_t chunk = PATTERN == 0 ? (size_t)wave * dim0 + j : (size_t)j * nwaves + wave;
+        const u64x2 w = __builtin_nontemporal_load(base + chunk * 64u);
+        x ^= w;
+    }
+    if ((x.x ^ x.y) == 0x1234567ull) acc[wave * 64 + lane] = x.x;  // practically never
+}
+
 template <int UNROLL, bool NT, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void sweep_v(const uint64_t* __restrict__ db, const uint32_t* __restrict__ qs, uint64_t* __restrict__ acc,
                                                       uint32_t nic, uint32_t dim0) {
@@ -124,6 +287,48 @@ int main(int argc, char** argv) {
         V("u6 nt w2", hipLaunchKernelGGL((sweep_v<6, true, 2>), dim3(kN * (nic / 64) / 2), dim3(128), 0, 0, db, qs, acc, nic, dim0)),
         V("u6 nt w4", hipLaunchKernelGGL((sweep_v<6, true, 4>), dim3(kN * (nic / 64) / 4), dim3(256), 0, 0, db, qs, acc, nic, dim0)),
         V("u12 nt w4", hipLaunchKernelGGL((sweep_v<12, true, 4>), dim3(kN * (nic / 64) / 4), dim3(256), 0, 0, db, qs, acc, nic, dim0)),
+        V("rot8K  u8 w2", hipLaunchKernelGGL((sweep_rot<8, 0, 2>), dim3(kN * (nic / 64) / 2), dim3(128), 0, 0, db, qs, acc, nic, dim0)),
+        V("rot40K u8 w2", hipLaunchKernelGGL((sweep_rot<8, 1, 2>), dim3(kN * (nic / 64) / 2), dim3(128), 0, 0, db, qs, acc, nic, dim0)),
+        V("rotHash u8 w2", hipLaunchKernelGGL((sweep_rot<8, 2, 2>), dim3(kN * (nic / 64) / 2), dim3(128), 0, 0, db, qs, acc, nic, dim0)),
+        V("R-abl half MACs u8 w2", hipLaunchKernelGGL((sweep_abl<8, 1, 2>), dim3(kN * (nic / 64) / 2), dim3(128), 0, 0, db, qs, acc, nic, dim0)),
+        V("R-abl no s_load u8 w2", hipLaunchKernelGGL((sweep_abl<8, 2, 2>), dim3(kN * (nic / 64) / 2), dim3(128), 0, 0, db, qs, acc, nic, dim0)),
+        V("R-abl both u8 w2", hipLaunchKernelGGL((sweep_abl<8, 3, 2>), dim3(kN * (nic / 64) / 2), dim3(128), 0, 0, db, qs, acc, nic, dim0)),
+        V("u16 nt w2", hipLaunchKernelGGL((sweep_v<16, true, 2>), dim3(kN * (nic / 64) / 2), dim3(128), 0, 0, db, qs, acc, nic, dim0)),
+        V("u16 nt w1", hipLaunchKernelGGL((sweep_v<16, true, 1>), dim3(kN * (nic / 64)), dim3(64), 0, 0, db, qs, acc, nic, dim0)),
+        V("u8 nt w1", hipLaunchKernelGGL((sweep_v<8, true, 1>), dim3(kN * (nic / 64)), dim3(64), 0, 0, db, qs, acc, nic, dim0)),
+        V("zl8 u8", hipLaunchKernelGGL((sweep_zl<8, 8>), dim3(kN / 8 * (nic / 64)), dim3(512), 0, 0, db, qs, acc, nic, dim0)),
+        V("zl16 u8", hipLaunchKernelGGL((sweep_zl<8, 16>), dim3(kN / 16 * (nic / 64)), dim3(1024), 0, 0, db, qs, acc, nic, dim0)),
+        V("zl4 u8", hipLaunchKernelGGL((sweep_zl<8, 4>), dim3(kN / 4 * (nic / 64)), dim3(256), 0, 0, db, qs, acc, nic, dim0)),
+        V("zl8 u6", hipLaunchKernelGGL((sweep_zl<6, 8>), dim3(kN / 8 * (nic / 64)), dim3(512), 0, 0, db, qs, acc, nic, dim0)),
+        V("zl8 u16", hipLaunchKernelGGL((sweep_zl<16, 8>), dim3(kN / 8 * (nic / 64)), dim3(512), 0, 0, db, qs, acc, nic, dim0)),
+        V("zl8 u8 nt-store", hipLaunchKernelGGL((sweep_zl<8, 8, 1>), dim3(kN / 8 * (nic / 64)), dim3(512), 0, 0, db, qs, acc, nic, dim0)),
+        V("zl16 u8 nt-store", hipLaunchKernelGGL((sweep_zl<8, 16, 1>), dim3(kN / 16 * (nic / 64)), dim3(1024), 0, 0, db, qs, acc, nic, dim0)),
+        V("zl8 u8 sys-store", hipLaunchKernelGGL((sweep_zl<8, 8, 2>), dim3(kN / 8 * (nic / 64)), dim3(512), 0, 0, db, qs, acc, nic, dim0)),
+        V("zl16 u8 sys-store", hipLaunchKernelGGL((sweep_zl<8, 16, 2>), dim3(kN / 16 * (nic / 64)), dim3(1024), 0, 0, db, qs, acc, nic, dim0)),
+        V("persist 4096w u8 w2", hipLaunchKernelGGL((sweep_p<8, true, 2>), dim3(2048), dim3(128), 0, 0, db, qs, acc, nic, dim0, kN * (nic / 64))),
+        V("persist 2048w u8 w2", hipLaunchKernelGGL((sweep_p<8, true, 2>), dim3(1024), dim3(128), 0, 0, db, qs, acc, nic, dim0, kN * (nic / 64))),
+        V("persist 4096w u16 w2", hipLaunchKernelGGL((sweep_p<16, true, 2>), dim3(2048), dim3(128), 0, 0, db, qs, acc, nic, dim0, kN * (nic / 64))),
+        V("persist 2048w u16 w2", hipLaunchKernelGGL((sweep_p<16, true, 2>), dim3(1024), dim3(128), 0, 0, db, qs, acc, nic, dim0, kN * (nic / 64))),
+        V("persist 4096w u8 w1", hipLaunchKernelGGL((sweep_p<8, true, 1>), dim3(4096), dim3(64), 0, 0, db, qs, acc, nic, dim0, kN * (nic / 64))),
+        V("persist 6144w u8 w2", hipLaunchKernelGGL((sweep_p<8, true, 2>), dim3(3072), dim3(128), 0, 0, db, qs, acc, nic, dim0, kN * (nic / 64))),
+        V("16384 waves half-j? n/a", hipLaunchKernelGGL((sweep_p<8, true, 2>), dim3(1536), dim3(128), 0, 0, db, qs, acc, nic, dim0, kN * (nic / 64))),
+        V("R-bis plain", hipLaunchKernelGGL((read_bisect<8, 0, 2>), dim3(kN * (nic / 64) / 2), dim3(128), 0, 0, db, qs, acc, nic, dim0)),
+        V("R-bis 6acc-xor", hipLaunchKernelGGL((read_bisect<8, 16, 2>), dim3(kN * (nic / 64) / 2), dim3(128), 0, 0, db, qs, acc, nic, dim0)),
+        V("R-bis 6mac", hipLaunchKernelGGL((read_bisect<8, 1, 2>), dim3(kN * (nic / 64) / 2), dim3(128), 0, 0, db, qs, acc, nic, dim0)),
+        V("R-bis 12mac", hipLaunchKernelGGL((read_bisect<8, 2, 2>), dim3(kN * (nic / 64) / 2), dim3(128), 0, 0, db, qs, acc, nic, dim0)),
+        V("R-bis 12mac+reduce", hipLaunchKernelGGL((read_bisect<8, 6, 2>), dim3(kN * (nic / 64) / 2), dim3(128), 0, 0, db, qs, acc, nic, dim0)),
+        V("R-bis 12mac+reduce+store", hipLaunchKernelGGL((read_bisect<8, 14, 2>), dim3(kN * (nic / 64) / 2), dim3(128), 0, 0, db, qs, acc, nic, dim0)),
+        V("R-bis 12mac+reduce+SMALLstore", hipLaunchKernelGGL((read_bisect<8, 6 + 32, 2>), dim3(kN * (nic / 64) / 2), dim3(128), 0, 0, db, qs, acc, nic, dim0)),
+        V("R-bis 12mac+reduce+WAVEstore", hipLaunchKernelGGL((read_bisect<8, 6 + 64, 2>), dim3(kN * (nic / 64) / 2), dim3(128), 0, 0, db, qs, acc, nic, dim0)),
+        V("R-bis 12mac+reduce+EARLYstore", hipLaunchKernelGGL((read_bisect<8, 6 + 128, 2>), dim3(kN * (nic / 64) / 2), dim3(128), 0, 0, db, qs, acc, nic, dim0)),
+        V("R-bis 12mac+reduce+EARLYquarter", hipLaunchKernelGGL((read_bisect<8, 6 + 256, 2>), dim3(kN * (nic / 64) / 2), dim3(128), 0, 0, db, qs, acc, nic, dim0)),
+        V("R-bis plain+store", hipLaunchKernelGGL((read_bisect<8, 8, 2>), dim3(kN * (nic / 64) / 2), dim3(128), 0, 0, db, qs, acc, nic, dim0)),
+        V("R-bis plain+reduce", hipLaunchKernelGGL((read_bisect<8, 4, 2>), dim3(kN * (nic / 64) / 2), dim3(128), 0, 0, db, qs, acc, nic, dim0)),
+        V("READ-ONLY own-stream u8 w2", hipLaunchKernelGGL((read_probe<8, 0, 2>), dim3(kN * (nic / 64) / 2), dim3(128), 0, 0, db, acc, dim0, kN * (nic / 64))),
+        V("READ-ONLY own-stream u16 w2", hipLaunchKernelGGL((read_probe<16, 0, 2>), dim3(kN * (nic / 64) / 2), dim3(128), 0, 0, db, acc, dim0, kN * (nic / 64))),
+        V("READ-ONLY interleaved u8 w2", hipLaunchKernelGGL((read_probe<8, 1, 2>), dim3(kN * (nic / 64) / 2), dim3(128), 0, 0, db, acc, dim0, kN * (nic / 64))),
+        V("READ-ONLY interleaved u8 w4", hipLaunchKernelGGL((read_probe<8, 1, 4>), dim3(kN * (nic / 64) / 4), dim3(256), 0, 0, db, acc, dim0, kN * (nic / 64))),
+        V("READ-ONLY interleaved u16 w4", hipLaunchKernelGGL((read_probe<16, 1, 4>), dim3(kN * (nic / 64) / 4), dim3(256), 0, 0, db, acc, dim0, kN * (nic / 64))),
         V("persist 8192w u4 nt w1", hipLaunchKernelGGL((sweep_p<4, true, 1>), dim3(8192), dim3(64), 0, 0, db, qs, acc, nic, dim0, kN * (nic / 64))),
     };
     (void)ntiles;
@@ -141,7 +346,7 @@ int main(int argc, char** argv) {
             if (round > 0) times[v].push_back(ms);
             if (round == 0) {
                 hipMemcpy(v == 0 ? href.data() : hacc.data(), acc, accw * 8, hipMemcpyDeviceToHost);
-                if (v > 0 && href != hacc) printf("!! variant %s differs from variant 0\n", vs[v].name);
+                if (v > 0 && vs[v].name[0] != 'R' && href != hacc) printf("!! variant %s differs from variant 0\n", vs[v].name);
             }
         }
     }
