@@ -187,17 +187,18 @@ void launch_fold_key(const uint64_t* gsw, uint64_t* key, uint32_t dims, uint32_t
 void launch_fold_key_from_reoriented(const uint64_t* q_re, const uint64_t* qneg_re, uint64_t* key, uint32_t m2, hipStream_t s);
 
 // ---- first-dimension sweep (sweep.hip) -----------------------------------------------------------------
-// device DB layout: common.h db_word_index(z, j - j0, ic, m), ic = ii*2 + c, nic = 2*num_per.
+// device DB layout: common.h (packed 7-byte words for real geometries, plain for tiny ones), ic = ii*2 + c, nic = 2*num_per.
 // acc[ii][r][c][z] PK (fields < m).
 // g_log: log2 of the number of ranks of a distributed fold (accumulators grouped by ii mod 2^g_log), 0 = natural order
 void launch_sweep(const uint64_t* db, const uint32_t* qs, uint64_t* acc, uint32_t num_per, uint32_t jm_total, uint32_t g_log, hipStream_t s);
-// reference DB layout (src/spiral.cpp:1139-1153) -> device layout, for the j-range [j0, j0 + dim0_shard) and
-// nz consecutive z slabs starting at the given pointers
-void launch_db_relayout(const uint64_t* db_ref, uint64_t* db_dev, uint32_t num_per, uint32_t dim0, uint32_t j0, uint32_t dim0_shard, uint32_t nz,
-                        hipStream_t s);
+// reference DB layout (src/spiral.cpp:1139-1153) -> device layout, for the j-range [j0, j0 + dim0_shard): db_ref holds the nz
+// consecutive z slabs z0 .. z0+nz-1, db_dev is the base of the shard's device database
+void launch_db_relayout(const uint64_t* db_ref, uint64_t* db_dev, uint32_t num_per, uint32_t dim0, uint32_t j0, uint32_t dim0_shard, uint32_t z0,
+                        uint32_t nz, hipStream_t s);
 // reference reorientCiphertexts layout (z, j, m, r_pad4) u64 -> sweep query records
 void launch_qs_from_reoriented(const uint64_t* reoriented, uint32_t* qs, uint32_t jm_total, hipStream_t s);
-void launch_fill_db_random(uint64_t* db_dev, uint64_t nwords, uint64_t seed, hipStream_t s);
+void launch_fill_db_random(uint64_t* db_dev, uint32_t num_per, uint32_t dim0_shard, uint64_t seed, hipStream_t s);
+void launch_fill_words_random(uint64_t* db_dev, uint64_t nwords, uint64_t seed, hipStream_t s);
 
 // ---- SpiralPack (pack.hip; reference src/testing.cpp) -----------------------------------------------------------
 // device DB layout, 1 x 1 plaintexts: word(z, j, ii) at (((z*nblk + ii/W)*(dim0/2) + j/2)*W + ii%W)*2 + (j&1), W = min(64, num_per)

@@ -234,10 +234,8 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
         const uint32_t mc = b & 3u, m = mc >> 1, c = mc & 1u;
         const uint32_t ii = (uint32_t)(item % p.num_per), j = (uint32_t)(item / p.num_per);
         const uint32_t ic = ii * 2u + c, nic = 2u * p.num_per;
-        const size_t zstride = (size_t)p.dim0_shard * nic * 2u;  // words per z slab
-        uint64_t* dst = p.dst + db_word_index(0, j - p.j0, ic, m, nic, p.dim0_shard);
 #pragma unroll
-        for (int r = 0; r < 8; r++) dst[(size_t)(r * 256u + tid) * zstride] = pack(lo[r], hi[r]);  // slab index = pk_pos(slot)
+        for (int r = 0; r < 8; r++) db_put_word(p.dst, r * 256u + tid, j - p.j0, ic, m, nic, p.dim0_shard, pack(lo[r], hi[r]));  // z = pk_pos(slot)
     }
 }
 

@@ -255,7 +255,7 @@ int spiral_gpu_pack_server_load_db(spiral_gpu_pack_server* S, uint32_t trial, co
 int spiral_gpu_pack_server_fill_db_random(spiral_gpu_pack_server* S, uint64_t seed) {
     if (!S) return fail("null server");
     HIP_OK(hipSetDevice(S->device));
-    launch_fill_db_random(S->db.p, S->db.words, seed, S->stream);
+    launch_fill_words_random(S->db.p, S->db.words, seed, S->stream);
     HIP_OK(hipStreamSynchronize(S->stream));
     S->have_db = true;
     return 0;

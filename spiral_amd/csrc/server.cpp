@@ -54,7 +54,7 @@ int srv_alloc(spiral_gpu_server* S) {
     const spiral_gpu_params& p = S->p;
     const spiral_gpu_shape& s = S->s;
     const size_t nic = 2 * (size_t)s.num_per;
-    if (S->db.alloc((size_t)kN * S->dim0_shard * nic * 2)) return -1;
+    if (S->db.alloc(db_device_words((uint32_t)nic, S->dim0_shard))) return -1;
     if (S->w_left.alloc((size_t)s.n_left * 2 * p.t_exp * kN)) return -1;
     if (S->w_right.alloc((size_t)s.n_right * 2 * p.t_exp_right * kN)) return -1;
     if (S->w.alloc((size_t)3 * 2 * p.t_conv * kN)) return -1;
@@ -328,12 +328,12 @@ int spiral_gpu_multiply_query_by_database(uint64_t* output, const uint64_t* reor
     Scratch sc;
     const size_t db_words = (size_t)kN * dim0 * num_per * 4;
     uint64_t* d_ref = sc.upload(database, db_words);
-    uint64_t* d_db = sc.get(db_words);
+    uint64_t* d_db = sc.get(db_device_words((uint32_t)(2 * num_per), (uint32_t)dim0));
     uint64_t* d_re = sc.upload(reorientedCiphertexts, (size_t)kN * dim0 * 8);
     uint64_t* d_qs = sc.get((size_t)kN * dim0 * 6);
     uint64_t* d_acc = sc.get(num_per * 6 * kN);
     if (!d_ref || !d_db || !d_re || !d_qs || !d_acc) return fail("device allocation/upload failed");
-    launch_db_relayout(d_ref, d_db, (uint32_t)num_per, (uint32_t)dim0, 0, (uint32_t)dim0, kN, 0);
+    launch_db_relayout(d_ref, d_db, (uint32_t)num_per, (uint32_t)dim0, 0, (uint32_t)dim0, 0, kN, 0);
     launch_qs_from_reoriented(d_re, (uint32_t*)d_qs, (uint32_t)(2 * dim0), 0);
     launch_sweep(d_db, (const uint32_t*)d_qs, d_acc, (uint32_t)num_per, (uint32_t)(2 * dim0), 0, 0);
     return download_pk(sc, d_acc, identity_map(), output, num_per * 6);
@@ -561,8 +561,9 @@ int spiral_gpu_server_load_db(spiral_gpu_server* S, const uint64_t* database) {
     HIP_OK(hipSetDevice(S->device));
     // stage the reference-layout database one z-slab group at a time and re-lay the shard
     const size_t per_z_ref = (size_t)S->s.num_per * 2 * S->s.dim0 * 2;
-    const size_t per_z_dev = (size_t)S->dim0_shard * 2 * S->s.num_per * 2;
-    const uint32_t zchunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(kN, ((size_t)64 << 20) / per_z_ref));
+    size_t stage_bytes = (size_t)64 << 20;
+    if (const char* e = getenv("SPIRAL_DB_STAGE_BYTES")) stage_bytes = strtoull(e, nullptr, 10);  // tests: force several staging passes
+    const uint32_t zchunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(kN, stage_bytes / (per_z_ref * sizeof(uint64_t))));
     DevBuf st;
     if (st.alloc(per_z_ref * zchunk)) return -1;
     for (uint32_t z = 0; z < kN; z += zchunk) {
@@ -572,7 +573,7 @@ int spiral_gpu_server_load_db(spiral_gpu_server* S, const uint64_t* database) {
             st.release();
             return fail("database upload failed");
         }
-        launch_db_relayout(st.p, S->db.p + (size_t)z * per_z_dev, S->s.num_per, S->s.dim0, S->j0, S->dim0_shard, nz, S->stream);
+        launch_db_relayout(st.p, S->db.p, S->s.num_per, S->s.dim0, S->j0, S->dim0_shard, z, nz, S->stream);
         if (hipStreamSynchronize(S->stream) != hipSuccess) {
             st.release();
             return fail("database relayout failed");
@@ -609,7 +610,7 @@ int spiral_gpu_server_gen_db(spiral_gpu_server* S, uint64_t seed) {
 int spiral_gpu_server_fill_db_random(spiral_gpu_server* S, uint64_t seed) {
     if (!S) return fail("null server");
     HIP_OK(hipSetDevice(S->device));
-    launch_fill_db_random(S->db.p, S->db.words, seed, S->stream);
+    launch_fill_db_random(S->db.p, S->s.num_per, S->dim0_shard, seed, S->stream);
     HIP_OK(hipStreamSynchronize(S->stream));
     S->have_db = true;
     return 0;

@@ -7,10 +7,10 @@
 // (ii, c) and JM = 2*dim0 terms (j, m): 6 integer MADs per 8-byte database word, so the kernel is bound
 // by streaming the database once from HBM.  MFMA does not apply (32x32->64-bit modular integer MACs).
 //
-// Device database layout (built at load time, any re-layout is internal; common.h db_word_index):
-//     [z][column block of 64][j][lane][m], u64 = p-limb | b-limb << 32
-// so that one wave reads 64 lanes x 16 B = 1 KiB per step (lane = column, both m of one j) and its dim0
-// steps are strictly sequential addresses (a dim0 KiB contiguous stream per wave).  The query is stored as one 48-byte record per (z, j):
+// Device database layout (built at load time, any re-layout is internal; common.h): tiles (z, block of 64 columns), each
+// one sequential stream; a word is stored in 7 bytes (two 28-bit residues), 8 j of a lane = 112 bytes = 7 x 16-byte loads,
+// so one wave reads 64 lanes x 16 B = 1 KiB per instruction and 7/8 of the reference's database bytes per query.
+// The query is stored as one 48-byte record per (z, j):
 //     {p-limb rows 0..2 | b-limb rows 0..2} for m = 0, then the same for m = 1      (12 u32)
 // which are wave-uniform (a wave works on one z) and are fetched through the scalar cache into SGPRs,
 // so the vector memory pipe carries only the database stream.  Accumulation is v_mad_u64_u32 into six
@@ -54,37 +54,81 @@ __device__ __forceinline__ void store_acc(uint64_t* acc, const uint64_t (&a)[6],
     for (uint32_t r = 0; r < 3; r++) acc[((size_t)(6u * ii + 2u * r + c)) * kN + z] = pack((uint32_t)a[r], (uint32_t)a[3 + r]);
 }
 
-// fast path: nic >= 64.  One wave per (z, block of 64 output columns), 8 database loads in flight per wave
-// (tools/sweep_tune.hip).  A workgroup is kSweepZ waves on CONSECUTIVE z of the same column block: a lane's three results
-// belong to three different accumulator polynomials, 16 KiB apart; the waves of a workgroup trade results through LDS and
-// write full 128-byte lines instead of 1.5 M scattered 8-byte words per launch.
-// What the probes in tools/sweep_tune.hip say about this kernel (config 2, one MI355X): streaming the database alone takes
-// 311-316 us (7.0 TB/s); the MACs, scalar query loads and reductions add nothing to that (315 us); writing the 12.6 MB of
-// results costs 22-40 us whatever their pattern and whenever they are issued (quarter of the bytes: quarter of the cost) --
-// writes interleaved into a saturated HBM read stream are expensive per burst -- 25 us as 128-byte lines (this kernel,
-// 338-342 us), 30-35 us as 64-byte runs or scattered words.  Fewer, fatter waves (persistent, 2 or 4 tiles per wave) lose
-// far more to the lower load concurrency (400-610 us).
+// ---- fast path: packed database (nic >= 64, dim0 % 8 == 0) ---------------------------------------------------------------
+// One wave per (z, block of 64 output columns).  A workgroup is kSweepZ waves on CONSECUTIVE z of the same column block: a
+// lane's three results belong to three different accumulator polynomials, 16 KiB apart; the waves of a workgroup trade
+// results through LDS and write full 128-byte lines instead of 1.5 M scattered 8-byte words per launch.
+// What the probes in tools/sweep_tune.hip say (config 2, one MI355X): streaming an 8-byte-per-word database alone takes
+// 311-316 us (7.0 TB/s); the MACs, scalar query loads and reductions add nothing to that; writing the 12.6 MB of results
+// costs 22-40 us whatever their pattern and whenever they are issued (writes interleaved into a saturated HBM read stream
+// are expensive per burst), 25 us as 128-byte lines; fewer, fatter waves (persistent, 2 or 4 tiles per wave) lose far more
+// to the lower load concurrency (400-610 us).  Packing the words in 7 bytes removes an eighth of the stream for ~2 extra
+// VALU instructions per residue (funnel shift + mask), which the memory-bound loop absorbs: 343 -> 295 us.
 #ifndef SPIRAL_SWEEP_Z
 #define SPIRAL_SWEEP_Z 16
 #endif
 constexpr uint32_t kSweepZ = SPIRAL_SWEEP_Z;  // tools/build_variants.sh can override for A/B runs
-constexpr uint32_t kSweepRow = 64 * 3 + 1;  // packed results per z in LDS, +1 word of padding against bank conflicts
+constexpr uint32_t kSweepRow = 64 * 3 + 1;    // packed results per z in LDS, +1 word of padding against bank conflicts
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int T>
+__device__ __forceinline__ uint32_t field28(const uint32_t (&d)[28]) {  // 28-bit field T of a 112-byte group
+    constexpr uint32_t bit = 28u * T, w = bit >> 5, sh = bit & 31u;
+    if constexpr (sh <= 4)
+        return (d[w] >> sh) & 0xFFFFFFFu;
+    else
+        return __builtin_amdgcn_alignbit(d[w + 1], d[w], sh) & 0xFFFFFFFu;
+}
+// j = JJ of the group: fields 4JJ .. 4JJ+3 = (p, b) of m = 0, (p, b) of m = 1, against the 12-dword query record of that j
+template <int JJ>
+__device__ __forceinline__ void mac_packed_j(uint64_t (&a)[6], const uint4* q, const uint32_t (&d)[28]) {
+    const uint4 qa = q[0], qb = q[1], qc = q[2];
+    const uint32_t p0 = field28<4 * JJ>(d), b0 = field28<4 * JJ + 1>(d), p1 = field28<4 * JJ + 2>(d), b1 = field28<4 * JJ + 3>(d);
+    a[0] += (uint64_t)qa.x * p0;
+    a[1] += (uint64_t)qa.y * p0;
+    a[2] += (uint64_t)qa.z * p0;
+    a[3] += (uint64_t)qa.w * b0;
+    a[4] += (uint64_t)qb.x * b0;
+    a[5] += (uint64_t)qb.y * b0;
+    a[0] += (uint64_t)qb.z * p1;
+    a[1] += (uint64_t)qb.w * p1;
+    a[2] += (uint64_t)qc.x * p1;
+    a[3] += (uint64_t)qc.y * b1;
+    a[4] += (uint64_t)qc.z * b1;
+    a[5] += (uint64_t)qc.w * b1;
+}
 __global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __restrict__ db, const uint32_t* __restrict__ qs, uint64_t* __restrict__ acc,
                                                              uint32_t nic, uint32_t dim0, uint32_t g_log) {
     __shared__ uint64_t sh[kSweepZ * kSweepRow];
     const uint32_t lane = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t wpz = nic >> 6;  // column blocks (= waves) per z
     const uint32_t zg = blockIdx.x / wpz, icb = blockIdx.x - zg * wpz;
-    const uint32_t z = zg * kSweepZ + wv, tile = z * wpz + icb;
-    const u64x2* dbp = reinterpret_cast<const u64x2*>(db) + (size_t)tile * dim0 * 64u + lane;  // block (z, icb)
+    const uint32_t z = zg * kSweepZ + wv, tile = z * wpz + icb, groups = dim0 >> 3;
+    const u32x4* dbp = reinterpret_cast<const u32x4*>(db) + (size_t)tile * groups * 7u * 64u + lane;
     const uint4* q = reinterpret_cast<const uint4*>(qs) + (size_t)z * dim0 * 3u;  // wave-uniform, 3 x uint4 per j
     uint64_t a[6] = {0, 0, 0, 0, 0, 0};
-    for (uint32_t j0 = 0; j0 < dim0; j0 += 128) {  // 128 j = 256 terms per accumulator between reductions
-        const uint32_t jend = min(j0 + 128u, dim0);
-#pragma unroll 8
-        for (uint32_t j = j0; j < jend; j++) {
-            const u64x2 w = __builtin_nontemporal_load(dbp + (size_t)j * 64u);
-            mac_j(a, q + j * 3u, w.x, w.y);
+    for (uint32_t g0 = 0; g0 < groups; g0 += 16) {  // 16 groups = 128 j = 256 terms per accumulator between reductions
+        const uint32_t gend = min(g0 + 16u, groups);
+#pragma unroll 2
+        for (uint32_t g = g0; g < gend; g++) {
+            uint32_t d[28];
+#pragma unroll
+            for (uint32_t k = 0; k < 7; k++) {
+                const u32x4 v = __builtin_nontemporal_load(dbp + ((size_t)g * 7u + k) * 64u);
+                d[4 * k] = v.x;
+                d[4 * k + 1] = v.y;
+                d[4 * k + 2] = v.z;
+                d[4 * k + 3] = v.w;
+            }
+            const uint4* qg = q + (size_t)g * 24u;
+            mac_packed_j<0>(a, qg, d);
+            mac_packed_j<1>(a, qg + 3, d);
+            mac_packed_j<2>(a, qg + 6, d);
+            mac_packed_j<3>(a, qg + 9, d);
+            mac_packed_j<4>(a, qg + 12, d);
+            mac_packed_j<5>(a, qg + 15, d);
+            mac_packed_j<6>(a, qg + 18, d);
+            mac_packed_j<7>(a, qg + 21, d);
         }
         reduce6(a);
     }
@@ -105,17 +149,16 @@ __global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __r
     }
 }
 
-// small-geometry path (nic < 64, test sizes only): one thread per (z, ic), no wave-uniform query
+// small-geometry path (plain layout: nic < 64 or dim0 % 8 != 0, test sizes only): one thread per (z, ic), no wave-uniform query
 __global__ __launch_bounds__(256) void sweep_small_kernel(const uint64_t* __restrict__ db, const uint32_t* __restrict__ qs,
                                                           uint64_t* __restrict__ acc, uint32_t nic, uint32_t dim0, uint32_t g_log) {
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     const uint32_t z = g / nic, ic = g - z * nic;
     if (z >= kN) return;
-    const ulonglong2* dbp = reinterpret_cast<const ulonglong2*>(db + db_word_index(z, 0, ic, 0, nic, dim0));
     const uint4* q = reinterpret_cast<const uint4*>(qs) + (size_t)z * dim0 * 3u;
     uint64_t a[6] = {0, 0, 0, 0, 0, 0};
     for (uint32_t j = 0; j < dim0; j++) {
-        const ulonglong2 w = dbp[(size_t)j * nic];  // nic < 64: one block per z, block width = nic
+        const ulonglong2 w = *reinterpret_cast<const ulonglong2*>(db + db_word_index(z, j, ic, 0, nic, dim0));
         mac_j(a, q + j * 3u, w.x, w.y);
         if ((j & 127u) == 127u) reduce6(a);
     }
@@ -126,7 +169,7 @@ __global__ __launch_bounds__(256) void sweep_small_kernel(const uint64_t* __rest
 void launch_sweep(const uint64_t* db, const uint32_t* qs, uint64_t* acc, uint32_t num_per, uint32_t jm_total, uint32_t g_log, hipStream_t s) {
     const uint32_t nic = 2 * num_per, dim0 = jm_total / 2;
     if (dim0 == 0) return;
-    if (nic >= 64) {
+    if (db_packed(nic, dim0)) {
         hipLaunchKernelGGL(sweep_kernel, dim3((kN / kSweepZ) * (nic >> 6)), dim3(kSweepZ * 64), 0, s, db, qs, acc, nic, dim0, g_log);
     } else {
         const uint32_t threads = kN * nic;
@@ -134,25 +177,27 @@ void launch_sweep(const uint64_t* db, const uint32_t* qs, uint64_t* acc, uint32_
     }
 }
 
-// reference layout (src/spiral.cpp:1139-1153): z*(num_per*2*dim0*2) + ii*(2*dim0*2) + c*(dim0*2) + j*2 + m
+// reference layout (src/spiral.cpp:1139-1153): z*(num_per*2*dim0*2) + ii*(2*dim0*2) + c*(dim0*2) + j*2 + m.
+// `ref` holds the nz slabs z0 .. z0+nz-1 (reference slot order); `dev` is the base of the shard's device database.
 __global__ __launch_bounds__(256) void db_relayout_kernel(const uint64_t* __restrict__ ref, uint64_t* __restrict__ dev, uint32_t num_per, uint32_t dim0,
-                                                          uint32_t j0, uint32_t dim0_shard, uint32_t nz) {
+                                                          uint32_t j0, uint32_t dim0_shard, uint32_t z0, uint32_t nz) {
     const uint32_t nic = 2 * num_per;
-    const size_t o = (size_t)blockIdx.x * 256u + threadIdx.x;  // output word index
+    const size_t o = (size_t)blockIdx.x * 256u + threadIdx.x;  // word of the shard, slab-major
     const size_t per_z = (size_t)dim0_shard * nic * 2u;
-    const uint32_t z = (uint32_t)(o / per_z);
-    if (z >= nz) return;
-    size_t rem = o - (size_t)z * per_z;
+    const uint32_t zl = (uint32_t)(o / per_z);
+    if (zl >= nz) return;
+    size_t rem = o - (size_t)zl * per_z;
     const uint32_t m = (uint32_t)(rem & 1u);
     rem >>= 1;
     const uint32_t ic = (uint32_t)(rem % nic), jl = (uint32_t)(rem / nic);
     const uint32_t ii = ic >> 1, c = ic & 1u, j = j0 + jl;
-    dev[db_word_index(pk_pos(z), jl, ic, m, nic, dim0_shard)] = ref[(size_t)z * ((size_t)num_per * 2u * dim0 * 2u) + (size_t)ii * (2u * dim0 * 2u) + (size_t)c * (dim0 * 2u) + (size_t)j * 2u + m];
+    const uint64_t v = ref[(size_t)zl * ((size_t)num_per * 2u * dim0 * 2u) + (size_t)ii * (2u * dim0 * 2u) + (size_t)c * (dim0 * 2u) + (size_t)j * 2u + m];
+    db_put_word(dev, pk_pos(z0 + zl), jl, ic, m, nic, dim0_shard, pack(lo32(v) % kP, hi32(v) % kB));
 }
-void launch_db_relayout(const uint64_t* db_ref, uint64_t* db_dev, uint32_t num_per, uint32_t dim0, uint32_t j0, uint32_t dim0_shard, uint32_t nz,
-                        hipStream_t s) {
+void launch_db_relayout(const uint64_t* db_ref, uint64_t* db_dev, uint32_t num_per, uint32_t dim0, uint32_t j0, uint32_t dim0_shard, uint32_t z0,
+                        uint32_t nz, hipStream_t s) {
     const size_t words = (size_t)nz * dim0_shard * 2u * num_per * 2u;
-    hipLaunchKernelGGL(db_relayout_kernel, dim3((uint32_t)((words + 255) / 256)), dim3(256), 0, s, db_ref, db_dev, num_per, dim0, j0, dim0_shard, nz);
+    hipLaunchKernelGGL(db_relayout_kernel, dim3((uint32_t)((words + 255) / 256)), dim3(256), 0, s, db_ref, db_dev, num_per, dim0, j0, dim0_shard, z0, nz);
 }
 
 // reference reorientCiphertexts layout (src/spiral.cpp:410-433): z*(dim0*2*4) + j*8 + m*4 + r
@@ -173,7 +218,26 @@ void launch_qs_from_reoriented(const uint64_t* reoriented, uint32_t* qs, uint32_
     hipLaunchKernelGGL(qs_from_reoriented_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, reoriented, qs, jm_total);
 }
 
-__global__ __launch_bounds__(256) void fill_db_random_kernel(uint64_t* db, uint64_t nwords, uint64_t seed) {
+// arbitrary valid words (benchmarks): word number i of the shard, any order
+__global__ __launch_bounds__(256) void fill_db_random_kernel(uint64_t* db, uint32_t nic, uint32_t dim0, uint64_t seed) {
+    const uint64_t nwords = (uint64_t)kN * dim0 * nic * 2u, stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < nwords; i += stride) {
+        uint64_t x = seed + i + 0x9E3779B97F4A7C15ull;
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+        x ^= x >> 31;
+        const uint32_t m = (uint32_t)(i & 1u), ic = (uint32_t)((i >> 1) % nic);
+        const uint64_t rest = (i >> 1) / nic;
+        const uint32_t j = (uint32_t)(rest % dim0), z = (uint32_t)(rest / dim0);
+        db_put_word(db, z, j, ic, m, nic, dim0, pack((uint32_t)(x & 0xffffffffull) % kP, (uint32_t)(x >> 32) % kB));
+    }
+}
+void launch_fill_db_random(uint64_t* db_dev, uint32_t num_per, uint32_t dim0_shard, uint64_t seed, hipStream_t s) {
+    hipLaunchKernelGGL(fill_db_random_kernel, dim3(4096), dim3(256), 0, s, db_dev, 2 * num_per, dim0_shard, seed);
+}
+
+// arbitrary valid 8-byte words, linear (the SpiralPack database layout, pack.hip)
+__global__ __launch_bounds__(256) void fill_words_random_kernel(uint64_t* db, uint64_t nwords, uint64_t seed) {
     const uint64_t stride = (uint64_t)gridDim.x * 256u;
     for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < nwords; i += stride) {
         uint64_t x = seed + i + 0x9E3779B97F4A7C15ull;
@@ -183,8 +247,8 @@ __global__ __launch_bounds__(256) void fill_db_random_kernel(uint64_t* db, uint6
         db[i] = pack((uint32_t)(x & 0xffffffffull) % kP, (uint32_t)(x >> 32) % kB);
     }
 }
-void launch_fill_db_random(uint64_t* db_dev, uint64_t nwords, uint64_t seed, hipStream_t s) {
-    hipLaunchKernelGGL(fill_db_random_kernel, dim3(2048), dim3(256), 0, s, db_dev, nwords, seed);
+void launch_fill_words_random(uint64_t* db_dev, uint64_t nwords, uint64_t seed, hipStream_t s) {
+    hipLaunchKernelGGL(fill_words_random_kernel, dim3(2048), dim3(256), 0, s, db_dev, nwords, seed);
 }
 
 }  // namespace spiral

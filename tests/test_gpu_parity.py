@@ -199,7 +199,8 @@ CONFIGS = [
     (3, 3, dict(t_gsw=8)),
     (6, 2, {}),  # stopround with dim0 >> ell*nu2
     (2, 2, dict(t_gsw=5, t_exp=2, qprime_bits=19, direct_upload=1)),  # direct upload (SpiralStream-style)
-    (2, 6, dict(t_gsw=8)),  # nic >= 64: the fast sweep path
+    (2, 6, dict(t_gsw=8)),  # nic >= 64 but dim0 < 8: plain database layout, wide accumulator
+    (3, 5, dict(t_gsw=8)),  # nic >= 64 and dim0 % 8 == 0: the packed 7-byte database layout and the fast sweep
 ]
 
 
@@ -263,6 +264,33 @@ def test_answer_and_device_db(sa, oracle, nu1, nu2, kw):
         assert_eq(fin, O.answer(po, q, wl, wr, w, v, db), "answer")
         assert_eq(cl.decode(resp), O.db_item(po, 4321, idx), "decoded plaintext")
         assert us["total_us"] > 0
+    srv.close()
+
+
+def test_load_db_in_several_staging_passes(sa, oracle, monkeypatch):
+    """load_db stages the reference-layout database a few z slabs at a time; every pass must land its slabs at the
+    right (thread-transposed) positions of the packed device layout: answer == oracle, and == the device-generated DB"""
+    O = oracle
+    from spiral_amd import server as SV
+
+    kw = dict(t_gsw=8)
+    po, pg = O.make_params(4, 5, **kw), sa.make_params(4, 5, **kw)
+    cl = O.Client(po, seed=11)
+    wl, wr, w, v = cl.pub_params()
+    db = O.gen_db(po, 99)
+    q = cl.query(333)
+    want = O.answer(po, q, wl, wr, w, v, db)
+    monkeypatch.setenv("SPIRAL_DB_STAGE_BYTES", str(48 * 16 * 32 * 4 * 8))  # 48 slabs per pass: 43 passes, the last one short
+    srv = sa.Server(pg)
+    srv.load_db(db)
+    srv.set_pub_params(wl, wr, w, v)
+    fin, resp, _ = srv.answer(q)
+    assert_eq(fin, want, "answer from a database loaded in 43 passes")
+    acc_loaded = srv.read(SV.BUF_ACC)
+    srv.gen_db(99)
+    fin2, _, _ = srv.answer(q)
+    assert_eq(fin2, want, "answer from the device-generated database")
+    assert_eq(srv.read(SV.BUF_ACC), acc_loaded, "accumulators: loaded vs generated database")
     srv.close()
 
 

@@ -200,6 +200,82 @@ __global__ __launch_bounds__(ZW * 64) void sweep_zl(const uint64_t* __restrict__
         else *dst = sh[zz * ROW + res];
     }
 }
+// ---- packed database: 7 bytes per word (two 28-bit residues), 8 j = 16 words = 112 bytes = 7 x 16-byte loads per lane --------
+// layout per tile: [j/8][k < 7][lane][16 B]
+__global__ void pack_db(const uint64_t* __restrict__ db, uint32_t* __restrict__ pk, uint32_t dim0, uint32_t ntiles) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (tile, group, lane)
+    const uint32_t groups = dim0 / 8;
+    if (g >= (size_t)ntiles * groups * 64) return;
+    const uint32_t lane = g & 63u, grp = (g >> 6) % groups, tile = (uint32_t)((g >> 6) / groups);
+    uint32_t out[28];
+    for (int i = 0; i < 28; i++) out[i] = 0;
+    for (uint32_t w = 0; w < 16; w++) {
+        const uint32_t jj = w >> 1, m = w & 1u;
+        const uint64_t v = db[((size_t)tile * dim0 + grp * 8 + jj) * 128u + lane * 2u + m];
+        const uint64_t f = (uint64_t)lo32(v) | ((uint64_t)hi32(v) << 28);  // 56 bits
+        const uint32_t bit = 56u * w, d = bit >> 5, sh = bit & 31u;
+        out[d] |= (uint32_t)(f << sh);
+        out[d + 1] |= (uint32_t)(sh ? (f >> (32 - sh)) : (f >> 32));
+        if (sh > 8) out[d + 2] |= (uint32_t)(f >> (64 - sh));
+    }
+    for (uint32_t k = 0; k < 7; k++) {
+        uint4* dst = reinterpret_cast<uint4*>(pk) + (((size_t)tile * groups + grp) * 7u + k) * 64u + lane;
+        *dst = make_uint4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+    }
+}
+template <int T>
+__device__ __forceinline__ uint32_t field28(const uint32_t (&D)[28]) {  // 28-bit field number T of the 112-byte group
+    constexpr uint32_t bit = 28u * T, d = bit >> 5, sh = bit & 31u;
+    if constexpr (sh <= 4) return (D[d] >> sh) & 0xFFFFFFFu;
+    else return __builtin_amdgcn_alignbit(D[d + 1], D[d], sh) & 0xFFFFFFFu;
+}
+template <int JJ>
+__device__ __forceinline__ void mac_packed_j(uint64_t (&a)[6], const uint4* q, const uint32_t (&D)[28]) {
+    const uint4 qa = q[0], qb = q[1], qc = q[2];
+    const uint32_t p0 = field28<4 * JJ>(D), b0 = field28<4 * JJ + 1>(D), p1 = field28<4 * JJ + 2>(D), b1 = field28<4 * JJ + 3>(D);
+    a[0] += (uint64_t)qa.x * p0; a[1] += (uint64_t)qa.y * p0; a[2] += (uint64_t)qa.z * p0;
+    a[3] += (uint64_t)qa.w * b0; a[4] += (uint64_t)qb.x * b0; a[5] += (uint64_t)qb.y * b0;
+    a[0] += (uint64_t)qb.z * p1; a[1] += (uint64_t)qb.w * p1; a[2] += (uint64_t)qc.x * p1;
+    a[3] += (uint64_t)qc.y * b1; a[4] += (uint64_t)qc.z * b1; a[5] += (uint64_t)qc.w * b1;
+}
+template <int ZW, int GU>
+__global__ __launch_bounds__(ZW * 64) void sweep_packed(const uint32_t* __restrict__ pk, const uint32_t* __restrict__ qs, uint64_t* __restrict__ acc,
+                                                        uint32_t nic, uint32_t dim0) {
+    constexpr uint32_t ROW = 64 * 3 + 1;
+    __shared__ uint64_t sh[ZW * ROW];
+    const uint32_t lane = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t wpz = nic >> 6;
+    const uint32_t zg = blockIdx.x / wpz, icb = blockIdx.x - zg * wpz;
+    const uint32_t z = zg * ZW + wv, tile = z * wpz + icb, groups = dim0 / 8;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4* dbp = reinterpret_cast<const u32x4*>(pk) + (size_t)tile * groups * 7u * 64u + lane;
+    const uint4* q = reinterpret_cast<const uint4*>(qs) + (size_t)z * dim0 * 3u;
+    uint64_t a[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t g0 = 0; g0 < groups; g0 += 16) {  // 16 groups = 128 j = 256 terms between reductions
+#pragma unroll GU
+        for (uint32_t g = g0; g < g0 + 16u; g++) {
+            uint32_t D[28];
+#pragma unroll
+            for (uint32_t k = 0; k < 7; k++) {
+                const u32x4 v = __builtin_nontemporal_load(dbp + ((size_t)g * 7u + k) * 64u);
+                D[4 * k] = v.x; D[4 * k + 1] = v.y; D[4 * k + 2] = v.z; D[4 * k + 3] = v.w;
+            }
+            const uint4* qg = q + (size_t)g * 24u;
+            mac_packed_j<0>(a, qg, D); mac_packed_j<1>(a, qg + 3, D); mac_packed_j<2>(a, qg + 6, D); mac_packed_j<3>(a, qg + 9, D);
+            mac_packed_j<4>(a, qg + 12, D); mac_packed_j<5>(a, qg + 15, D); mac_packed_j<6>(a, qg + 18, D); mac_packed_j<7>(a, qg + 21, D);
+        }
+        reduce6(a);
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < 3; r++) sh[wv * ROW + lane * 3u + r] = pack((uint32_t)a[r], (uint32_t)a[3 + r]);
+    __syncthreads();
+#pragma unroll
+    for (uint32_t m = 0; m < 3; m++) {
+        const uint32_t idx = threadIdx.x + ZW * 64u * m, res = idx / ZW, zz = idx - res * ZW;
+        const uint32_t col = res / 3u, r = res - col * 3u, ic = icb * 64u + col, ii = ic >> 1, c = ic & 1u;
+        acc[((size_t)(6u * ii + 2u * r + c)) * kN + zg * ZW + zz] = sh[zz * ROW + res];
+    }
+}
 // read-only probes (no arithmetic beyond an xor, no query): the HBM read ceiling for a given access pattern.
 // PATTERN 0: the sweep's (each wave streams its own contiguous dim0 KiB); 1: grid-interleaved (at step t wave w reads KiB t*nwaves + w)
 template <int UNROLL, int PATTERN, int WAVES>
@@ -263,6 +339,7 @@ __global__ void fillq(uint32_t* p, size_t n, uint64_t seed) {
     }
 }
 
+static uint32_t* pkg;
 struct Variant { const char* name; void (*launch)(const uint64_t*, const uint32_t*, uint64_t*, uint32_t, uint32_t); };
 
 #define V(NAME, ...) {NAME, [](const uint64_t* db, const uint32_t* qs, uint64_t* acc, uint32_t nic, uint32_t dim0) { __VA_ARGS__; }}
@@ -274,6 +351,13 @@ int main(int argc, char** argv) {
     uint64_t *db, *acc, *ref; uint32_t* qs;
     hipMalloc(&db, dbw * 8); hipMalloc(&qs, qw * 4); hipMalloc(&acc, accw * 8); hipMalloc(&ref, accw * 8);
     fill<<<2048, 256>>>(db, dbw, 1); fillq<<<2048, 256>>>(qs, qw, 2);
+    uint32_t* pk;
+    hipMalloc(&pk, dbw * 7);
+    pkg = pk;
+    {
+        const size_t n = (size_t)ntiles * (dim0 / 8) * 64;
+        pack_db<<<(unsigned)((n + 255) / 256), 256>>>(db, pk, dim0, ntiles);
+    }
     hipDeviceSynchronize();
     const double bytes = (double)dbw * 8 + (double)dim0 * 6 * kN * 8 + (double)num_per * 12 * kN * 8;
     std::vector<Variant> vs = {
@@ -312,6 +396,9 @@ int main(int argc, char** argv) {
         V("persist 4096w u8 w1", hipLaunchKernelGGL((sweep_p<8, true, 1>), dim3(4096), dim3(64), 0, 0, db, qs, acc, nic, dim0, kN * (nic / 64))),
         V("persist 6144w u8 w2", hipLaunchKernelGGL((sweep_p<8, true, 2>), dim3(3072), dim3(128), 0, 0, db, qs, acc, nic, dim0, kN * (nic / 64))),
         V("16384 waves half-j? n/a", hipLaunchKernelGGL((sweep_p<8, true, 2>), dim3(1536), dim3(128), 0, 0, db, qs, acc, nic, dim0, kN * (nic / 64))),
+        V("PACKED zl16 gu1", hipLaunchKernelGGL((sweep_packed<16, 1>), dim3(kN / 16 * (nic / 64)), dim3(1024), 0, 0, pkg, qs, acc, nic, dim0)),
+        V("PACKED zl16 gu2", hipLaunchKernelGGL((sweep_packed<16, 2>), dim3(kN / 16 * (nic / 64)), dim3(1024), 0, 0, pkg, qs, acc, nic, dim0)),
+        V("PACKED zl8 gu1", hipLaunchKernelGGL((sweep_packed<8, 1>), dim3(kN / 8 * (nic / 64)), dim3(512), 0, 0, pkg, qs, acc, nic, dim0)),
         V("R-bis plain", hipLaunchKernelGGL((read_bisect<8, 0, 2>), dim3(kN * (nic / 64) / 2), dim3(128), 0, 0, db, qs, acc, nic, dim0)),
         V("R-bis 6acc-xor", hipLaunchKernelGGL((read_bisect<8, 16, 2>), dim3(kN * (nic / 64) / 2), dim3(128), 0, 0, db, qs, acc, nic, dim0)),
         V("R-bis 6mac", hipLaunchKernelGGL((read_bisect<8, 1, 2>), dim3(kN * (nic / 64) / 2), dim3(128), 0, 0, db, qs, acc, nic, dim0)),
