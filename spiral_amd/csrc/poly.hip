@@ -334,8 +334,16 @@ __global__ __launch_bounds__(kTpb) void scal2mat_rec_kernel(Scal2MatParams p) {
 #pragma unroll
     for (uint32_t m = 0; m < 3; m++) {
         const uint32_t q = threadIdx.x + 256u * m, zz = q / 48u, within = q - zz * 48u;  // 48 pieces per slot
-        uint4* rec = reinterpret_cast<uint4*>(p.qs + ((size_t)(z0 + zz) * (p.jm_total / 2) + p.j_base + a0) * 12);
-        rec[within] = flat[q];
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        u32x4* rec = reinterpret_cast<u32x4*>(p.qs + ((size_t)(z0 + zz) * (p.jm_total / 2) + p.j_base + a0) * 12);
+        const uint4 v = flat[q];
+#ifdef S2M_PLAIN_STORE
+        rec[within] = u32x4{v.x, v.y, v.z, v.w};
+#else
+        // streaming store: the 25 MB of records should not sit dirty in the caches when the sweep starts -- dirty lines
+        // written back into a saturated read stream cost the sweep ~20 us (tools/sweep_in_situ.py)
+        __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, rec + within);
+#endif
     }
 }
 void launch_scal2mat(const Scal2MatParams& p, hipStream_t s) {
