@@ -102,7 +102,13 @@ __global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __r
     __shared__ uint64_t sh[kSweepZ * kSweepRow];
     const uint32_t lane = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t wpz = nic >> 6;  // column blocks (= waves) per z
-    const uint32_t zg = blockIdx.x / wpz, icb = blockIdx.x - zg * wpz;
+    // Workgroups go to the 8 XCDs round-robin by blockIdx, and each XCD has its own L2.  The wpz workgroups that share a
+    // z-group read the same query records, so consecutive WORK items (not consecutive block ids) are given to one XCD:
+    // block b = 8q + x takes work x * (nblocks/8) + q.  (FETCH_SIZE showed the records being fetched once per XCD that
+    // touched them: 4 x 25 MB instead of 25 MB at config 2.)
+    uint32_t work = blockIdx.x;
+    if ((gridDim.x & 7u) == 0) work = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const uint32_t zg = work / wpz, icb = work - zg * wpz;
     const uint32_t z = zg * kSweepZ + wv, tile = z * wpz + icb, groups = dim0 >> 3;
     const u32x4* dbp = reinterpret_cast<const u32x4*>(db) + (size_t)tile * groups * 7u * 64u + lane;
     const uint4* q = reinterpret_cast<const uint4*>(qs) + (size_t)z * dim0 * 3u;  // wave-uniform, 3 x uint4 per j
