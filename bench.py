@@ -222,7 +222,9 @@ def main():
         "reference_buckets_us_eager": ({k: round(v, 1) for k, v in detail.items() if k != "scaltomat_us"} if detail else None),
         "roofline": {"bound": "hbm", "kernel": "sweep_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(bytes_sweep),
-                     "avg_launch_ms": round(sweep_ms, 4), "launches_timed": len(sampled), "shard": f"j in [{j0},{j1}) on rank 0"},
+                     "avg_launch_ms": round(sweep_ms, 4),
+                     "device_bytes_per_launch": int(srv.sweep_device_bytes()), "achieved_device_bytes": round(srv.sweep_device_bytes() / (sweep_ms * 1e-3) / 1e9, 1),
+                     "note": "achieved = SURVEY 8d algorithmic bytes (8 B per database word) / launch time; the device keeps a word's two 28-bit residues in 7 bytes, so a launch moves device_bytes_per_launch (traffic = the PMC measurement of that)", "launches_timed": len(sampled), "shard": f"j in [{j0},{j1}) on rank 0"},
     }
     srv.close()
     if use_dist:

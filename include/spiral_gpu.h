@@ -212,6 +212,9 @@ int spiral_gpu_server_write_raw(spiral_gpu_server *s, const uint64_t *raw_cts);
 int spiral_gpu_server_time_sweep(spiral_gpu_server *s, int iters, float *avg_ms);
 /* algorithmic bytes of one sweep on this shard: DB + query records + accumulators */
 uint64_t spiral_gpu_server_sweep_bytes(spiral_gpu_server *s);
+/* bytes one launch actually has to move on this device: the database in its device layout (two 28-bit residues
+ * packed in 7 bytes), the query records and the accumulators -- below the algorithmic figure above */
+uint64_t spiral_gpu_server_sweep_device_bytes(spiral_gpu_server *s);
 
 /* ------------------------------------------------------------------------------------------------
  * SpiralPack / SpiralStreamPack (`--high-rate`, src/testing.cpp): base_dim x 1 scalar Regev ciphertexts,

@@ -1129,6 +1129,14 @@ int spiral_gpu_server_time_sweep(spiral_gpu_server* S, int iters, float* avg_ms)
     return 0;
 }
 
+uint64_t spiral_gpu_server_sweep_device_bytes(spiral_gpu_server* S) {
+    if (!S) return 0;
+    // what one launch has to move on this device: the database in its device layout (7 bytes per word when packed),
+    // the query records (48 B per (z, j)) and the accumulators
+    const uint64_t n = kN;
+    return (uint64_t)db_device_words(2 * S->s.num_per, S->dim0_shard) * 8 + (uint64_t)S->dim0_shard * 48 * n + (uint64_t)S->s.num_per * 6 * n * 8;
+}
+
 uint64_t spiral_gpu_server_sweep_bytes(spiral_gpu_server* S) {
     if (!S) return 0;
     // SURVEY.md 8d at 8 B per packed word: database + packed query (3 rows x 2 x dim0) + output (2 limbs as u64)

@@ -165,3 +165,7 @@ class Server:
 
     def sweep_bytes(self) -> int:
         return int(lib().spiral_gpu_server_sweep_bytes(self.h))
+
+    def sweep_device_bytes(self) -> int:
+        """bytes one sweep launch has to move on this device (packed database + query records + accumulators)"""
+        return int(lib().spiral_gpu_server_sweep_device_bytes(self.h))
