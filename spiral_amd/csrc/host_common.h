@@ -135,7 +135,8 @@ inline size_t expand_g_polys(uint32_t g, uint32_t t_exp, uint32_t t_exp_right) {
 // src/spiral.cpp:1664-1743.  cv: 2^g cts (2 PK polys each).
 inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_t t_exp, const uint64_t* w_left, uint32_t t_exp_right,
                 const uint64_t* w_right, uint32_t max_bits_right, uint32_t stopround, const ExpandWork& wk, hipStream_t st,
-                const uint64_t* query = nullptr) {  // query: the packed query ciphertext when cv[0] does not hold it yet
+                const uint64_t* query = nullptr,  // query: the packed query ciphertext when cv[0] does not hold it yet
+                uint32_t r_begin = 0, uint32_t r_end = 0xffffffffu) {  // rounds [r_begin, min(r_end, g))
     // active odd-index ciphertexts of round r (:1701-1702); the even ones are all 2^r
     auto odd_count = [&](uint32_t r) {
         const uint32_t num_in = 1u << r;
@@ -143,7 +144,7 @@ inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_
         if (stopround > 0 && r == stopround) return std::min(num_in, max_bits_right + 1);
         return num_in;
     };
-    for (uint32_t r = 0; r < g; r++) {
+    for (uint32_t r = r_begin; r < std::min(r_end, g); r++) {
         const uint32_t num_in = 1u << r;
         const uint32_t t = (kN >> r) + 1;
         const uint32_t cnt_even = num_in, cnt_odd = odd_count(r);

@@ -520,6 +520,13 @@ int spiral_gpu_server_create(const spiral_gpu_params* p, int device, uint32_t j_
         return fail("hipStreamCreate failed");
     }
     S->stream = S->own_stream;
+    if (hipStreamCreateWithFlags(&S->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&S->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&S->ev_join, hipEventDisableTiming) != hipSuccess) {
+        srv_free(S);
+        delete S;
+        return fail("side stream setup failed");
+    }
     for (auto& e : S->ev)
         if (hipEventCreate(&e) != hipSuccess) {
             srv_free(S);
@@ -728,6 +735,24 @@ int convert_gsw(spiral_gpu_server* S, hipStream_t st) {
 
 extern "C" {
 
+int spiral_gpu_server_expand(spiral_gpu_server* S);
+int spiral_gpu_server_convert(spiral_gpu_server* S);
+
+}  // extern "C"
+
+namespace {
+// expand + convert as the launch groups run them.  (Tried: forking the Regev->GSW conversion onto the side stream after
+// round `stopround`, where the odd-index side of the expansion is complete, to run beside the remaining even-only rounds.
+// Inside a hipGraph the second branch costs far more than the 26 us it hides -- expand + convert went from 340 to 415 us --
+// so the group stays one chain.)
+int expand_convert(spiral_gpu_server* S) {
+    if (spiral_gpu_server_expand(S)) return -1;
+    return spiral_gpu_server_convert(S);
+}
+}  // namespace
+
+extern "C" {
+
 int spiral_gpu_server_convert(spiral_gpu_server* S) {
     if (!S) return fail("null server");
     if (convert_scal2mat(S, S->stream)) return -1;
@@ -738,11 +763,6 @@ int spiral_gpu_server_convert(spiral_gpu_server* S) {
 int spiral_gpu_server_set_overlap(spiral_gpu_server* S, int on) {
     if (!S) return fail("null server");
     HIP_OK(hipSetDevice(S->device));
-    if (on && !S->side_stream) {
-        HIP_OK(hipStreamCreateWithFlags(&S->side_stream, hipStreamNonBlocking));
-        HIP_OK(hipEventCreateWithFlags(&S->ev_fork, hipEventDisableTiming));
-        HIP_OK(hipEventCreateWithFlags(&S->ev_join, hipEventDisableTiming));
-    }
     if (srv_join_side(S)) return -1;
     S->overlap = on != 0;
     srv_drop_graphs(S);
@@ -903,11 +923,7 @@ extern "C" {
 int spiral_gpu_server_run_pre(spiral_gpu_server* S) {
     if (!S) return fail("null server");
     if (!S->have_query || !S->have_pp) return fail("query and public parameters must be set first");
-    if (!S->overlap)
-        return run_group(S, 0, S->stream, [&]() {
-            if (spiral_gpu_server_expand(S)) return -1;
-            return spiral_gpu_server_convert(S);
-        });
+    if (!S->overlap) return run_group(S, 0, S->stream, [&]() { return expand_convert(S); });
     // overlap mode: expansion + ScalToMat on the main stream (the sweep needs only these); the Regev->GSW conversion
     // is forked onto the side stream and joined by the fold
     if (srv_join_side(S)) return -1;
@@ -930,8 +946,7 @@ int spiral_gpu_server_run_query(spiral_gpu_server* S) {
     if (!S->have_db) return fail("no database loaded");
     if (srv_join_side(S)) return -1;
     return run_group(S, 4, S->stream, [&]() {
-        if (spiral_gpu_server_expand(S)) return -1;
-        if (spiral_gpu_server_convert(S)) return -1;
+        if (expand_convert(S)) return -1;
         if (spiral_gpu_server_first_dim(S)) return -1;
         return run_fold_rounds(S, S->s.num_per, 0, S->p.nu2, S->acc, false, true);
     });
@@ -981,8 +996,7 @@ int spiral_gpu_server_run_pre_sweep(spiral_gpu_server* S) {
         return spiral_gpu_server_first_dim(S);
     }
     return run_group(S, 7, S->stream, [&]() {
-        if (spiral_gpu_server_expand(S)) return -1;
-        if (spiral_gpu_server_convert(S)) return -1;
+        if (expand_convert(S)) return -1;
         return spiral_gpu_server_first_dim(S);
     });
 }
