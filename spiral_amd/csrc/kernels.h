@@ -82,6 +82,8 @@ struct InvParams {
     IndexMap src_map, dst_map;
     uint32_t pre_reduce;  // 1: fields are lazy sums (< 2^32), reduce mod m first
     uint32_t src_ref;     // 1: source is reference layout [2][N] u64 instead of PK
+    uint32_t split;       // > 0: blocks b >= split take their source from src_map2(b - split) (two source regions, one launch)
+    IndexMap src_map2;
     // expansion round (launch_ntt_inverse_expand): block b = (active ct a, row); a < cnt_e -> i = 2a, else
     // i = 2(a - cnt_e) + 1; a ct with i >= num_in is first created as neg1 * cv[i - num_in] (src/spiral.cpp:1709)
     // Row 0 is transformed to dst[2a]; row 1 is not: its automorphed image, a slot permutation, goes to dst[2a + 1] in PK.

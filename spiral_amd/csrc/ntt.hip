@@ -311,7 +311,8 @@ __global__ __launch_bounds__(256) void ntt_inverse_kernel(Tables t, InvParams p)
             hi[r] = (uint32_t)src[kN + r];
         }
     } else {
-        const uint64_t* src = p.src + (size_t)p.src_map(b) * kN + tid;  // pk_pos(8*tid + r) = r*256 + tid
+        const uint32_t sp = (p.split && b >= p.split) ? p.src_map2(b - p.split) : p.src_map(b);
+        const uint64_t* src = p.src + (size_t)sp * kN + tid;  // pk_pos(8*tid + r) = r*256 + tid
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const uint64_t v = src[r * 256];

@@ -25,6 +25,7 @@ struct spiral_gpu_server {
 
     DevBuf db, w_left, w_right, w, v, query, cv, ex_raw, ex_g, ex_a1;
     DevBuf cv_raw, cv_g, gs_raw, gs_chat, gsw, key, cts_keep;
+    uint64_t *gs_raw_p = nullptr, *gs_chat_p = nullptr;  // the Regev->GSW halves of cv_raw / cv_g
     DevBuf qs, acc_own, raw, fold_d, fold_c, resp, stage;
     uint64_t* acc = nullptr;
     hipEvent_t ev[8] = {};
@@ -67,11 +68,13 @@ int srv_alloc(spiral_gpu_server* S) {
         if (S->ex_raw.alloc((size_t)S->n_cv * 2 * kN)) return -1;
         if (S->ex_g.alloc(expand_g_polys(s.g, p.t_exp, p.t_exp_right) * kN)) return -1;
     }
-    if (S->cv_raw.alloc((size_t)S->dim0_shard * kN)) return -1;
-    if (S->cv_g.alloc((size_t)S->dim0_shard * p.t_conv * kN)) return -1;
+    // conversion scratch: the ScalToMat sources/digits followed by the Regev->GSW ones, so both sets go through one lift
+    // launch and one digit-transform launch
     const size_t ngs = (size_t)p.nu2 * s.ell;
-    if (S->gs_raw.alloc(ngs * 2 * kN)) return -1;
-    if (S->gs_chat.alloc(ngs * 2 * p.t_conv * kN)) return -1;
+    if (S->cv_raw.alloc(((size_t)S->dim0_shard + ngs * 2) * kN)) return -1;
+    if (S->cv_g.alloc(((size_t)S->dim0_shard + ngs * 2) * p.t_conv * kN)) return -1;
+    S->gs_raw_p = S->cv_raw.p + (size_t)S->dim0_shard * kN;
+    S->gs_chat_p = S->cv_g.p + (size_t)S->dim0_shard * p.t_conv * kN;
     if (S->gsw.alloc((size_t)p.nu2 * 3 * s.m2 * kN)) return -1;
     if (S->key.alloc((size_t)p.nu2 * 3 * 2 * s.m2 * kN)) return -1;
     if (S->qs.alloc((size_t)kN * S->dim0_shard * 6)) return -1;  // 12 u32 per (z, j)
@@ -662,24 +665,35 @@ int spiral_gpu_server_expand(spiral_gpu_server* S) {
 }  // extern "C"
 
 namespace {
-// scalToMat for this shard's first-dimension ciphertexts (src/spiral.cpp:2230-2253)
-int convert_scal2mat(spiral_gpu_server* S, hipStream_t st) {
+// The conversion is: lift (INTT + CRT) of the source rows, t_conv gadget digits of each + forward transforms, then the two
+// products.  WHAT selects the ScalToMat part (this shard's first-dimension ciphertexts, src/spiral.cpp:2230-2253), the
+// Regev->GSW part (the nu2 further dimensions + fold keys, src/spiral.cpp:2315-2331, 2361-2386), or both with the lifts and
+// the digit transforms of the two parts merged into one launch each (their scratch is contiguous).
+enum ConvertWhat : uint32_t { CONV_S2M = 1, CONV_GSW = 2, CONV_BOTH = 3 };
+int convert_part(spiral_gpu_server* S, uint32_t what, hipStream_t st, bool mark_split = false) {
     const spiral_gpu_params& p = S->p;
-    const uint32_t ps = S->pos_stride;
-    {
-        InvParams ip{};
-        ip.src = S->cv.p;
-        ip.dst = S->cv_raw.p;
-        ip.src_map = IndexMap{1, 2 * ps, 2 * (S->j0 * ps + S->pos_first)};  // row 0 of ct pos(j0 + a)
-        ip.dst_map = identity_map();
-        launch_ntt_inverse(S->tb, ip, IST_CRT, S->dim0_shard, st);
-        FwdParams fp{};
-        fp.src = S->cv_raw.p;
-        fp.dst = S->cv_g.p;
-        fp.src_map = fp.dst_map = identity_map();
-        fp.n_digits = p.t_conv;
-        fp.bits = get_bits_per(p.t_conv);
-        launch_ntt_forward(S->tb, fp, LD_DIGIT, ST_PK, S->dim0_shard * p.t_conv, st);
+    const spiral_gpu_shape& s = S->s;
+    const uint32_t ps = S->pos_stride, ngs = p.nu2 * s.ell;
+    if (ngs == 0) what &= ~CONV_GSW;
+    const uint32_t n1 = (what & CONV_S2M) ? S->dim0_shard : 0, n2 = (what & CONV_GSW) ? 2 * ngs : 0;
+    const IndexMap map1{1, 2 * ps, 2 * (S->j0 * ps + S->pos_first)};  // row 0 of ct pos(j0 + a)
+    const IndexMap map2{2, 2 * ps, 2 * S->pos_rest};                   // rows 0, 1 of the nu2*ell GSW-bit cts
+    InvParams ip{};
+    ip.src = S->cv.p;
+    ip.dst = n1 ? S->cv_raw.p : S->gs_raw_p;
+    ip.src_map = n1 ? map1 : map2;
+    ip.split = (n1 && n2) ? n1 : 0;
+    ip.src_map2 = map2;
+    ip.dst_map = identity_map();
+    launch_ntt_inverse(S->tb, ip, IST_CRT, n1 + n2, st);
+    FwdParams fp{};
+    fp.src = ip.dst;
+    fp.dst = n1 ? S->cv_g.p : S->gs_chat_p;
+    fp.src_map = fp.dst_map = identity_map();
+    fp.n_digits = p.t_conv;
+    fp.bits = get_bits_per(p.t_conv);
+    launch_ntt_forward(S->tb, fp, LD_DIGIT, ST_PK, (n1 + n2) * p.t_conv, st);
+    if (what & CONV_S2M) {
         Scal2MatParams sp{};
         sp.w = S->w.p;
         sp.g = S->cv_g.p;
@@ -693,33 +707,12 @@ int convert_scal2mat(spiral_gpu_server* S, hipStream_t st) {
         sp.j_base = 0;
         launch_scal2mat(sp, st);
     }
-    return 0;
-}
-
-// regevToGSW for the nu2 further dimensions + fold keys (src/spiral.cpp:2315-2331, 2361-2386)
-int convert_gsw(spiral_gpu_server* S, hipStream_t st) {
-    const spiral_gpu_params& p = S->p;
-    const spiral_gpu_shape& s = S->s;
-    const uint32_t ps = S->pos_stride;
-    if (p.nu2) {
-        const uint32_t ngs = p.nu2 * s.ell;
-        InvParams ip{};
-        ip.src = S->cv.p;
-        ip.dst = S->gs_raw.p;
-        ip.src_map = IndexMap{2, 2 * ps, 2 * S->pos_rest};
-        ip.dst_map = identity_map();
-        launch_ntt_inverse(S->tb, ip, IST_CRT, 2 * ngs, st);
-        FwdParams fp{};
-        fp.src = S->gs_raw.p;
-        fp.dst = S->gs_chat.p;
-        fp.src_map = fp.dst_map = identity_map();
-        fp.n_digits = p.t_conv;
-        fp.bits = get_bits_per(p.t_conv);
-        launch_ntt_forward(S->tb, fp, LD_DIGIT, ST_PK, 2 * ngs * p.t_conv, st);
+    if (mark_split) HIP_OK(hipEventRecord(S->ev[7], st));  // ScalToMat | RegevToGSW split of the reference summary
+    if (what & CONV_GSW) {
         GswParams gp{};
         gp.w = S->w.p;
         gp.v = S->v.p;
-        gp.chat = S->gs_chat.p;
+        gp.chat = S->gs_chat_p;
         gp.cv = S->cv.p;
         gp.cv_pos = IndexMap{1, ps, S->pos_rest};
         gp.gsw = S->gsw.p;
@@ -731,6 +724,8 @@ int convert_gsw(spiral_gpu_server* S, hipStream_t st) {
     }
     return 0;
 }
+int convert_scal2mat(spiral_gpu_server* S, hipStream_t st) { return convert_part(S, CONV_S2M, st); }
+int convert_gsw(spiral_gpu_server* S, hipStream_t st) { return convert_part(S, CONV_GSW, st); }
 }  // namespace
 
 extern "C" {
@@ -755,9 +750,7 @@ extern "C" {
 
 int spiral_gpu_server_convert(spiral_gpu_server* S) {
     if (!S) return fail("null server");
-    if (convert_scal2mat(S, S->stream)) return -1;
-    if (!S->use_graphs) HIP_OK(hipEventRecord(S->ev[7], S->stream));  // ScalToMat | RegevToGSW split of the reference summary
-    return convert_gsw(S, S->stream);
+    return convert_part(S, CONV_BOTH, S->stream, !S->use_graphs);
 }
 
 int spiral_gpu_server_set_overlap(spiral_gpu_server* S, int on) {
