@@ -45,7 +45,7 @@ struct spiral_gpu_server {
     // when n_src*ell <= fold_dmax, one per polynomial when n_src >= fold_lmin, and the separate lift + digit
     // transforms otherwise.  SPIRAL_FOLD_CHAIN / SPIRAL_FOLD_DMAX / SPIRAL_FOLD_LMIN override (tuning only).
     bool fold_chain = true;
-    uint32_t fold_dmax = 1024, fold_lmin = 0xffffffffu;
+    uint32_t fold_dmax = 1024, fold_lmin = 768;
     uint32_t fold_g_log = 0;  // distributed fold over 2^fold_g_log ranks: the sweep groups its output by ii mod G
 };
 
