@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "common.h"
 
 namespace spiral {
 
@@ -200,14 +201,38 @@ void launch_db_relayout(const uint64_t* db_ref, uint64_t* db_dev, uint32_t num_p
 // reference reorientCiphertexts layout (z, j, m, r_pad4) u64 -> sweep query records
 void launch_qs_from_reoriented(const uint64_t* reoriented, uint32_t* qs, uint32_t jm_total, hipStream_t s);
 void launch_fill_db_random(uint64_t* db_dev, uint32_t num_per, uint32_t dim0_shard, uint64_t seed, hipStream_t s);
-void launch_fill_words_random(uint64_t* db_dev, uint64_t nwords, uint64_t seed, hipStream_t s);
+void launch_fill_db1_random(uint64_t* db_dev, uint32_t num_per, uint32_t dim0, uint64_t seed, hipStream_t s);
 
 // ---- SpiralPack (pack.hip; reference src/testing.cpp) -----------------------------------------------------------
-// device DB layout, 1 x 1 plaintexts: word(z, j, ii) at (((z*nblk + ii/W)*(dim0/2) + j/2)*W + ii%W)*2 + (j&1), W = min(64, num_per)
+// device DB layout, 1 x 1 plaintexts.  Packed (num_per >= 64 and dim0 % 16 == 0, as the base path's, common.h): a word is two
+// 28-bit residues in 7 bytes; a lane's 16 words of 16 consecutive j are one 112-byte string fetched as 7 x 16 bytes:
+//     tile (z, ii/64) -> group j/16 -> chunk k < 7 -> lane ii%64 -> 16 bytes.
+// Plain (tiny geometries): word(z, j, ii) at (((z*nblk + ii/W)*(dim0/2) + j/2)*W + ii%W)*2 + (j&1), W = min(64, num_per)
 __host__ __device__ inline size_t db1_word_index(uint32_t z, uint32_t j, uint32_t ii, uint32_t num_per, uint32_t dim0) {
     const uint32_t w = num_per < 64u ? num_per : 64u, nblk = num_per / w;
     return ((((size_t)z * nblk + ii / w) * (dim0 / 2) + (j >> 1)) * w + ii % w) * 2u + (j & 1u);
 }
+__host__ __device__ inline bool db1_packed(uint32_t num_per, uint32_t dim0) { return num_per >= 64u && (dim0 & 15u) == 0u; }
+__host__ __device__ inline size_t db1_device_words(uint32_t num_per, uint32_t dim0) {  // u64 words per trial
+    const size_t words = (size_t)kN * dim0 * num_per;
+    return db1_packed(num_per, dim0) ? words / 8u * 7u : words;
+}
+__host__ __device__ inline size_t db1_packed_byte(uint32_t z, uint32_t j, uint32_t ii, uint32_t by, uint32_t num_per, uint32_t dim0) {
+    const uint32_t tile = z * (num_per >> 6) + (ii >> 6), lane = ii & 63u, b = 7u * (j & 15u) + by;
+    return ((((size_t)tile * (dim0 >> 4) + (j >> 4)) * 7u + (b >> 4)) * 64u + lane) * 16u + (b & 15u);
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ void db1_put_word(uint64_t* db, uint32_t z, uint32_t j, uint32_t ii, uint32_t num_per, uint32_t dim0, uint64_t v) {
+    if (db1_packed(num_per, dim0)) {
+        const uint64_t f = (uint64_t)(uint32_t)v | ((uint64_t)(uint32_t)(v >> 32) << 28);
+        uint8_t* bytes = reinterpret_cast<uint8_t*>(db);
+#pragma unroll
+        for (uint32_t by = 0; by < 7; by++) bytes[db1_packed_byte(z, j, ii, by, num_per, dim0)] = (uint8_t)(f >> (8u * by));
+    } else {
+        db[db1_word_index(z, j, ii, num_per, dim0)] = v;
+    }
+}
+#endif
 // fastMultiplyQueryByDatabaseDim1 (src/testing.cpp:364): acc[ii][r][z] PK; qs1 records [z][j] = {p r0, p r1, b r0, b r1}
 void launch_sweep1(const uint64_t* db, const uint32_t* qs1, uint64_t* acc, uint32_t num_per, uint32_t dim0, hipStream_t s);
 // query records from the expanded cts: first-dimension ct j is cv[j * idx_factor] (reorientCiphertextsDim1, :342)

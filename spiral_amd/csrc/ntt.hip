@@ -225,10 +225,8 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
     } else if constexpr (STORE == ST_DB1) {
         const uint64_t item = p.item_base + b;
         const uint32_t ii = (uint32_t)(item % p.num_per), j = (uint32_t)(item / p.num_per);
-        const size_t zstride = (size_t)p.dim0_shard * p.num_per;  // words per z slab
-        uint64_t* dst = p.dst + db1_word_index(0, j, ii, p.num_per, p.dim0_shard);
 #pragma unroll
-        for (int r = 0; r < 8; r++) dst[(size_t)(r * 256u + tid) * zstride] = pack(lo[r], hi[r]);  // slab index = pk_pos(slot)
+        for (int r = 0; r < 8; r++) db1_put_word(p.dst, r * 256u + tid, j, ii, p.num_per, p.dim0_shard, pack(lo[r], hi[r]));  // z = pk_pos(slot)
     } else {  // ST_DB: scatter into the sweep layout
         const uint64_t item = p.item_base + (b >> 2);
         const uint32_t mc = b & 3u, m = mc >> 1, c = mc & 1u;

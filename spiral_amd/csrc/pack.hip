@@ -27,28 +27,82 @@ __device__ __forceinline__ void store_acc1(uint64_t* acc, const uint64_t (&a)[4]
     acc[((size_t)ii * 2u + 1u) * kN + z] = pack((uint32_t)a[1], (uint32_t)a[3]);
 }
 
-// fast path (num_per >= 64): one wave per (z, block of 64 plaintext columns); lane = column; a 16-byte load brings
-// two consecutive j; the two query records of the pair are wave-uniform (SGPRs)
-constexpr uint32_t kSweep1Waves = 2;
-__global__ __launch_bounds__(kSweep1Waves * 64) void sweep1_kernel(const uint64_t* __restrict__ db, const uint32_t* __restrict__ qs,
-                                                                   uint64_t* __restrict__ acc, uint32_t num_per, uint32_t dim0) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * kSweep1Waves + (threadIdx.x >> 6));
-    const uint32_t wpz = num_per >> 6, z = wave / wpz, ii = (wave - z * wpz) * 64u + lane, jp_n = dim0 >> 1;
-    const u64x2* dbp = reinterpret_cast<const u64x2*>(db) + (size_t)wave * jp_n * 64u + lane;
+// fast path (packed database): one wave per (z, block of 64 plaintext columns), lane = column; per 16 j seven 16-byte loads
+// (112 packed bytes = 16 words), the query records of those j are wave-uniform (SGPRs).  As the base sweep (sweep.hip): 16
+// waves of a workgroup work on consecutive z and trade their results through LDS to store full 128-byte lines, and the
+// block -> tile mapping keeps the workgroups that share a z-group's query records on one XCD.
+constexpr uint32_t kSweep1Z = 16, kSweep1Row = 64 * 2 + 1;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int T>
+__device__ __forceinline__ uint32_t field28(const uint32_t (&d)[28]) {  // 28-bit field T of a 112-byte group
+    constexpr uint32_t bit = 28u * T, w = bit >> 5, sh = bit & 31u;
+    if constexpr (sh <= 4)
+        return (d[w] >> sh) & 0xFFFFFFFu;
+    else
+        return __builtin_amdgcn_alignbit(d[w + 1], d[w], sh) & 0xFFFFFFFu;
+}
+template <int W>
+__device__ __forceinline__ void mac4_packed(uint64_t (&a)[4], uint4 q, const uint32_t (&d)[28]) {
+    const uint32_t bl = field28<2 * W>(d), bh = field28<2 * W + 1>(d);
+    a[0] += (uint64_t)q.x * bl;
+    a[1] += (uint64_t)q.y * bl;
+    a[2] += (uint64_t)q.z * bh;
+    a[3] += (uint64_t)q.w * bh;
+}
+__global__ __launch_bounds__(kSweep1Z * 64) void sweep1_kernel(const uint64_t* __restrict__ db, const uint32_t* __restrict__ qs,
+                                                               uint64_t* __restrict__ acc, uint32_t num_per, uint32_t dim0) {
+    __shared__ uint64_t sh[kSweep1Z * kSweep1Row];
+    const uint32_t lane = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t wpz = num_per >> 6;
+    uint32_t work = blockIdx.x;
+    if ((gridDim.x & 7u) == 0) work = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // XCD-aware, see sweep.hip
+    const uint32_t zg = work / wpz, iib = work - zg * wpz;
+    const uint32_t z = zg * kSweep1Z + wv, tile = z * wpz + iib, groups = dim0 >> 4;
+    const u32x4* dbp = reinterpret_cast<const u32x4*>(db) + (size_t)tile * groups * 7u * 64u + lane;
     const uint4* q = reinterpret_cast<const uint4*>(qs) + (size_t)z * dim0;
     uint64_t a[4] = {0, 0, 0, 0};
-    for (uint32_t j0 = 0; j0 < jp_n; j0 += 128) {  // 128 pairs = 256 terms per accumulator between reductions
-        const uint32_t jend = min(j0 + 128u, jp_n);
-#pragma unroll 8
-        for (uint32_t jp = j0; jp < jend; jp++) {
-            const u64x2 w = __builtin_nontemporal_load(dbp + (size_t)jp * 64u);
-            mac4(a, q[2 * jp], w.x);
-            mac4(a, q[2 * jp + 1], w.y);
+    for (uint32_t g0 = 0; g0 < groups; g0 += 16) {  // 16 groups = 256 j = 256 terms per accumulator between reductions
+        const uint32_t gend = min(g0 + 16u, groups);
+#pragma unroll 2
+        for (uint32_t g = g0; g < gend; g++) {
+            uint32_t d[28];
+#pragma unroll
+            for (uint32_t k = 0; k < 7; k++) {
+                const u32x4 v = __builtin_nontemporal_load(dbp + ((size_t)g * 7u + k) * 64u);
+                d[4 * k] = v.x;
+                d[4 * k + 1] = v.y;
+                d[4 * k + 2] = v.z;
+                d[4 * k + 3] = v.w;
+            }
+            const uint4* qg = q + (size_t)g * 16u;
+            mac4_packed<0>(a, qg[0], d);
+            mac4_packed<1>(a, qg[1], d);
+            mac4_packed<2>(a, qg[2], d);
+            mac4_packed<3>(a, qg[3], d);
+            mac4_packed<4>(a, qg[4], d);
+            mac4_packed<5>(a, qg[5], d);
+            mac4_packed<6>(a, qg[6], d);
+            mac4_packed<7>(a, qg[7], d);
+            mac4_packed<8>(a, qg[8], d);
+            mac4_packed<9>(a, qg[9], d);
+            mac4_packed<10>(a, qg[10], d);
+            mac4_packed<11>(a, qg[11], d);
+            mac4_packed<12>(a, qg[12], d);
+            mac4_packed<13>(a, qg[13], d);
+            mac4_packed<14>(a, qg[14], d);
+            mac4_packed<15>(a, qg[15], d);
         }
         reduce4(a);
     }
-    store_acc1(acc, a, ii, z);
+    sh[wv * kSweep1Row + lane * 2u] = pack((uint32_t)a[0], (uint32_t)a[2]);
+    sh[wv * kSweep1Row + lane * 2u + 1u] = pack((uint32_t)a[1], (uint32_t)a[3]);
+    __syncthreads();
+    // 128 (column, row) results x 16 consecutive z: thread -> (result, z) with z fastest; acc[ii][r][z]
+#pragma unroll
+    for (uint32_t m = 0; m < 2; m++) {
+        const uint32_t idx = threadIdx.x + kSweep1Z * 64u * m, res = idx / kSweep1Z, zz = idx - res * kSweep1Z;
+        acc[((size_t)(iib * 64u) * 2u + res) * kN + zg * kSweep1Z + zz] = sh[zz * kSweep1Row + res];
+    }
 }
 __global__ __launch_bounds__(256) void sweep1_small_kernel(const uint64_t* __restrict__ db, const uint32_t* __restrict__ qs, uint64_t* __restrict__ acc,
                                                            uint32_t num_per, uint32_t dim0) {
@@ -64,9 +118,8 @@ __global__ __launch_bounds__(256) void sweep1_small_kernel(const uint64_t* __res
     store_acc1(acc, a, ii, z);
 }
 void launch_sweep1(const uint64_t* db, const uint32_t* qs1, uint64_t* acc, uint32_t num_per, uint32_t dim0, hipStream_t s) {
-    if (num_per >= 64) {
-        const uint32_t waves = kN * (num_per >> 6);
-        hipLaunchKernelGGL(sweep1_kernel, dim3(waves / kSweep1Waves), dim3(kSweep1Waves * 64), 0, s, db, qs1, acc, num_per, dim0);
+    if (db1_packed(num_per, dim0)) {
+        hipLaunchKernelGGL(sweep1_kernel, dim3((kN / kSweep1Z) * (num_per >> 6)), dim3(kSweep1Z * 64), 0, s, db, qs1, acc, num_per, dim0);
     } else {
         hipLaunchKernelGGL(sweep1_small_kernel, dim3((kN * num_per + 255) / 256), dim3(256), 0, s, db, qs1, acc, num_per, dim0);
     }
@@ -100,7 +153,8 @@ __global__ __launch_bounds__(256) void db1_relayout_kernel(const uint64_t* __res
     if (z >= kN) return;
     const size_t rem = o - (size_t)z * per_z;
     const uint32_t ii = (uint32_t)(rem / dim0), j = (uint32_t)(rem % dim0);
-    dev[db1_word_index(pk_pos(z), j, ii, num_per, dim0)] = ref[o];
+    const uint64_t v = ref[o];
+    db1_put_word(dev, pk_pos(z), j, ii, num_per, dim0, pack(lo32(v) % kP, hi32(v) % kB));
 }
 void launch_db1_relayout(const uint64_t* ref, uint64_t* dev, uint32_t num_per, uint32_t dim0, hipStream_t s) {
     const size_t words = (size_t)kN * num_per * dim0;
@@ -173,6 +227,23 @@ __global__ __launch_bounds__(kTpb) void pack_mac_kernel(const uint64_t* v_w, con
 }
 void launch_pack_mac(const uint64_t* v_w, const uint64_t* ginv, const uint64_t* ct2, uint64_t* result, uint32_t out_n, uint32_t t_conv, hipStream_t s) {
     hipLaunchKernelGGL(pack_mac_kernel, dim3(kBpp, (out_n + 1) * out_n), dim3(kTpb), 0, s, v_w, ginv, ct2, result, out_n, t_conv);
+}
+
+// arbitrary valid words (benchmarks)
+__global__ __launch_bounds__(256) void fill_db1_random_kernel(uint64_t* db, uint32_t num_per, uint32_t dim0, uint64_t seed) {
+    const uint64_t nwords = (uint64_t)kN * dim0 * num_per, stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < nwords; i += stride) {
+        uint64_t x = seed + i + 0x9E3779B97F4A7C15ull;
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+        x ^= x >> 31;
+        const uint32_t ii = (uint32_t)(i % num_per);
+        const uint64_t rest = i / num_per;
+        db1_put_word(db, (uint32_t)(rest / dim0), (uint32_t)(rest % dim0), ii, num_per, dim0, pack((uint32_t)(x & 0xffffffffull) % kP, (uint32_t)(x >> 32) % kB));
+    }
+}
+void launch_fill_db1_random(uint64_t* db_dev, uint32_t num_per, uint32_t dim0, uint64_t seed, hipStream_t s) {
+    hipLaunchKernelGGL(fill_db1_random_kernel, dim3(4096), dim3(256), 0, s, db_dev, num_per, dim0, seed);
 }
 
 }  // namespace spiral

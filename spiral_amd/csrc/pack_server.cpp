@@ -62,7 +62,7 @@ int pk_alloc(spiral_gpu_pack_server* S) {
     const spiral_gpu_params& p = S->p;
     const spiral_gpu_pack_shape& s = S->s;
     const size_t ngs = (size_t)p.nu2 * s.ell, rows = S->out_n + 1;
-    S->db_words = (size_t)kN * s.dim0 * s.num_per;
+    S->db_words = db1_device_words(s.num_per, s.dim0);  // u64 words of one trial in the device layout
     if (S->db.alloc(S->db_words * s.trials)) return -1;
     if (S->w_left.alloc((size_t)s.n_left * 2 * p.t_exp * kN)) return -1;
     if (S->w_right.alloc((size_t)s.n_right * 2 * p.t_exp_right * kN)) return -1;
@@ -165,7 +165,7 @@ int spiral_gpu_fast_multiply_query_by_database_dim1(uint64_t* out, const uint64_
     Scratch sc;
     const size_t words = (size_t)kN * dim0 * num_per;
     uint64_t* d_ref = sc.upload(db, words);
-    uint64_t* d_db = sc.get(words);
+    uint64_t* d_db = sc.get(db1_device_words((uint32_t)num_per, (uint32_t)dim0));
     uint64_t* d_re = sc.upload(v_firstdim, (size_t)kN * dim0 * 2);
     uint64_t* d_qs = sc.get((size_t)kN * dim0 * 2);
     uint64_t* d_acc = sc.get(num_per * 2 * kN);
@@ -240,8 +240,9 @@ int spiral_gpu_pack_server_load_db(spiral_gpu_pack_server* S, uint32_t trial, co
     if (trial >= S->s.trials) return fail("trial out of range");
     HIP_OK(hipSetDevice(S->device));
     DevBuf st;
-    if (st.alloc(S->db_words)) return -1;
-    hipError_t e = hipMemcpy(st.p, db, S->db_words * sizeof(uint64_t), hipMemcpyHostToDevice);
+    const size_t ref_words = (size_t)kN * S->s.dim0 * S->s.num_per;
+    if (st.alloc(ref_words)) return -1;
+    hipError_t e = hipMemcpy(st.p, db, ref_words * sizeof(uint64_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         launch_db1_relayout(st.p, S->db.p + (size_t)trial * S->db_words, S->s.num_per, S->s.dim0, S->stream);
         e = hipStreamSynchronize(S->stream);
@@ -255,7 +256,7 @@ int spiral_gpu_pack_server_load_db(spiral_gpu_pack_server* S, uint32_t trial, co
 int spiral_gpu_pack_server_fill_db_random(spiral_gpu_pack_server* S, uint64_t seed) {
     if (!S) return fail("null server");
     HIP_OK(hipSetDevice(S->device));
-    launch_fill_words_random(S->db.p, S->db.words, seed, S->stream);
+    for (uint32_t t = 0; t < S->s.trials; t++) launch_fill_db1_random(S->db.p + (size_t)t * S->db_words, S->s.num_per, S->s.dim0, seed + t, S->stream);
     HIP_OK(hipStreamSynchronize(S->stream));
     S->have_db = true;
     return 0;

@@ -242,19 +242,4 @@ void launch_fill_db_random(uint64_t* db_dev, uint32_t num_per, uint32_t dim0_sha
     hipLaunchKernelGGL(fill_db_random_kernel, dim3(4096), dim3(256), 0, s, db_dev, 2 * num_per, dim0_shard, seed);
 }
 
-// arbitrary valid 8-byte words, linear (the SpiralPack database layout, pack.hip)
-__global__ __launch_bounds__(256) void fill_words_random_kernel(uint64_t* db, uint64_t nwords, uint64_t seed) {
-    const uint64_t stride = (uint64_t)gridDim.x * 256u;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < nwords; i += stride) {
-        uint64_t x = seed + i + 0x9E3779B97F4A7C15ull;
-        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-        x ^= x >> 31;
-        db[i] = pack((uint32_t)(x & 0xffffffffull) % kP, (uint32_t)(x >> 32) % kB);
-    }
-}
-void launch_fill_words_random(uint64_t* db_dev, uint64_t nwords, uint64_t seed, hipStream_t s) {
-    hipLaunchKernelGGL(fill_words_random_kernel, dim3(2048), dim3(256), 0, s, db_dev, nwords, seed);
-}
-
 }  // namespace spiral
