@@ -214,7 +214,13 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
         }
         uint64_t* dst = p.dst + (size_t)di * kN + tid;  // pk_pos(8*tid + r) = r*256 + tid
 #pragma unroll
-        for (int r = 0; r < 8; r++) dst[r * 256] = pack(lo[r], hi[r]);
+        for (int r = 0; r < 8; r++) {
+#ifdef FWD_NT_STORE
+            __builtin_nontemporal_store(pack(lo[r], hi[r]), dst + r * 256);
+#else
+            dst[r * 256] = pack(lo[r], hi[r]);
+#endif
+        }
     } else if constexpr (STORE == ST_REF) {
         uint64_t* dst = p.dst + (size_t)p.dst_map(b) * (2 * kN) + 8u * tid;
 #pragma unroll
@@ -313,7 +319,11 @@ __global__ __launch_bounds__(256) void ntt_inverse_kernel(Tables t, InvParams p)
         const uint64_t* src = p.src + (size_t)sp * kN + tid;  // pk_pos(8*tid + r) = r*256 + tid
 #pragma unroll
         for (int r = 0; r < 8; r++) {
+#ifdef INV_NT_LOAD
+            const uint64_t v = __builtin_nontemporal_load(src + r * 256);
+#else
             const uint64_t v = src[r * 256];
+#endif
             lo[r] = lo32(v);
             hi[r] = hi32(v);
         }

@@ -63,7 +63,11 @@ __global__ __launch_bounds__(kTpb) void fold_mac_kernel(FoldMacParams p) {
         for (uint32_t r = 0; r < 3; r++) kv[r] = kp[((size_t)r * p.K + mm) * kN];
 #pragma unroll
         for (uint32_t b = 0; b < B; b++) {
+#ifndef MAC_PLAIN_LOADS  // streamed operand: read once, must not push the shared W / key rows out of L2 (-17 us on expand + convert)
+            const uint64_t d0 = __builtin_nontemporal_load(&dp[((size_t)b * p.K + mm) * 2 * kN]), d1 = __builtin_nontemporal_load(&dp[(((size_t)b * p.K + mm) * 2 + 1) * kN]);
+#else
             const uint64_t d0 = dp[((size_t)b * p.K + mm) * 2 * kN], d1 = dp[(((size_t)b * p.K + mm) * 2 + 1) * kN];
+#endif
 #pragma unroll
             for (uint32_t r = 0; r < 3; r++) {
                 acc[b][r][0].mac(kv[r], d0);
@@ -238,7 +242,11 @@ __global__ __launch_bounds__(kTpb) void expand_mac_round_kernel(ExpandMacParams 
     Acc2 acc0, acc1;
 #pragma unroll 7
     for (uint32_t k = kg; k < tdim; k += 4) {
+#ifndef MAC_PLAIN_LOADS  // streamed operand: read once, must not push the shared W / key rows out of L2 (-17 us on expand + convert)
+        const uint64_t gv = __builtin_nontemporal_load(&gp[(size_t)k * kN]);
+#else
         const uint64_t gv = gp[(size_t)k * kN];
+#endif
         acc0.mac(w[(size_t)k * kN], gv);
         acc1.mac(w[(size_t)(tdim + k) * kN], gv);
     }
