@@ -287,7 +287,11 @@ void launch_expand_mac_round(const ExpandMacParams& p, hipStream_t s) {
 __device__ __forceinline__ void scal2mat_slot(const uint64_t* w, const uint64_t* g, uint32_t t_conv, uint64_t cv1, uint32_t z, uint64_t out[3][2]) {
     Acc2 acc[3][2];
     for (uint32_t k = 0; k < t_conv; k++) {
+#ifndef S2M_PLAIN_LOADS  // digits are read once
+        uint64_t gv = __builtin_nontemporal_load(&g[(size_t)k * kN]);
+#else
         uint64_t gv = g[(size_t)k * kN];
+#endif
 #pragma unroll
         for (uint32_t r = 0; r < 3; r++) {
             const uint64_t* wr = w + ((size_t)r * 2 * t_conv + 2 * k) * kN + z;
