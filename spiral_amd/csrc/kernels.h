@@ -139,11 +139,6 @@ void launch_rescale(const uint64_t* in, uint64_t* out, uint32_t n, uint64_t inp_
 void launch_rescale2(const uint64_t* in, uint64_t* out, uint32_t n0, uint32_t n, uint64_t inp_mod, uint64_t out_mod0, uint64_t out_mod1, hipStream_t s);
 
 // ---- expansion / conversion / fold specials ----------------------------------------------------------
-// cv[dst0 + step*a] = neg1[r] * cv[src0 + step*a], both rows (src/spiral.cpp:1709)
-void launch_mul_neg1(uint64_t* cv, const uint64_t* neg1_r, uint32_t src0, uint32_t dst0, uint32_t step, uint32_t count, hipStream_t s);
-// cv[i][j] = cv[i][j] + sum_k W[j][k] * G[a][k] + j * A1[a],  i = i0 + step*a   (src/spiral.cpp:1722-1733)
-void launch_expand_mac(uint64_t* cv, const uint64_t* w, const uint64_t* g, const uint64_t* a1, uint32_t t_dim, uint32_t i0, uint32_t step,
-                       uint32_t count, hipStream_t s);
 // the same for a whole round in one launch: active ct a < cnt_e even (W_left, t_e digits) else odd (W_right, t_o);
 // g holds t digit polynomials per ct in LD_EXPAND job order; a1[2a + 1] is NTT(automorph(c_1)) of active ct a
 struct ExpandMacParams {
@@ -180,12 +175,10 @@ struct GswParams {
     const uint64_t* cv;
     IndexMap cv_pos;       // i (over dims*ell) -> ct index
     uint64_t* gsw;         // [dims][3][3*ell] PK, dimension d stored at index (dims-1-d)  (src/spiral.cpp:2324)
-    uint64_t* key;         // optional: the fold key of the same matrices (see launch_fold_key), written in the same pass
+    uint64_t* key;         // optional: the fold key of the same matrices, written in the same pass: key[d][r][0..m2) = G2 - gsw (= Q_neg, src/spiral.cpp:2361-2379), key[d][r][m2..2*m2) = gsw
     uint32_t t_conv, ell, dims;
 };
 void launch_regev_to_gsw(const GswParams& p, hipStream_t s);
-// fold key: key[d][r][0..m2) = G2 - gsw (= Q_neg, src/spiral.cpp:2361-2379), key[d][r][m2..2*m2) = gsw
-void launch_fold_key(const uint64_t* gsw, uint64_t* key, uint32_t dims, uint32_t ell, hipStream_t s);
 // the same key from the reference's reoriented (z, r, m) packed matrices (reorient_Q, src/spiral.cpp:388)
 void launch_fold_key_from_reoriented(const uint64_t* q_re, const uint64_t* qneg_re, uint64_t* key, uint32_t m2, hipStream_t s);
 

@@ -186,41 +186,6 @@ void launch_rescale(const uint64_t* in, uint64_t* out, uint32_t n, uint64_t inp_
 }
 
 // ---- coefficient expansion (src/spiral.cpp:1664-1743) -------------------------------------------------------
-// cv[dst0 + step*a][j] = neg1_r * cv[src0 + step*a][j]
-__global__ __launch_bounds__(kTpb) void mul_neg1_kernel(uint64_t* cv, const uint64_t* neg1_r, uint32_t src0, uint32_t dst0, uint32_t step) {
-    const uint32_t z = blockIdx.x * kTpb + threadIdx.x, a = blockIdx.y;
-    const uint64_t w = neg1_r[z];
-    const size_t si = (size_t)(src0 + step * a) * 2 * kN + z, di = (size_t)(dst0 + step * a) * 2 * kN + z;
-#pragma unroll
-    for (uint32_t j = 0; j < 2; j++) {
-        uint64_t x = cv[si + (size_t)j * kN];
-        cv[di + (size_t)j * kN] = pack(mod_p((uint64_t)lo32(x) * lo32(w)), mod_b((uint64_t)hi32(x) * hi32(w)));
-    }
-}
-void launch_mul_neg1(uint64_t* cv, const uint64_t* neg1_r, uint32_t src0, uint32_t dst0, uint32_t step, uint32_t count, hipStream_t s) {
-    if (count) hipLaunchKernelGGL(mul_neg1_kernel, dim3(kBpp, count), dim3(kTpb), 0, s, cv, neg1_r, src0, dst0, step);
-}
-
-// cv[i][j] = cv[i][j] + (W * G^-1(c'_0))[j] + j * NTT(c'_1),  i = i0 + step*a
-__global__ __launch_bounds__(kTpb) void expand_mac_kernel(uint64_t* cv, const uint64_t* w, const uint64_t* g, const uint64_t* a1, uint32_t t_dim,
-                                                          uint32_t i0, uint32_t step) {
-    const uint32_t z = blockIdx.x * kTpb + threadIdx.x, a = blockIdx.y;
-    const uint64_t* gp = g + (size_t)a * t_dim * kN + z;
-    Acc2 acc0, acc1;
-    for (uint32_t k = 0; k < t_dim; k++) {
-        uint64_t gv = gp[(size_t)k * kN];
-        acc0.mac(w[(size_t)k * kN + z], gv);
-        acc1.mac(w[(size_t)(t_dim + k) * kN + z], gv);
-    }
-    uint64_t* c = cv + (size_t)(i0 + step * a) * 2 * kN + z;
-    c[0] = add_pk(c[0], acc0.reduced());
-    c[kN] = add_pk(add_pk(c[kN], acc1.reduced()), a1[(size_t)a * kN + z]);
-}
-void launch_expand_mac(uint64_t* cv, const uint64_t* w, const uint64_t* g, const uint64_t* a1, uint32_t t_dim, uint32_t i0, uint32_t step,
-                       uint32_t count, hipStream_t s) {
-    if (count) hipLaunchKernelGGL(expand_mac_kernel, dim3(kBpp, count), dim3(kTpb), 0, s, cv, w, g, a1, t_dim, i0, step);
-}
-
 // whole-round MAC: 64 slots x 4 k-groups per workgroup, partial sums combined through LDS
 __global__ __launch_bounds__(kTpb) void expand_mac_round_kernel(ExpandMacParams p) {
     __shared__ uint64_t sh[3][64][4];
@@ -406,30 +371,7 @@ void launch_regev_to_gsw(const GswParams& p, hipStream_t s) {
     if (p.dims) hipLaunchKernelGGL(regev_to_gsw_kernel, dim3(kBpp, p.dims * p.ell), dim3(kTpb), 0, s, p);
 }
 
-// ---- fold key (src/spiral.cpp:2361-2386) ------------------------------------------------------------------------------
-// Q_neg = NTT(G2 - INTT(Q)) = NTT(G2) - Q slot-wise (the NTT is linear and a constant polynomial c has
-// NTT c in every slot); G2[r][mm] = 2^(bits*j) when mm == r + 3j (src/util.cpp:89-106)
-__global__ __launch_bounds__(kTpb) void fold_key_kernel(const uint64_t* gsw, uint64_t* key, uint32_t ell) {
-    const uint32_t z = blockIdx.x * kTpb + threadIdx.x;
-    const uint32_t m2 = 3 * ell, rm = blockIdx.y, r = rm / m2, mm = rm - r * m2, d = blockIdx.z;
-    const uint64_t q = gsw[((size_t)d * 3 * m2 + rm) * kN + z];
-    uint32_t gp = 0, gb = 0;
-    if (mm % 3 == r) {
-        const uint32_t j = mm / 3, sh = get_bits_per(ell) * j;
-        if (sh < 64) {
-            gp = mod_p(1ull << sh);
-            gb = mod_b(1ull << sh);
-        }
-    }
-    const uint32_t np = csub(gp + kP - lo32(q), kP), nb = csub(gb + kB - hi32(q), kB);
-    uint64_t* k = key + ((size_t)d * 3 + r) * (2 * m2) * kN + z;
-    k[(size_t)mm * kN] = pack(np, nb);
-    k[(size_t)(m2 + mm) * kN] = q;
-}
-void launch_fold_key(const uint64_t* gsw, uint64_t* key, uint32_t dims, uint32_t ell, hipStream_t s) {
-    if (dims) hipLaunchKernelGGL(fold_key_kernel, dim3(kBpp, 9 * ell, dims), dim3(kTpb), 0, s, gsw, key, ell);
-}
-
+// ---- fold key from the reference's reoriented matrices (the resident path writes its keys in regev_to_gsw_kernel) --------
 __global__ __launch_bounds__(kTpb) void fold_key_from_reoriented_kernel(const uint64_t* q_re, const uint64_t* qneg_re, uint64_t* key, uint32_t m2) {
     const uint32_t z = blockIdx.x * kTpb + threadIdx.x, rm = blockIdx.y, r = rm / m2, mm = rm - r * m2;
     const size_t src = (size_t)z * (3 * m2) + rm;  // z in the reference's slot order

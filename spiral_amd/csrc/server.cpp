@@ -23,8 +23,8 @@ struct spiral_gpu_server {
     // expanded-ciphertext positions inside cv: first-dim j at j*pos_stride + pos_first, rest i at i*pos_stride + pos_rest
     uint32_t pos_stride = 1, pos_first = 0, pos_rest = 0, n_cv = 0;
 
-    DevBuf db, w_left, w_right, w, v, query, cv, ex_raw, ex_g, ex_a1;
-    DevBuf cv_raw, cv_g, gs_raw, gs_chat, gsw, key, cts_keep;
+    DevBuf db, w_left, w_right, w, v, query, cv, ex_raw, ex_g;
+    DevBuf cv_raw, cv_g, gsw, key, cts_keep;
     uint64_t *gs_raw_p = nullptr, *gs_chat_p = nullptr;  // the Regev->GSW halves of cv_raw / cv_g
     DevBuf qs, acc_own, raw, fold_d, fold_c, resp, stage;
     uint64_t* acc = nullptr;
@@ -45,7 +45,7 @@ struct spiral_gpu_server {
     // when n_src*ell <= fold_dmax, one per polynomial when n_src >= fold_lmin, and the separate lift + digit
     // transforms otherwise.  SPIRAL_FOLD_CHAIN / SPIRAL_FOLD_DMAX / SPIRAL_FOLD_LMIN override (tuning only).
     bool fold_chain = true;
-    uint32_t fold_dmax = 1024, fold_lmin = 768;
+    uint32_t fold_dmax = 512, fold_lmin = 768;
     uint32_t fold_g_log = 0;  // distributed fold over 2^fold_g_log ranks: the sweep groups its output by ii mod G
 };
 
@@ -98,8 +98,8 @@ void srv_drop_graphs(spiral_gpu_server* S) {
 
 void srv_free(spiral_gpu_server* S) {
     srv_drop_graphs(S);
-    DevBuf* all[] = {&S->db, &S->w_left, &S->w_right, &S->w, &S->v, &S->query, &S->cv, &S->ex_raw, &S->ex_g, &S->ex_a1, &S->cv_raw,
-                     &S->cv_g, &S->gs_raw, &S->gs_chat, &S->gsw, &S->key, &S->cts_keep, &S->qs, &S->acc_own, &S->raw, &S->fold_d, &S->fold_c,
+    DevBuf* all[] = {&S->db, &S->w_left, &S->w_right, &S->w, &S->v, &S->query, &S->cv, &S->ex_raw, &S->ex_g, &S->cv_raw,
+                     &S->cv_g, &S->gsw, &S->key, &S->cts_keep, &S->qs, &S->acc_own, &S->raw, &S->fold_d, &S->fold_c,
                      &S->resp, &S->stage};
     for (DevBuf* b : all) b->release();
     for (auto& e : S->ev)
