@@ -1,0 +1,101 @@
+"""The N > 1 answer path as two real processes on one MI355X (both ranks on cuda:0, gloo collectives on device tensors):
+j-shards, run_pre_sweep / fold_local / fold_root replayed as hipGraphs, reduce-scatter and all-gather between them, exactly the
+call sequence of bench.py's step().  Checks the multi-process ordering between the library's stream work and
+torch.distributed that the single-process emulation (test_gpu_parity.py::test_distributed_fold_emulated_on_one_gpu) cannot."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, root_fold, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+
+    torch.cuda.is_available()  # torch initialises HIP first
+    import torch.distributed as dist
+
+    import spiral_amd as sa
+    from oracle import pyoracle as O
+    from spiral_amd import dist as sdist
+    from spiral_amd import server as SV
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    kw = dict(t_gsw=4)
+    po, pg = O.make_params(4, 4, **kw), sa.make_params(4, 4, **kw)
+    s = O.shape_of(po)
+    cl = O.Client(po, seed=77)  # same keys and queries on every rank
+    wl, wr, w, v = cl.pub_params()
+    j0, j1 = sdist.shard_range(rank, world, s.dim0)
+    srv = sa.Server(pg, 0, j0, j1)
+    stream = torch.cuda.Stream(device=dev)
+    srv.set_stream(stream.cuda_stream)
+    srv.gen_db(5)
+    srv.set_pub_params(wl, wr, w, v)
+    words = s.num_per * 6 * sa.N
+    acc = torch.zeros(words, dtype=torch.int64, device=dev)
+    srv.set_acc(acc.data_ptr())
+    G = 1 if root_fold else world
+    srv.set_fold_ranks(G)
+    chunk = torch.zeros(words // G, dtype=torch.int64, device=dev)
+    ct = torch.zeros(6 * sa.N, dtype=torch.int64, device=dev)
+    gathered = torch.zeros(G * 6 * sa.N, dtype=torch.int64, device=dev)
+    srv.use_graphs(True)
+    ok = True
+    db = O.gen_db(po, 5) if rank == 0 else None
+    with torch.cuda.stream(stream):
+        for idx in (9, 200, 255, 9):
+            qy = cl.query(idx)
+            srv.set_query(qy)
+            srv.run_pre_sweep()
+            if root_fold:
+                sdist.reduce_accumulators(acc, dst=0)
+                if rank == 0:
+                    srv.run_post(reduce_first=True)
+            else:
+                sdist.reduce_scatter_accumulators(chunk, acc)
+                srv.fold_local(chunk.data_ptr(), ct.data_ptr())
+                sdist.all_gather_cts(gathered, ct)
+                if rank == 0:
+                    srv.fold_root(gathered.data_ptr())
+            srv.sync()
+            if rank == 0:
+                want = O.answer(po, qy, wl, wr, w, v, db)
+                got = srv.read(SV.BUF_FINAL)
+                ok = ok and bool((got == want).all()) and bool((cl.decode(srv.read(SV.BUF_RESPONSE)) == O.db_item(po, 5, idx)).all())
+            dist.barrier()
+    srv.close()
+    if rank == 0:
+        q.put(ok)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("root_fold", [False, True])
+def test_two_processes_one_gpu(root_fold):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, root_fold, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert q.get(timeout=5) is True
