@@ -99,3 +99,20 @@ def test_two_processes_one_gpu(root_fold):
         p.join(timeout=300)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert q.get(timeout=5) is True
+
+
+def test_bench_two_rank_flow_on_one_gpu():
+    """bench.py's own N = 2 step loop (sampled stage events, run_pre_sweep, the collectives, fold_local / fold_root), launched the
+    way the driver launches it, with the two ranks sharing the one device and gloo standing in for RCCL: one JSON line from rank 0"""
+    import json
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--backend", "gloo", "--shared-device"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["value"] > 0 and out["scaling"] == "strong"
+    assert out["roofline"]["bound"] == "hbm" and out["roofline"]["achieved"] > 0
+    assert "reduce-scatter" in out["config"]["parallelism"]
