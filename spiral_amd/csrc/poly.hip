@@ -1,6 +1,7 @@
 // Pointwise polynomial kernels on PK (packed NTT) and RAW buffers, gfx950.
 // One thread per NTT slot / coefficient, 256-thread workgroups, 8 workgroups per polynomial.
 // All NTT-domain outputs are canonical residues in [0, m).
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 
@@ -242,8 +243,88 @@ __global__ __launch_bounds__(kTpb) void expand_mac_round_kernel(ExpandMacParams 
         }
     }
 }
+// the same with two adjacent slots per thread (16-byte loads, 1 KiB per wave instruction) for the wide rounds
+typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(kTpb) void expand_mac_round_wide_kernel(ExpandMacParams p) {
+    __shared__ uint64_t sh[3][64][8];
+    const uint32_t zz = threadIdx.x & 63u, kg = threadIdx.x >> 6, z = (blockIdx.x * 64u + zz) * 2u, a = blockIdx.y;
+    const bool odd = a >= p.cnt_e;
+    const uint32_t tdim = odd ? p.t_o : p.t_e;
+    const uint32_t i = odd ? 2u * (a - p.cnt_e) + 1u : 2u * a;
+    const size_t gbase = odd ? (size_t)p.cnt_e * p.t_e + (size_t)(a - p.cnt_e) * p.t_o : (size_t)a * p.t_e;
+    const uint64_t* w = (odd ? p.w_o : p.w_e) + z;
+    const uint64_t* gp = p.g + gbase * kN + z;
+    const uint32_t ao = a - p.cnt_e;
+    const bool make_next = kg == 0 && p.neg1n != nullptr && (!odd || ao + (p.next_num_in >> 1) < p.next_cnt_o);
+    u64x2_t nw = {0, 0}, nws = {0, 0};
+    if (make_next) {
+        nw = *reinterpret_cast<const u64x2_t*>(p.neg1n + z);
+        nws = *reinterpret_cast<const u64x2_t*>(p.neg1ns + z);
+    }
+    Acc2 acc0[2], acc1[2];
+#pragma unroll 7
+    for (uint32_t k = kg; k < tdim; k += 4) {
+        const u64x2_t gv = __builtin_nontemporal_load(reinterpret_cast<const u64x2_t*>(gp + (size_t)k * kN));
+        const u64x2_t w0 = *reinterpret_cast<const u64x2_t*>(w + (size_t)k * kN), w1 = *reinterpret_cast<const u64x2_t*>(w + (size_t)(tdim + k) * kN);
+        acc0[0].mac(w0.x, gv.x);
+        acc0[1].mac(w0.y, gv.y);
+        acc1[0].mac(w1.x, gv.x);
+        acc1[1].mac(w1.y, gv.y);
+    }
+    if (kg > 0) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            sh[kg - 1][zz][4 * h + 0] = acc0[h].lo;
+            sh[kg - 1][zz][4 * h + 1] = acc0[h].hi;
+            sh[kg - 1][zz][4 * h + 2] = acc1[h].lo;
+            sh[kg - 1][zz][4 * h + 3] = acc1[h].hi;
+        }
+    }
+    __syncthreads();
+    if (kg == 0) {
+        uint64_t c0[2], c1[2];
+        uint64_t* c = p.cv + (size_t)i * 2 * kN + z;
+        const u64x2_t old0 = *reinterpret_cast<const u64x2_t*>(c), old1 = *reinterpret_cast<const u64x2_t*>(c + kN);
+        const u64x2_t a1v = *reinterpret_cast<const u64x2_t*>(p.a1 + ((size_t)a * 2u + 1u) * kN + z);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) {  // <= 56 terms of < 2^56 in total: no overflow
+                acc0[h].lo += sh[q][zz][4 * h + 0];
+                acc0[h].hi += sh[q][zz][4 * h + 1];
+                acc1[h].lo += sh[q][zz][4 * h + 2];
+                acc1[h].hi += sh[q][zz][4 * h + 3];
+            }
+            c0[h] = add_pk(h ? old0.y : old0.x, acc0[h].reduced());
+            c1[h] = add_pk(add_pk(h ? old1.y : old1.x, acc1[h].reduced()), h ? a1v.y : a1v.x);
+        }
+        *reinterpret_cast<u64x2_t*>(c) = u64x2_t{c0[0], c0[1]};
+        *reinterpret_cast<u64x2_t*>(c + kN) = u64x2_t{c1[0], c1[1]};
+        if (make_next) {
+            uint64_t* n = p.cv + (size_t)(i + p.next_num_in) * 2 * kN + z;
+            uint64_t n0[2], n1[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint64_t ww = h ? nw.y : nw.x, ws = h ? nws.y : nws.x;
+                n0[h] = pack(csub(shoup32(lo32(c0[h]), lo32(ww), lo32(ws), kP), kP), csub(shoup32(hi32(c0[h]), hi32(ww), hi32(ws), kB), kB));
+                n1[h] = pack(csub(shoup32(lo32(c1[h]), lo32(ww), lo32(ws), kP), kP), csub(shoup32(hi32(c1[h]), hi32(ww), hi32(ws), kB), kB));
+            }
+            *reinterpret_cast<u64x2_t*>(n) = u64x2_t{n0[0], n0[1]};
+            *reinterpret_cast<u64x2_t*>(n + kN) = u64x2_t{n1[0], n1[1]};
+        }
+    }
+}
 void launch_expand_mac_round(const ExpandMacParams& p, hipStream_t s) {
-    if (p.cnt_e + p.cnt_o) hipLaunchKernelGGL(expand_mac_round_kernel, dim3(kN / 64, p.cnt_e + p.cnt_o), dim3(kTpb), 0, s, p);
+    const uint32_t cnt = p.cnt_e + p.cnt_o;
+    if (cnt == 0) return;
+    static const uint32_t wide_min = [] {
+        const char* e = getenv("SPIRAL_MAC_WIDE_MIN");  // tuning only
+        return e ? (uint32_t)strtoul(e, nullptr, 10) : 64u;
+    }();
+    if (cnt >= wide_min)
+        hipLaunchKernelGGL(expand_mac_round_wide_kernel, dim3(kN / 128, cnt), dim3(kTpb), 0, s, p);
+    else
+        hipLaunchKernelGGL(expand_mac_round_kernel, dim3(kN / 64, cnt), dim3(kTpb), 0, s, p);
 }
 
 // ---- scalToMat (src/spiral.cpp:1834-1885) ----------------------------------------------------------------------
