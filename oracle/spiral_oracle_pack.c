@@ -28,7 +28,7 @@ static uint32_t ceil_log2(uint64_t x) {
 }
 
 int orc_pack_get_shape(const orc_params *p, uint32_t out_n, orc_pack_shape *s) { /* src/testing.cpp:777-801 */
-    if (!p || !s || out_n < 1 || out_n > 8 || p->nu1 > 16 || p->nu2 > 16 || p->nu2 < 1 || p->t_gsw < 2) return -1;
+    if (!p || !s || out_n < 1 || out_n > 16 || p->nu1 > 16 || p->nu2 > 16 || p->nu2 < 1 || p->t_gsw < 2) return -1;
     if (p->qprime_bits >= 37 || QPRIME_MODS[p->qprime_bits] == 0) return -1;
     s->dim0 = 1u << p->nu1;
     s->num_per = 1u << p->nu2;
@@ -252,7 +252,7 @@ struct orc_pack_client {
     int nonoise;
     double cdf[129];
     uint64_t sr[N];
-    uint64_t sp[8 * N]; /* out_n x 1 */
+    uint64_t sp[16 * N]; /* out_n x 1, out_n <= 16 (the published parameter sets go up to 12) */
 };
 
 static uint64_t rng_next(orc_pack_client *c) {

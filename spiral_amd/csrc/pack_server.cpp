@@ -27,7 +27,7 @@ int pack_shape_of(const spiral_gpu_params* p, uint32_t out_n, spiral_gpu_pack_sh
     spiral_gpu_params q = *p;
     q.direct_upload = 1;  // validate the common fields without the base path's query-size rule
     if (shape_of(&q, &base)) return -1;
-    if (out_n < 1 || out_n > 8) return fail("out_n out of range");
+    if (out_n < 1 || out_n > 16) return fail("out_n out of range");
     if (p->nu2 < 1 || p->nu1 < 1) return fail("SpiralPack needs nu1 >= 1 and nu2 >= 1");
     s->dim0 = base.dim0;
     s->num_per = base.num_per;
@@ -147,7 +147,7 @@ int spiral_gpu_pack_get_shape(const spiral_gpu_params* p, uint32_t out_n, spiral
 int spiral_gpu_pack(uint64_t* result, uint32_t out_n, uint32_t m_conv, const uint64_t* v_ct, const uint64_t* v_W) {
     DeviceTables tb;
     if (current_tables(&tb)) return -1;
-    if (out_n < 1 || out_n > 8 || m_conv < 1 || m_conv > 56) return fail("bad pack dimensions");
+    if (out_n < 1 || out_n > 16 || m_conv < 1 || m_conv > 56) return fail("bad pack dimensions");
     Scratch sc;
     const uint32_t trials = out_n * out_n, rows = out_n + 1;
     uint64_t* d_ct = sc.upload(v_ct, (size_t)trials * 2 * kN);

@@ -57,6 +57,7 @@ def test_pack_seam(sa, oracle, out_n, t_conv):
         (5, 2, 3, dict(t_gsw=4)),
         (4, 6, 2, dict(t_gsw=4)),  # num_per = 64: the fast sweep path
         (3, 2, 2, dict(t_gsw=5, t_exp=2, qprime_bits=19, direct_upload=1)),
+        (3, 2, 12, dict(t_gsw=3, t_conv=56, t_exp=56, qprime_bits=31, p_db=524288, direct_upload=1)),  # n = 12: the "movie" set's shape of parameters
     ],
 )
 def test_pack_server_matches_oracle(sa, oracle, nu1, nu2, out_n, kw):
