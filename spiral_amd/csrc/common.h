@@ -49,28 +49,38 @@ __host__ __device__ inline uint32_t pk_pos(uint32_t s) { return ((s & 7u) << 8) 
 // Device database layout (internal; built at load time).  The nic = 2*num_per output columns ic = ii*2 + c are
 // grouped in blocks of 64 -- one wave of the sweep owns one (z, block) tile and streams it front to back.
 //
-// Packed layout (nic >= 64 and dim0 % 8 == 0, every real geometry): a database word is two 28-bit residues, so it is
-// stored in 7 bytes, not 8: the sweep is bound by streaming the database and 1/8 of the reference's bytes are zero bits.
-// A lane's 16 words of 8 consecutive j (j-major, m minor) form one 112-byte little-endian bit string, word w at bits
-// [56w, 56w + 56) = p-residue | b-residue << 28, fetched as 7 x 16 bytes:
-//     tile (z, ic/64) -> group j/8 -> chunk k < 7 -> lane ic%64 -> 16 bytes
-// so every load instruction of a wave still covers 1 KiB of consecutive addresses and a tile is one sequential stream of
-// dim0/8 * 7 KiB.
-// Plain layout (tiny test geometries): word(z, j, ic, m) at (((z*nblk + ic/W)*dim0 + j)*W + ic%W)*2 + m, W = min(64, nic).
+// Packed layout (dim0 % 8 == 0, every real geometry): a database word is two 28-bit residues, so it is stored in 7 bytes,
+// not 8: the sweep is bound by streaming the database and 1/8 of the reference's bytes are zero bits.  A lane's 16 words
+// of 8 consecutive j (j-major, m minor) form one 112-byte little-endian bit string, word w at bits [56w, 56w + 56) =
+// p-residue | b-residue << 28, fetched as 7 x 16 bytes:
+//     tile -> group j/8 -> chunk k < 7 -> lane -> 16 bytes
+// so every load instruction of a wave covers 1 KiB of consecutive addresses and a tile is one sequential stream of
+// dim0/8 * 7 KiB.  A tile is 64 lanes wide: W = min(64, nic) columns x P = 64/W consecutive z.  With nic >= 64 a tile is
+// (z, block of 64 columns); with fewer columns (small nu2: the streaming parameter sets) a wave takes P slots z at once,
+// lane = (z % P) * W + ic.
+// Plain layout (dim0 < 8, tiny test geometries only): word(z, j, ic, m) at (((z*nblk + ic/W)*dim0 + j)*W + ic%W)*2 + m.
 __host__ __device__ inline uint32_t db_block_width(uint32_t nic) { return nic < 64u ? nic : 64u; }
 __host__ __device__ inline size_t db_word_index(uint32_t z, uint32_t j, uint32_t ic, uint32_t m, uint32_t nic, uint32_t dim0) {
     const uint32_t w = db_block_width(nic), nblk = nic / w;
     return ((((size_t)z * nblk + ic / w) * dim0 + j) * w + ic % w) * 2u + m;
 }
-__host__ __device__ inline bool db_packed(uint32_t nic, uint32_t dim0) { return nic >= 64u && (dim0 & 7u) == 0u; }
+__host__ __device__ inline bool db_packed(uint32_t nic, uint32_t dim0) { return (dim0 & 7u) == 0u && nic >= 2u && (nic & (nic - 1u)) == 0u; }
 // u64 words to allocate for the device database of one shard
 __host__ __device__ inline size_t db_device_words(uint32_t nic, uint32_t dim0) {
     const size_t words = (size_t)kN * dim0 * nic * 2u;
     return db_packed(nic, dim0) ? words / 8u * 7u : words;
 }
+// tile and lane of (z, ic): W columns x P slots per tile
+__host__ __device__ inline void db_tile_lane(uint32_t z, uint32_t ic, uint32_t nic, uint32_t& tile, uint32_t& lane) {
+    const uint32_t w = db_block_width(nic), pz = 64u / w, nblk = nic / w;
+    tile = (z / pz) * nblk + ic / w;
+    lane = (z % pz) * w + ic % w;
+}
 // byte address of byte `by` < 7 of word (z, j, ic, m) in the packed layout
 __host__ __device__ inline size_t db_packed_byte(uint32_t z, uint32_t j, uint32_t ic, uint32_t m, uint32_t by, uint32_t nic, uint32_t dim0) {
-    const uint32_t tile = z * (nic >> 6) + (ic >> 6), lane = ic & 63u, b = 7u * ((j & 7u) * 2u + m) + by;
+    uint32_t tile, lane;
+    db_tile_lane(z, ic, nic, tile, lane);
+    const uint32_t b = 7u * ((j & 7u) * 2u + m) + by;
     return ((((size_t)tile * (dim0 >> 3) + (j >> 3)) * 7u + (b >> 4)) * 64u + lane) * 16u + (b & 15u);
 }
 // store one database word (p-residue | b-residue << 32, both < 2^28) in whichever layout the geometry uses

@@ -197,21 +197,23 @@ void launch_fill_db_random(uint64_t* db_dev, uint32_t num_per, uint32_t dim0_sha
 void launch_fill_db1_random(uint64_t* db_dev, uint32_t num_per, uint32_t dim0, uint64_t seed, hipStream_t s);
 
 // ---- SpiralPack (pack.hip; reference src/testing.cpp) -----------------------------------------------------------
-// device DB layout, 1 x 1 plaintexts.  Packed (num_per >= 64 and dim0 % 16 == 0, as the base path's, common.h): a word is two
-// 28-bit residues in 7 bytes; a lane's 16 words of 16 consecutive j are one 112-byte string fetched as 7 x 16 bytes:
-//     tile (z, ii/64) -> group j/16 -> chunk k < 7 -> lane ii%64 -> 16 bytes.
-// Plain (tiny geometries): word(z, j, ii) at (((z*nblk + ii/W)*(dim0/2) + j/2)*W + ii%W)*2 + (j&1), W = min(64, num_per)
+// device DB layout, 1 x 1 plaintexts.  Packed (dim0 % 16 == 0; as the base path's, common.h): a word is two 28-bit
+// residues in 7 bytes; a lane's 16 words of 16 consecutive j are one 112-byte string fetched as 7 x 16 bytes:
+//     tile -> group j/16 -> chunk k < 7 -> lane -> 16 bytes,
+// a tile being W = min(64, num_per) columns x P = 64/W consecutive slots z, lane = (z % P) * W + ii % W.
+// Plain (dim0 < 16, tiny geometries): word(z, j, ii) at (((z*nblk + ii/W)*(dim0/2) + j/2)*W + ii%W)*2 + (j&1)
 __host__ __device__ inline size_t db1_word_index(uint32_t z, uint32_t j, uint32_t ii, uint32_t num_per, uint32_t dim0) {
     const uint32_t w = num_per < 64u ? num_per : 64u, nblk = num_per / w;
     return ((((size_t)z * nblk + ii / w) * (dim0 / 2) + (j >> 1)) * w + ii % w) * 2u + (j & 1u);
 }
-__host__ __device__ inline bool db1_packed(uint32_t num_per, uint32_t dim0) { return num_per >= 64u && (dim0 & 15u) == 0u; }
+__host__ __device__ inline bool db1_packed(uint32_t num_per, uint32_t dim0) { return (dim0 & 15u) == 0u && num_per >= 1u && (num_per & (num_per - 1u)) == 0u; }
 __host__ __device__ inline size_t db1_device_words(uint32_t num_per, uint32_t dim0) {  // u64 words per trial
     const size_t words = (size_t)kN * dim0 * num_per;
     return db1_packed(num_per, dim0) ? words / 8u * 7u : words;
 }
 __host__ __device__ inline size_t db1_packed_byte(uint32_t z, uint32_t j, uint32_t ii, uint32_t by, uint32_t num_per, uint32_t dim0) {
-    const uint32_t tile = z * (num_per >> 6) + (ii >> 6), lane = ii & 63u, b = 7u * (j & 15u) + by;
+    const uint32_t w = num_per < 64u ? num_per : 64u, pz = 64u / w, nblk = num_per / w;
+    const uint32_t tile = (z / pz) * nblk + ii / w, lane = (z % pz) * w + ii % w, b = 7u * (j & 15u) + by;
     return ((((size_t)tile * (dim0 >> 4) + (j >> 4)) * 7u + (b >> 4)) * 64u + lane) * 16u + (b & 15u);
 }
 #ifdef __HIPCC__

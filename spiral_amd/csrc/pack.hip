@@ -49,20 +49,27 @@ __device__ __forceinline__ void mac4_packed(uint64_t (&a)[4], uint4 q, const uin
     a[2] += (uint64_t)q.z * bh;
     a[3] += (uint64_t)q.w * bh;
 }
+// WIDE (num_per >= 64): a wave is one slot z and 64 plaintext columns, query records wave-uniform.  !WIDE: a wave is
+// P = 64/num_per consecutive slots x num_per columns, every lane reads the records of its own z.
+template <bool WIDE>
 __global__ __launch_bounds__(kSweep1Z * 64) void sweep1_kernel(const uint64_t* __restrict__ db, const uint32_t* __restrict__ qs,
                                                                uint64_t* __restrict__ acc, uint32_t num_per, uint32_t dim0) {
     __shared__ uint64_t sh[kSweep1Z * kSweep1Row];
     const uint32_t lane = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t wpz = num_per >> 6;
+    const uint32_t w = WIDE ? 64u : num_per, pz = 64u / w, nblk = num_per / w;
     uint32_t work = blockIdx.x;
     if ((gridDim.x & 7u) == 0) work = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // XCD-aware, see sweep.hip
-    const uint32_t zg = work / wpz, iib = work - zg * wpz;
-    const uint32_t z = zg * kSweep1Z + wv, tile = z * wpz + iib, groups = dim0 >> 4;
+    const uint32_t zg = work / nblk, iib = work - zg * nblk, groups = dim0 >> 4;
+    // !WIDE: one workgroup per tile, its waves split the tile's j range and add their partial sums through LDS (sweep.hip)
+    const uint32_t ztile = WIDE ? zg * kSweep1Z + wv : zg, tile = ztile * nblk + iib;
+    const uint32_t gper = WIDE ? groups : (groups + kSweep1Z - 1u) / kSweep1Z;
+    const uint32_t gfirst = WIDE ? 0u : min(wv * gper, groups), glast = WIDE ? groups : min(gfirst + gper, groups);
+    const uint32_t z = WIDE ? ztile : ztile * pz + lane / w;
     const u32x4* dbp = reinterpret_cast<const u32x4*>(db) + (size_t)tile * groups * 7u * 64u + lane;
     const uint4* q = reinterpret_cast<const uint4*>(qs) + (size_t)z * dim0;
     uint64_t a[4] = {0, 0, 0, 0};
-    for (uint32_t g0 = 0; g0 < groups; g0 += 16) {  // 16 groups = 256 j = 256 terms per accumulator between reductions
-        const uint32_t gend = min(g0 + 16u, groups);
+    for (uint32_t g0 = gfirst; g0 < glast; g0 += 16) {  // 16 groups = 256 j = 256 terms per accumulator between reductions
+        const uint32_t gend = min(g0 + 16u, glast);
 #pragma unroll 2
         for (uint32_t g = g0; g < gend; g++) {
             uint32_t d[28];
@@ -97,11 +104,22 @@ __global__ __launch_bounds__(kSweep1Z * 64) void sweep1_kernel(const uint64_t* _
     sh[wv * kSweep1Row + lane * 2u] = pack((uint32_t)a[0], (uint32_t)a[2]);
     sh[wv * kSweep1Row + lane * 2u + 1u] = pack((uint32_t)a[1], (uint32_t)a[3]);
     __syncthreads();
-    // 128 (column, row) results x 16 consecutive z: thread -> (result, z) with z fastest; acc[ii][r][z]
+    if constexpr (WIDE) {  // 128 (column, row) results x 16 consecutive z: thread -> (result, z) with z fastest; acc[ii][r][z]
 #pragma unroll
-    for (uint32_t m = 0; m < 2; m++) {
-        const uint32_t idx = threadIdx.x + kSweep1Z * 64u * m, res = idx / kSweep1Z, zz = idx - res * kSweep1Z;
-        acc[((size_t)(iib * 64u) * 2u + res) * kN + zg * kSweep1Z + zz] = sh[zz * kSweep1Row + res];
+        for (uint32_t m = 0; m < 2; m++) {
+            const uint32_t idx = threadIdx.x + kSweep1Z * 64u * m, res = idx / kSweep1Z, zz = idx - res * kSweep1Z;
+            acc[((size_t)(iib * 64u) * 2u + res) * kN + zg * kSweep1Z + zz] = sh[zz * kSweep1Row + res];
+        }
+    } else if (threadIdx.x < 128u) {  // 64 lanes x 2 results of this tile, each the sum of the waves' partials
+        const uint32_t sl = threadIdx.x >> 1, r = threadIdx.x & 1u, zz = sl / w, col = sl - zz * w;
+        uint64_t sp = 0, sb = 0;
+#pragma unroll
+        for (uint32_t v = 0; v < kSweep1Z; v++) {
+            const uint64_t x = sh[v * kSweep1Row + threadIdx.x];
+            sp += lo32(x);
+            sb += hi32(x);
+        }
+        acc[((size_t)col * 2u + r) * kN + zg * pz + zz] = pack(mod_p(sp), mod_b(sb));
     }
 }
 __global__ __launch_bounds__(256) void sweep1_small_kernel(const uint64_t* __restrict__ db, const uint32_t* __restrict__ qs, uint64_t* __restrict__ acc,
@@ -119,7 +137,10 @@ __global__ __launch_bounds__(256) void sweep1_small_kernel(const uint64_t* __res
 }
 void launch_sweep1(const uint64_t* db, const uint32_t* qs1, uint64_t* acc, uint32_t num_per, uint32_t dim0, hipStream_t s) {
     if (db1_packed(num_per, dim0)) {
-        hipLaunchKernelGGL(sweep1_kernel, dim3((kN / kSweep1Z) * (num_per >> 6)), dim3(kSweep1Z * 64), 0, s, db, qs1, acc, num_per, dim0);
+        if (num_per >= 64)
+            hipLaunchKernelGGL(sweep1_kernel<true>, dim3((kN / kSweep1Z) * (num_per >> 6)), dim3(kSweep1Z * 64), 0, s, db, qs1, acc, num_per, dim0);
+        else  // one workgroup per tile of 64/num_per slots, its waves split the j range
+            hipLaunchKernelGGL(sweep1_kernel<false>, dim3(kN / (64 / num_per)), dim3(kSweep1Z * 64), 0, s, db, qs1, acc, num_per, dim0);
     } else {
         hipLaunchKernelGGL(sweep1_small_kernel, dim3((kN * num_per + 255) / 256), dim3(256), 0, s, db, qs1, acc, num_per, dim0);
     }

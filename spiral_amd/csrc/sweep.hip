@@ -97,24 +97,35 @@ __device__ __forceinline__ void mac_packed_j(uint64_t (&a)[6], const uint4* q, c
     a[4] += (uint64_t)qc.z * b1;
     a[5] += (uint64_t)qc.w * b1;
 }
+// WIDE (nic >= 64): a wave is one slot z and 64 columns, the query records are wave-uniform (SGPR operands).
+// !WIDE (nic = W < 64): a wave is P = 64/W consecutive slots x W columns, lane = (z % P) * W + column; every lane reads the
+// records of its own z (the W lanes of a slot read the same address), the rest is the same.
+template <bool WIDE>
 __global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __restrict__ db, const uint32_t* __restrict__ qs, uint64_t* __restrict__ acc,
                                                              uint32_t nic, uint32_t dim0, uint32_t g_log) {
     __shared__ uint64_t sh[kSweepZ * kSweepRow];
     const uint32_t lane = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t wpz = nic >> 6;  // column blocks (= waves) per z
-    // Workgroups go to the 8 XCDs round-robin by blockIdx, and each XCD has its own L2.  The wpz workgroups that share a
+    const uint32_t w = WIDE ? 64u : nic, pz = 64u / w, nblk = nic / w;  // columns and slots per tile, column blocks per slot group
+    // Workgroups go to the 8 XCDs round-robin by blockIdx, and each XCD has its own L2.  The nblk workgroups that share a
     // z-group read the same query records, so consecutive WORK items (not consecutive block ids) are given to one XCD:
     // block b = 8q + x takes work x * (nblocks/8) + q.  (FETCH_SIZE showed the records being fetched once per XCD that
     // touched them: 4 x 25 MB instead of 25 MB at config 2.)
     uint32_t work = blockIdx.x;
     if ((gridDim.x & 7u) == 0) work = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const uint32_t zg = work / wpz, icb = work - zg * wpz;
-    const uint32_t z = zg * kSweepZ + wv, tile = z * wpz + icb, groups = dim0 >> 3;
+    const uint32_t zg = work / nblk, icb = work - zg * nblk;  // WIDE: zg = group of kSweepZ slots; else one tile of pz slots
+    const uint32_t groups = dim0 >> 3;
+    // WIDE: the workgroup's waves take kSweepZ consecutive tiles whole.  !WIDE: there are only N/pz tiles, each a long
+    // stream, so the waves of a workgroup split ONE tile's j range between them (load concurrency is what buys bandwidth)
+    // and their partial sums are added through LDS.
+    const uint32_t ztile = WIDE ? zg * kSweepZ + wv : zg, tile = ztile * nblk + icb;
+    const uint32_t gper = WIDE ? groups : (groups + kSweepZ - 1u) / kSweepZ;
+    const uint32_t gfirst = WIDE ? 0u : min(wv * gper, groups), glast = WIDE ? groups : min(gfirst + gper, groups);
+    const uint32_t z = WIDE ? ztile : ztile * pz + lane / w;  // this lane's slot
     const u32x4* dbp = reinterpret_cast<const u32x4*>(db) + (size_t)tile * groups * 7u * 64u + lane;
-    const uint4* q = reinterpret_cast<const uint4*>(qs) + (size_t)z * dim0 * 3u;  // wave-uniform, 3 x uint4 per j
+    const uint4* q = reinterpret_cast<const uint4*>(qs) + (size_t)z * dim0 * 3u;  // 3 x uint4 per j; wave-uniform when WIDE
     uint64_t a[6] = {0, 0, 0, 0, 0, 0};
-    for (uint32_t g0 = 0; g0 < groups; g0 += 16) {  // 16 groups = 128 j = 256 terms per accumulator between reductions
-        const uint32_t gend = min(g0 + 16u, groups);
+    for (uint32_t g0 = gfirst; g0 < glast; g0 += 16) {  // 16 groups = 128 j = 256 terms per accumulator between reductions
+        const uint32_t gend = min(g0 + 16u, glast);
 #pragma unroll 2
         for (uint32_t g = g0; g < gend; g++) {
             uint32_t d[28];
@@ -141,21 +152,34 @@ __global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __r
 #pragma unroll
     for (uint32_t r = 0; r < 3; r++) sh[wv * kSweepRow + lane * 3u + r] = pack((uint32_t)a[r], (uint32_t)a[3 + r]);
     __syncthreads();
-    // 192 (column, row) results x kSweepZ consecutive z: thread -> (result, z) with z fastest.
+    // w*3 (column, row) results x kSweepZ*pz consecutive z: thread -> (result, z) with z fastest.
     // acc[perm(ii)][r][c][z], ic = ii*2 + c -> polynomial 6*perm(ii) + 2*r + c; perm groups the ciphertexts by ii mod G
     // (G = 2^g_log ranks of a distributed fold: rank g then owns the contiguous chunk ii = g + G*k, which is what one
     // reduce-scatter hands it); G = 1 is the identity.
     const uint32_t num_per = nic >> 1;
+    if constexpr (WIDE) {
 #pragma unroll
-    for (uint32_t m = 0; m < 3; m++) {
-        const uint32_t idx = threadIdx.x + kSweepZ * 64u * m, res = idx / kSweepZ, zz = idx - res * kSweepZ;
-        const uint32_t col = res / 3u, r = res - col * 3u, ic = icb * 64u + col, i0 = ic >> 1, c = ic & 1u;
+        for (uint32_t m = 0; m < 3; m++) {
+            const uint32_t idx = threadIdx.x + kSweepZ * 64u * m, res = idx / kSweepZ, zz = idx - res * kSweepZ;
+            const uint32_t col = res / 3u, r = res - col * 3u, ic = icb * 64u + col, i0 = ic >> 1, c = ic & 1u;
+            const uint32_t ii = (i0 & ((1u << g_log) - 1u)) * (num_per >> g_log) + (i0 >> g_log);
+            acc[((size_t)(6u * ii + 2u * r + c)) * kN + zg * kSweepZ + zz] = sh[zz * kSweepRow + res];
+        }
+    } else if (threadIdx.x < 192u) {  // 64 lanes x 3 results of this tile, each the sum of the kSweepZ waves' partials (< 16 * 2^28)
+        const uint32_t sl = threadIdx.x / 3u, r = threadIdx.x - sl * 3u, zz = sl / w, col = sl - zz * w, i0 = col >> 1, c = col & 1u;
+        uint64_t sp = 0, sb = 0;
+#pragma unroll
+        for (uint32_t v = 0; v < kSweepZ; v++) {
+            const uint64_t x = sh[v * kSweepRow + threadIdx.x];
+            sp += lo32(x);
+            sb += hi32(x);
+        }
         const uint32_t ii = (i0 & ((1u << g_log) - 1u)) * (num_per >> g_log) + (i0 >> g_log);
-        acc[((size_t)(6u * ii + 2u * r + c)) * kN + zg * kSweepZ + zz] = sh[zz * kSweepRow + res];
+        acc[((size_t)(6u * ii + 2u * r + c)) * kN + zg * pz + zz] = pack(mod_p(sp), mod_b(sb));
     }
 }
 
-// small-geometry path (plain layout: nic < 64 or dim0 % 8 != 0, test sizes only): one thread per (z, ic), no wave-uniform query
+// plain-layout path (dim0 < 8, test sizes only): one thread per (z, ic)
 __global__ __launch_bounds__(256) void sweep_small_kernel(const uint64_t* __restrict__ db, const uint32_t* __restrict__ qs,
                                                           uint64_t* __restrict__ acc, uint32_t nic, uint32_t dim0, uint32_t g_log) {
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
@@ -176,7 +200,10 @@ void launch_sweep(const uint64_t* db, const uint32_t* qs, uint64_t* acc, uint32_
     const uint32_t nic = 2 * num_per, dim0 = jm_total / 2;
     if (dim0 == 0) return;
     if (db_packed(nic, dim0)) {
-        hipLaunchKernelGGL(sweep_kernel, dim3((kN / kSweepZ) * (nic >> 6)), dim3(kSweepZ * 64), 0, s, db, qs, acc, nic, dim0, g_log);
+        if (nic >= 64)
+            hipLaunchKernelGGL(sweep_kernel<true>, dim3((kN / kSweepZ) * (nic >> 6)), dim3(kSweepZ * 64), 0, s, db, qs, acc, nic, dim0, g_log);
+        else  // one workgroup per tile of 64/nic slots, its waves split the j range
+            hipLaunchKernelGGL(sweep_kernel<false>, dim3(kN / (64 / nic)), dim3(kSweepZ * 64), 0, s, db, qs, acc, nic, dim0, g_log);
     } else {
         const uint32_t threads = kN * nic;
         hipLaunchKernelGGL(sweep_small_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, db, qs, acc, nic, dim0, g_log);
