@@ -229,7 +229,9 @@ __device__ __forceinline__ void db1_put_word(uint64_t* db, uint32_t z, uint32_t 
 }
 #endif
 // fastMultiplyQueryByDatabaseDim1 (src/testing.cpp:364): acc[ii][r][z] PK; qs1 records [z][j] = {p r0, p r1, b r0, b r1}
-void launch_sweep1(const uint64_t* db, const uint32_t* qs1, uint64_t* acc, uint32_t num_per, uint32_t dim0, hipStream_t s);
+// `trials` databases db + t*db_stride swept in one launch into acc + t*acc_stride (strides in u64 words)
+void launch_sweep1(const uint64_t* db, const uint32_t* qs1, uint64_t* acc, uint32_t num_per, uint32_t dim0, uint32_t trials, size_t db_stride,
+                   size_t acc_stride, hipStream_t s);
 // query records from the expanded cts: first-dimension ct j is cv[j * idx_factor] (reorientCiphertextsDim1, :342)
 void launch_qs1_from_cv(const uint64_t* cv, uint32_t* qs1, uint32_t dim0, uint32_t idx_factor, hipStream_t s);
 void launch_qs1_from_reoriented(const uint64_t* re, uint32_t* qs1, uint32_t dim0, hipStream_t s);

@@ -53,8 +53,11 @@ __device__ __forceinline__ void mac4_packed(uint64_t (&a)[4], uint4 q, const uin
 // P = 64/num_per consecutive slots x num_per columns, every lane reads the records of its own z.
 template <bool WIDE>
 __global__ __launch_bounds__(kSweep1Z * 64) void sweep1_kernel(const uint64_t* __restrict__ db, const uint32_t* __restrict__ qs,
-                                                               uint64_t* __restrict__ acc, uint32_t num_per, uint32_t dim0) {
+                                                               uint64_t* __restrict__ acc, uint32_t num_per, uint32_t dim0, size_t db_stride,
+                                                               size_t acc_stride) {
     __shared__ uint64_t sh[kSweep1Z * kSweep1Row];
+    db += (size_t)blockIdx.y * db_stride;  // blockIdx.y = trial: all trials of a query in one launch (same query records)
+    acc += (size_t)blockIdx.y * acc_stride;
     const uint32_t lane = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t w = WIDE ? 64u : num_per, pz = 64u / w, nblk = num_per / w;
     uint32_t work = blockIdx.x;
@@ -135,14 +138,20 @@ __global__ __launch_bounds__(256) void sweep1_small_kernel(const uint64_t* __res
     reduce4(a);
     store_acc1(acc, a, ii, z);
 }
-void launch_sweep1(const uint64_t* db, const uint32_t* qs1, uint64_t* acc, uint32_t num_per, uint32_t dim0, hipStream_t s) {
+void launch_sweep1(const uint64_t* db, const uint32_t* qs1, uint64_t* acc, uint32_t num_per, uint32_t dim0, uint32_t trials, size_t db_stride,
+                   size_t acc_stride, hipStream_t s) {
+    if (trials == 0) return;
     if (db1_packed(num_per, dim0)) {
         if (num_per >= 64)
-            hipLaunchKernelGGL(sweep1_kernel<true>, dim3((kN / kSweep1Z) * (num_per >> 6)), dim3(kSweep1Z * 64), 0, s, db, qs1, acc, num_per, dim0);
+            hipLaunchKernelGGL(sweep1_kernel<true>, dim3((kN / kSweep1Z) * (num_per >> 6), trials), dim3(kSweep1Z * 64), 0, s, db, qs1, acc, num_per, dim0,
+                               db_stride, acc_stride);
         else  // one workgroup per tile of 64/num_per slots, its waves split the j range
-            hipLaunchKernelGGL(sweep1_kernel<false>, dim3(kN / (64 / num_per)), dim3(kSweep1Z * 64), 0, s, db, qs1, acc, num_per, dim0);
+            hipLaunchKernelGGL(sweep1_kernel<false>, dim3(kN / (64 / num_per), trials), dim3(kSweep1Z * 64), 0, s, db, qs1, acc, num_per, dim0, db_stride,
+                               acc_stride);
     } else {
-        hipLaunchKernelGGL(sweep1_small_kernel, dim3((kN * num_per + 255) / 256), dim3(256), 0, s, db, qs1, acc, num_per, dim0);
+        for (uint32_t t = 0; t < trials; t++)
+            hipLaunchKernelGGL(sweep1_small_kernel, dim3((kN * num_per + 255) / 256), dim3(256), 0, s, db + t * db_stride, qs1, acc + t * acc_stride, num_per,
+                               dim0);
     }
 }
 

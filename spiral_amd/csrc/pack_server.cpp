@@ -172,7 +172,7 @@ int spiral_gpu_fast_multiply_query_by_database_dim1(uint64_t* out, const uint64_
     if (!d_ref || !d_db || !d_re || !d_qs || !d_acc) return fail("device allocation/upload failed");
     launch_db1_relayout(d_ref, d_db, (uint32_t)num_per, (uint32_t)dim0, 0);
     launch_qs1_from_reoriented(d_re, (uint32_t*)d_qs, (uint32_t)dim0, 0);
-    launch_sweep1(d_db, (const uint32_t*)d_qs, d_acc, (uint32_t)num_per, (uint32_t)dim0, 0);
+    launch_sweep1(d_db, (const uint32_t*)d_qs, d_acc, (uint32_t)num_per, (uint32_t)dim0, 1, 0, 0, 0);
     return download_pk(sc, d_acc, identity_map(), out, num_per * 2);
 }
 
@@ -324,8 +324,7 @@ int spiral_gpu_pack_server_answer(spiral_gpu_pack_server* S, const uint64_t* que
     launch_pack_fold_key(S->gsw.p, S->key.p, ell, p.nu2, st);
     HIP_OK(hipEventRecord(S->ev[2], st));
     // ---- first dimension for every trial (:1049-1051), then one INTT + CRT lift (:1055-1057)
-    for (uint32_t t = 0; t < s.trials; t++)
-        launch_sweep1(S->db.p + (size_t)t * S->db_words, (const uint32_t*)S->qs1.p, S->acc.p + (size_t)t * s.num_per * 2 * kN, s.num_per, s.dim0, st);
+    launch_sweep1(S->db.p, (const uint32_t*)S->qs1.p, S->acc.p, s.num_per, s.dim0, s.trials, S->db_words, (size_t)s.num_per * 2 * kN, st);
     HIP_OK(hipEventRecord(S->ev[3], st));
     {
         InvParams ip{};
