@@ -49,6 +49,10 @@ PUBLISHED = {
         "spiralstream": dict(_BASE, direct=1, nu_1=9, nu_2=5, p=16384, q_prime_bits=26, t_GSW=4, t_conv=16, t_exp=2),
         "spiralstream-pack": dict(_BASE, direct=1, n=5, nu_1=11, nu_2=3, p=65536, q_prime_bits=27, t_GSW=3, t_conv=56, t_exp=56),
     },
+    "20,100000": {  # BASELINE.json configs[3]: 2^20 x 100 KB; the two variants whose database (64 GiB, 7 instances by `factor`) fits one GPU
+        "spiral": dict(_BASE, nu_1=9, nu_2=11, p=256, q_prime_bits=20, t_GSW=10, t_conv=56, t_exp=16),
+        "spiralstream": dict(_BASE, direct=1, nu_1=11, nu_2=9, p=32768, q_prime_bits=27, t_GSW=4, t_conv=56, t_exp=2),
+    },
     "wiki": {
         "spiral": dict(_BASE, nu_1=9, nu_2=11, p=256, q_prime_bits=22, t_GSW=10, t_conv=4, t_exp=8),
         "spiral-pack": dict(_BASE, n=8, nu_1=10, nu_2=8, p=256, q_prime_bits=20, t_GSW=8, t_conv=4, t_exp=16),
@@ -60,7 +64,7 @@ PUBLISHED = {
         "spiralstream-pack": dict(_BASE, direct=1, n=12, nu_1=11, nu_2=3, p=524288, q_prime_bits=31, t_GSW=3, t_conv=56, t_exp=56),
     },
 }
-ITEM_BYTES = {"20,256": 256, "18,30000": 30000, "14,100000": 100000, "wiki": 30000, "movie": 2_000_000_000}
+ITEM_BYTES = {"20,256": 256, "18,30000": 30000, "14,100000": 100000, "20,100000": 100000, "wiki": 30000, "movie": 2_000_000_000}
 
 # select_params.py:386-401: what the reference scrapes from the executable's summary
 SCRAPE = {
