@@ -40,11 +40,14 @@ __device__ __forceinline__ uint64_t crt_compose(uint32_t x, uint32_t y) {
 }
 
 // Physical position of NTT slot s inside a PK polynomial.  The transforms hold slots 8*tid .. 8*tid+7 in thread tid,
-// so PK buffers are stored "thread-transposed": slot 8*tid + k lives at k*256 + tid.  A wave then reads / writes 512
-// contiguous bytes per instruction instead of 64 scattered 64-byte lines (the strided form made the forward
-// transforms store-bound).  Everything pointwise is oblivious to the order; only the boundary kernels that meet the
-// reference's slot order (ref<->PK conversion, database / query relayout) apply the map.
-__host__ __device__ inline uint32_t pk_pos(uint32_t s) { return ((s & 7u) << 8) | (s >> 3); }
+// so PK buffers are stored "thread-transposed" in pairs: slots 8*tid + 2q and 8*tid + 2q + 1 live at q*512 + 2*tid and
+// q*512 + 2*tid + 1.  A thread then moves its 8 slots with four 16-byte accesses and a wave reads / writes 1 KiB of
+// contiguous bytes per instruction instead of 64 scattered 64-byte lines (the strided form made the forward transforms
+// store-bound).  Everything pointwise is oblivious to the order; only the boundary kernels that meet the reference's
+// slot order (ref<->PK conversion, database / query relayout) apply the map.
+__host__ __device__ inline uint32_t pk_pos(uint32_t s) { return (((s & 7u) >> 1) << 9) | ((s >> 3) << 1) | (s & 1u); }
+// the same for register k of thread tid (slot 8*tid + k)
+__host__ __device__ inline uint32_t pk_pos_tk(uint32_t tid, uint32_t k) { return ((k >> 1) << 9) + 2u * tid + (k & 1u); }
 
 // Device database layout (internal; built at load time).  The nic = 2*num_per output columns ic = ii*2 + c are
 // grouped in blocks of 64 -- one wave of the sweep owns one (z, block) tile and streams it front to back.

@@ -207,6 +207,42 @@ __device__ __forceinline__ void lds_get(const uint64_t* sh, uint32_t tid, uint32
     }
 }
 
+// ---- PK polynomial <-> the 8 slots of a thread (common.h pk_pos): four 16-byte accesses -------------------------
+typedef unsigned long long pk_u64x2 __attribute__((ext_vector_type(2)));
+template <bool NT = false>
+__device__ __forceinline__ void pk_load8(const uint64_t* poly, uint32_t tid, uint64_t (&v)[8]) {
+    const pk_u64x2* src = reinterpret_cast<const pk_u64x2*>(poly) + tid;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const pk_u64x2 x = NT ? __builtin_nontemporal_load(src + q * 256) : src[q * 256];
+        v[2 * q] = x.x;
+        v[2 * q + 1] = x.y;
+    }
+}
+template <bool NT = false>
+__device__ __forceinline__ void pk_store8(uint64_t* poly, uint32_t tid, const uint64_t (&v)[8]) {
+    pk_u64x2* dst = reinterpret_cast<pk_u64x2*>(poly) + tid;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const pk_u64x2 x = {v[2 * q], v[2 * q + 1]};
+        if (NT)
+            __builtin_nontemporal_store(x, dst + q * 256);
+        else
+            dst[q * 256] = x;
+    }
+}
+__device__ __forceinline__ void pk_unpack8(const uint64_t (&v)[8], uint32_t* lo, uint32_t* hi) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        lo[k] = lo32(v[k]);
+        hi[k] = hi32(v[k]);
+    }
+}
+__device__ __forceinline__ void pk_pack8(const uint32_t* lo, const uint32_t* hi, uint64_t (&v)[8]) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = pack(lo[k], hi[k]);
+}
+
 // Forward transform of the 2048 coefficients held as (lo,hi)[k] <-> index ix_a(tid,k), values < 2m.
 // On return (lo,hi)[k] <-> slot ix_d(tid,k) = 8*tid + k, canonical in [0, m).
 // Bounds: < 2m in; +6m per pass: < 14m after passes A and B -> reduced to < 2m; < 12m after C and D.

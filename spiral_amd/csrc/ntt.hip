@@ -212,15 +212,13 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
         } else {
             di = p.dst_map(b);
         }
-        uint64_t* dst = p.dst + (size_t)di * kN + tid;  // pk_pos(8*tid + r) = r*256 + tid
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
+        uint64_t v[8];
+        pk_pack8(lo, hi, v);
 #ifdef FWD_NT_STORE
-            __builtin_nontemporal_store(pack(lo[r], hi[r]), dst + r * 256);
+        pk_store8<true>(p.dst + (size_t)di * kN, tid, v);
 #else
-            dst[r * 256] = pack(lo[r], hi[r]);
+        pk_store8(p.dst + (size_t)di * kN, tid, v);
 #endif
-        }
     } else if constexpr (STORE == ST_REF) {
         uint64_t* dst = p.dst + (size_t)p.dst_map(b) * (2 * kN) + 8u * tid;
 #pragma unroll
@@ -232,14 +230,14 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
         const uint64_t item = p.item_base + b;
         const uint32_t ii = (uint32_t)(item % p.num_per), j = (uint32_t)(item / p.num_per);
 #pragma unroll
-        for (int r = 0; r < 8; r++) db1_put_word(p.dst, r * 256u + tid, j, ii, p.num_per, p.dim0_shard, pack(lo[r], hi[r]));  // z = pk_pos(slot)
+        for (int r = 0; r < 8; r++) db1_put_word(p.dst, pk_pos_tk(tid, r), j, ii, p.num_per, p.dim0_shard, pack(lo[r], hi[r]));  // z = pk_pos(slot)
     } else {  // ST_DB: scatter into the sweep layout
         const uint64_t item = p.item_base + (b >> 2);
         const uint32_t mc = b & 3u, m = mc >> 1, c = mc & 1u;
         const uint32_t ii = (uint32_t)(item % p.num_per), j = (uint32_t)(item / p.num_per);
         const uint32_t ic = ii * 2u + c, nic = 2u * p.num_per;
 #pragma unroll
-        for (int r = 0; r < 8; r++) db_put_word(p.dst, r * 256u + tid, j - p.j0, ic, m, nic, p.dim0_shard, pack(lo[r], hi[r]));  // z = pk_pos(slot)
+        for (int r = 0; r < 8; r++) db_put_word(p.dst, pk_pos_tk(tid, r), j - p.j0, ic, m, nic, p.dim0_shard, pack(lo[r], hi[r]));  // z = pk_pos(slot)
     }
 }
 
@@ -264,47 +262,42 @@ __global__ __launch_bounds__(256) void ntt_inverse_kernel(Tables t, InvParams p)
         // round 0 may take the query ciphertext from its own buffer; cv[0] is then written here as well
         const bool from_query = p.create_here && p.query != nullptr;
         const uint64_t* src = (from_query ? p.query : p.cv) + ((size_t)(created ? i - p.num_in : i) * 2u + row) * kN;
-        if (from_query && !created) {
-            uint64_t* dstc = p.cv + ((size_t)i * 2u + row) * kN + tid;
-#pragma unroll
-            for (int r = 0; r < 8; r++) dstc[r * 256] = src[r * 256 + tid];
-        }
+        uint64_t* dstc = p.cv + ((size_t)i * 2u + row) * kN;
+        uint64_t v[8];
+        if (created || row == 0 || from_query) pk_load8(src, tid, v);
+        if (from_query && !created) pk_store8(dstc, tid, v);
         if (created) {
-            const uint64_t* ng = p.neg1 + tid;
-            const uint64_t* ngs = p.neg1s + tid;
-            uint64_t* dstc = p.cv + ((size_t)i * 2u + row) * kN + tid;
+            uint64_t w[8], ws[8];
+            pk_load8(p.neg1, tid, w);
+            pk_load8(p.neg1s, tid, ws);
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                const uint64_t v = src[r * 256 + tid], w = ng[r * 256], ws = ngs[r * 256];
-                lo[r] = csub(shoup(lo32(v), lo32(w), lo32(ws), kP), kP);
-                hi[r] = csub(shoup(hi32(v), hi32(w), hi32(ws), kB), kB);
-                dstc[r * 256] = pack(lo[r], hi[r]);
+                lo[r] = csub(shoup(lo32(v[r]), lo32(w[r]), lo32(ws[r]), kP), kP);
+                hi[r] = csub(shoup(hi32(v[r]), hi32(w[r]), hi32(ws[r]), kB), kB);
+                v[r] = pack(lo[r], hi[r]);
             }
+            pk_store8(dstc, tid, v);
         } else if (row == 0) {
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const uint64_t v = src[r * 256 + tid];
-                lo[r] = lo32(v);
-                hi[r] = hi32(v);
-            }
+            pk_unpack8(v, lo, hi);
         }
         if (row == 1) {
             // Row 1 only needs NTT(automorph(c_1)), and in the transform domain the automorphism x -> x^t is a slot
             // permutation: slot s evaluates at psi^(2 brev(s) + 1), so out[s] = in[s'] with 2 brev(s') + 1 =
             // (2 brev(s) + 1) t mod 2N.  The residues are the same canonical values the reference gets by going
             // through the coefficient domain (src/spiral.cpp:1713-1720), without the two transforms.
-            uint64_t* out = p.dst + (size_t)b * kN + tid;
+            uint64_t o[8];
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const uint32_t e = ((2u * (__brev(8u * tid + r) >> 21) + 1u) * p.auto_t) & (2u * kN - 1u);
                 const uint32_t pp = pk_pos(__brev(e >> 1) >> 21);
-                uint64_t v = src[pp];
+                uint64_t x = src[pp];
                 if (created) {
                     const uint64_t w = p.neg1[pp], ws = p.neg1s[pp];
-                    v = pack(csub(shoup(lo32(v), lo32(w), lo32(ws), kP), kP), csub(shoup(hi32(v), hi32(w), hi32(ws), kB), kB));
+                    x = pack(csub(shoup(lo32(x), lo32(w), lo32(ws), kP), kP), csub(shoup(hi32(x), hi32(w), hi32(ws), kB), kB));
                 }
-                out[r * 256] = v;
+                o[r] = x;
             }
+            pk_store8(p.dst + (size_t)b * kN, tid, o);
             return;
         }
     } else if (p.src_ref) {
@@ -316,17 +309,9 @@ __global__ __launch_bounds__(256) void ntt_inverse_kernel(Tables t, InvParams p)
         }
     } else {
         const uint32_t sp = (p.split && b >= p.split) ? p.src_map2(b - p.split) : p.src_map(b);
-        const uint64_t* src = p.src + (size_t)sp * kN + tid;  // pk_pos(8*tid + r) = r*256 + tid
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-#ifdef INV_NT_LOAD
-            const uint64_t v = __builtin_nontemporal_load(src + r * 256);
-#else
-            const uint64_t v = src[r * 256];
-#endif
-            lo[r] = lo32(v);
-            hi[r] = hi32(v);
-        }
+        uint64_t v[8];
+        pk_load8(p.src + (size_t)sp * kN, tid, v);
+        pk_unpack8(v, lo, hi);
     }
     if (p.pre_reduce) {
 #pragma unroll
@@ -383,13 +368,9 @@ __global__ __launch_bounds__(256) void fold_chain_kernel(Tables t, FoldChainPara
     const uint32_t s = LOOP ? b : b / p.ell;
     uint32_t lo[8], hi[8];
     {
-        const uint64_t* src = p.src + (size_t)s * kN + tid;
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const uint64_t v = src[r * 256];
-            lo[r] = lo32(v);
-            hi[r] = hi32(v);
-        }
+        uint64_t x[8];
+        pk_load8(p.src + (size_t)s * kN, tid, x);
+        pk_unpack8(x, lo, hi);
     }
     if (p.pre_reduce) {
 #pragma unroll
@@ -412,9 +393,9 @@ __global__ __launch_bounds__(256) void fold_chain_kernel(Tables t, FoldChainPara
         for (int r = 0; r < 8; r++) sdigit_of(v[r], sd, lo[r], hi[r]);
         if (LOOP && k > k0) __syncthreads();  // the previous transform's last LDS reads
         ntt_forward_block(lo, hi, sh, t.fwd, tid);
-        uint64_t* dst = p.dst + (size_t)(((i * 2u + hi_half) * m2 + row + 3u * k) * 2u + c) * kN + tid;
-#pragma unroll
-        for (int r = 0; r < 8; r++) dst[r * 256] = pack(lo[r], hi[r]);
+        uint64_t x[8];
+        pk_pack8(lo, hi, x);
+        pk_store8(p.dst + (size_t)(((i * 2u + hi_half) * m2 + row + 3u * k) * 2u + c) * kN, tid, x);
     }
 }
 

@@ -195,7 +195,16 @@ __global__ __launch_bounds__(ZW * 64) void sweep_zl(const uint64_t* __restrict__
         const uint32_t idx = threadIdx.x + ZW * 64u * m, res = idx / ZW, zz = idx - res * ZW;
         const uint32_t col = res / 3u, r = res - col * 3u, ic = icb * 64u + col, ii = ic >> 1, c = ic & 1u;
         uint64_t* dst = acc + ((size_t)(6u * ii + 2u * r + c)) * kN + zg * ZW + zz;
-        if (NTS == 1) __builtin_nontemporal_store(sh[zz * ROW + res], dst);
+        if (NTS == 3) {
+            const uint64_t val = sh[zz * ROW + res];
+            asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" ::"v"(dst), "v"(val) : "memory");
+        } else if (NTS == 4) {
+            const uint64_t val = sh[zz * ROW + res];
+            asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(val) : "memory");
+        } else if (NTS == 5) {
+            const uint64_t val = sh[zz * ROW + res];
+            asm volatile("global_store_dwordx2 %0, %1, off sc0 nt" ::"v"(dst), "v"(val) : "memory");
+        } else if (NTS == 1) __builtin_nontemporal_store(sh[zz * ROW + res], dst);
         else if (NTS == 2) __hip_atomic_store(dst, sh[zz * ROW + res], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         else *dst = sh[zz * ROW + res];
     }
@@ -387,6 +396,9 @@ int main(int argc, char** argv) {
         V("zl8 u16", hipLaunchKernelGGL((sweep_zl<16, 8>), dim3(kN / 8 * (nic / 64)), dim3(512), 0, 0, db, qs, acc, nic, dim0)),
         V("zl8 u8 nt-store", hipLaunchKernelGGL((sweep_zl<8, 8, 1>), dim3(kN / 8 * (nic / 64)), dim3(512), 0, 0, db, qs, acc, nic, dim0)),
         V("zl16 u8 nt-store", hipLaunchKernelGGL((sweep_zl<8, 16, 1>), dim3(kN / 16 * (nic / 64)), dim3(1024), 0, 0, db, qs, acc, nic, dim0)),
+        V("zl16 u8 asm sc0sc1nt", hipLaunchKernelGGL((sweep_zl<8, 16, 3>), dim3(kN / 16 * (nic / 64)), dim3(1024), 0, 0, db, qs, acc, nic, dim0)),
+        V("zl16 u8 asm sc1", hipLaunchKernelGGL((sweep_zl<8, 16, 4>), dim3(kN / 16 * (nic / 64)), dim3(1024), 0, 0, db, qs, acc, nic, dim0)),
+        V("zl16 u8 asm sc0nt", hipLaunchKernelGGL((sweep_zl<8, 16, 5>), dim3(kN / 16 * (nic / 64)), dim3(1024), 0, 0, db, qs, acc, nic, dim0)),
         V("zl8 u8 sys-store", hipLaunchKernelGGL((sweep_zl<8, 8, 2>), dim3(kN / 8 * (nic / 64)), dim3(512), 0, 0, db, qs, acc, nic, dim0)),
         V("zl16 u8 sys-store", hipLaunchKernelGGL((sweep_zl<8, 16, 2>), dim3(kN / 16 * (nic / 64)), dim3(1024), 0, 0, db, qs, acc, nic, dim0)),
         V("persist 4096w u8 w2", hipLaunchKernelGGL((sweep_p<8, true, 2>), dim3(2048), dim3(128), 0, 0, db, qs, acc, nic, dim0, kN * (nic / 64))),
