@@ -179,6 +179,8 @@ struct GswParams {
     uint32_t t_conv, ell, dims;
 };
 void launch_regev_to_gsw(const GswParams& p, hipStream_t s);
+// both conversion products in one launch when the record-writing ScalToMat applies (else the two launches)
+void launch_convert_products(const Scal2MatParams& sp, const GswParams& gp, hipStream_t s);
 // the same key from the reference's reoriented (z, r, m) packed matrices (reorient_Q, src/spiral.cpp:388)
 void launch_fold_key_from_reoriented(const uint64_t* q_re, const uint64_t* qneg_re, uint64_t* key, uint32_t m2, hipStream_t s);
 

@@ -375,9 +375,9 @@ __global__ __launch_bounds__(kTpb) void scal2mat_kernel(Scal2MatParams p) {
 // the same product for 16 ciphertexts x 16 slots per workgroup, records only: the 48-byte sweep records of one slot and
 // consecutive j are adjacent in memory, so the workgroup transposes its results through LDS and writes 768-byte runs
 // (one thread per slot and ciphertext writes 16-byte pieces 12 KiB apart instead)
-__global__ __launch_bounds__(kTpb) void scal2mat_rec_kernel(Scal2MatParams p) {
+__device__ __forceinline__ void scal2mat_rec_body(const Scal2MatParams& p, uint32_t bx, uint32_t by) {
     __shared__ uint4 sh[16][16][3];  // [slot][ct][piece]
-    const uint32_t zl = threadIdx.x & 15u, al = threadIdx.x >> 4, z0 = blockIdx.x * 16u, a0 = blockIdx.y * 16u;
+    const uint32_t zl = threadIdx.x & 15u, al = threadIdx.x >> 4, z0 = bx * 16u, a0 = by * 16u;
     {
         const uint32_t z = z0 + zl, a = a0 + al;
         const uint64_t cv1 = p.cv[((size_t)p.cv_pos(a) * 2 + 1) * kN + z];
@@ -404,8 +404,10 @@ __global__ __launch_bounds__(kTpb) void scal2mat_rec_kernel(Scal2MatParams p) {
 #endif
     }
 }
+__global__ __launch_bounds__(kTpb) void scal2mat_rec_kernel(Scal2MatParams p) { scal2mat_rec_body(p, blockIdx.x, blockIdx.y); }
+static bool scal2mat_rec_ok(const Scal2MatParams& p) { return p.count && p.count % 16 == 0 && p.qs && !p.out; }
 void launch_scal2mat(const Scal2MatParams& p, hipStream_t s) {
-    if (p.count && p.count % 16 == 0 && p.qs && !p.out) {
+    if (scal2mat_rec_ok(p)) {
         hipLaunchKernelGGL(scal2mat_rec_kernel, dim3(kN / 16, p.count / 16), dim3(kTpb), 0, s, p);
         return;
     }
@@ -413,8 +415,8 @@ void launch_scal2mat(const Scal2MatParams& p, hipStream_t s) {
 }
 
 // ---- regevToGSW (src/spiral.cpp:1985-2025) ------------------------------------------------------------------------
-__global__ __launch_bounds__(kTpb) void regev_to_gsw_kernel(GswParams p) {
-    const uint32_t z = blockIdx.x * kTpb + threadIdx.x, di = blockIdx.y;  // di = d*ell + i
+__device__ __forceinline__ void regev_to_gsw_body(const GswParams& p, uint32_t bx, uint32_t by) {
+    const uint32_t z = bx * kTpb + threadIdx.x, di = by;  // di = d*ell + i
     const uint32_t d = di / p.ell, i = di - d * p.ell, tc = p.t_conv;
     const uint64_t* chat = p.chat + (size_t)di * 2 * tc * kN + z;
     const uint64_t cv1 = p.cv[((size_t)p.cv_pos(di) * 2 + 1) * kN + z];
@@ -446,6 +448,26 @@ __global__ __launch_bounds__(kTpb) void regev_to_gsw_kernel(GswParams p) {
                 key[((size_t)r * 2 * cols + cols + 3 * i + c) * kN] = q;
             }
         }
+    }
+}
+__global__ __launch_bounds__(kTpb) void regev_to_gsw_kernel(GswParams p) { regev_to_gsw_body(p, blockIdx.x, blockIdx.y); }
+// the two conversion products are independent: one launch, the first n1 blocks ScalToMat, the rest Regev->GSW
+__global__ __launch_bounds__(kTpb) void convert_products_kernel(Scal2MatParams sp, GswParams gp, uint32_t n1) {
+    const uint32_t b = blockIdx.x;
+    if (b < n1) {
+        scal2mat_rec_body(sp, b % (kN / 16u), b / (kN / 16u));
+    } else {
+        const uint32_t bb = b - n1;
+        regev_to_gsw_body(gp, bb % kBpp, bb / kBpp);
+    }
+}
+void launch_convert_products(const Scal2MatParams& sp, const GswParams& gp, hipStream_t s) {
+    if (scal2mat_rec_ok(sp) && gp.dims) {
+        const uint32_t n1 = (kN / 16u) * (sp.count / 16u), n2 = kBpp * gp.dims * gp.ell;
+        hipLaunchKernelGGL(convert_products_kernel, dim3(n1 + n2), dim3(kTpb), 0, s, sp, gp, n1);
+    } else {
+        launch_scal2mat(sp, s);
+        launch_regev_to_gsw(gp, s);
     }
 }
 void launch_regev_to_gsw(const GswParams& p, hipStream_t s) {

@@ -693,35 +693,35 @@ int convert_part(spiral_gpu_server* S, uint32_t what, hipStream_t st, bool mark_
     fp.n_digits = p.t_conv;
     fp.bits = get_bits_per(p.t_conv);
     launch_ntt_forward(S->tb, fp, LD_DIGIT, ST_PK, (n1 + n2) * p.t_conv, st);
-    if (what & CONV_S2M) {
-        Scal2MatParams sp{};
-        sp.w = S->w.p;
-        sp.g = S->cv_g.p;
-        sp.cv = S->cv.p;
-        sp.cv_pos = IndexMap{1, ps, S->j0 * ps + S->pos_first};
-        sp.out = S->keep_cts ? S->cts_keep.p : nullptr;
-        sp.qs = (uint32_t*)S->qs.p;
-        sp.t_conv = p.t_conv;
-        sp.count = S->dim0_shard;
-        sp.jm_total = 2 * S->dim0_shard;
-        sp.j_base = 0;
-        launch_scal2mat(sp, st);
+    Scal2MatParams sp{};
+    sp.w = S->w.p;
+    sp.g = S->cv_g.p;
+    sp.cv = S->cv.p;
+    sp.cv_pos = IndexMap{1, ps, S->j0 * ps + S->pos_first};
+    sp.out = S->keep_cts ? S->cts_keep.p : nullptr;
+    sp.qs = (uint32_t*)S->qs.p;
+    sp.t_conv = p.t_conv;
+    sp.count = S->dim0_shard;
+    sp.jm_total = 2 * S->dim0_shard;
+    sp.j_base = 0;
+    GswParams gp{};
+    gp.w = S->w.p;
+    gp.v = S->v.p;
+    gp.chat = S->gs_chat_p;
+    gp.cv = S->cv.p;
+    gp.cv_pos = IndexMap{1, ps, S->pos_rest};
+    gp.gsw = S->gsw.p;
+    gp.t_conv = p.t_conv;
+    gp.ell = s.ell;
+    gp.dims = p.nu2;
+    gp.key = S->key.p;  // fold keys in the same pass
+    if (what == CONV_BOTH && !mark_split) {  // the two products are independent: one launch
+        launch_convert_products(sp, gp, st);
+        return 0;
     }
+    if (what & CONV_S2M) launch_scal2mat(sp, st);
     if (mark_split) HIP_OK(hipEventRecord(S->ev[7], st));  // ScalToMat | RegevToGSW split of the reference summary
-    if (what & CONV_GSW) {
-        GswParams gp{};
-        gp.w = S->w.p;
-        gp.v = S->v.p;
-        gp.chat = S->gs_chat_p;
-        gp.cv = S->cv.p;
-        gp.cv_pos = IndexMap{1, ps, S->pos_rest};
-        gp.gsw = S->gsw.p;
-        gp.t_conv = p.t_conv;
-        gp.ell = s.ell;
-        gp.dims = p.nu2;
-        gp.key = S->key.p;  // fold keys in the same pass
-        launch_regev_to_gsw(gp, st);
-    }
+    if (what & CONV_GSW) launch_regev_to_gsw(gp, st);
     return 0;
 }
 int convert_scal2mat(spiral_gpu_server* S, hipStream_t st) { return convert_part(S, CONV_S2M, st); }
