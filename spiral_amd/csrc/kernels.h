@@ -100,14 +100,15 @@ void launch_ntt_inverse(const DeviceTables& t, const InvParams& p, uint32_t stor
 void launch_ntt_inverse_expand(const DeviceTables& t, const InvParams& p, uint32_t nblocks, hipStream_t s);
 
 // fold chain (ntt.hip): PK polynomials [2*np][3][2] -> inverse transform, CRT lift, balanced digits, forward transforms
-// into the fold operand layout D (as LD_SDIGIT); loop = one workgroup per polynomial, else one per (polynomial, digit)
+// into the fold operand layout D (as LD_SDIGIT); a workgroup handles one polynomial and dpb consecutive digits
 struct FoldChainParams {
     const uint64_t* src;
     uint64_t* dst;
     uint32_t ell, bits, fold_np;
     uint32_t pre_reduce;  // 1: fields are lazy sums (< 2^32), reduce mod m first
+    uint32_t dpb;         // digits per block, 1 .. ell
 };
-void launch_fold_chain(const DeviceTables& t, const FoldChainParams& p, uint32_t n_src, bool loop, hipStream_t s);
+void launch_fold_chain(const DeviceTables& t, const FoldChainParams& p, uint32_t n_src, hipStream_t s);
 
 // ---- layout conversion at the C-ABI boundary -------------------------------------------------------
 // reference polynomial b <-> packed polynomial pk_map(b)

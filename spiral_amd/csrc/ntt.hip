@@ -358,14 +358,16 @@ __global__ __launch_bounds__(256) void ntt_inverse_kernel(Tables t, InvParams p)
 // round's product) followed in registers by the balanced digits and forward transforms the next fold round consumes
 // (nttInvAndCrtLiftCiphertexts / from_ntt then split_and_crt, src/spiral.cpp:1349-1410, 270-330).  The inverse leaves
 // coefficient tid + 256k in register k, which is exactly what the forward transform wants, so nothing is exchanged and
-// the raw polynomial never goes to memory.  LOOP: one workgroup per source polynomial, all ell digits in turn (no
-// redundant work: for rounds that fill the chip); otherwise one workgroup per (polynomial, digit), each repeating the
-// inverse transform (the small late rounds, which are latency-bound: one launch less per round).
-template <bool LOOP>
+// the raw polynomial never goes to memory.
+// A block takes source polynomial s and digits [k0, k0 + dpb): one inverse transform, then dpb forward transforms.
+// dpb = ell: one workgroup per polynomial, no redundant work (rounds that fill the chip); dpb = 1: one workgroup per
+// (polynomial, digit), every digit job repeating the inverse transform (the last rounds, which are latency-bound); the host
+// picks dpb per round so that a round is about as many blocks as the chip holds.
 __global__ __launch_bounds__(256) void fold_chain_kernel(Tables t, FoldChainParams p) {
     __shared__ uint64_t sh[kLdsWords];
     const uint32_t tid = threadIdx.x, b = blockIdx.x;
-    const uint32_t s = LOOP ? b : b / p.ell;
+    const uint32_t cpp = (p.ell + p.dpb - 1u) / p.dpb;  // chunks per polynomial
+    const uint32_t s = b / cpp, k0 = (b - s * cpp) * p.dpb, k1 = min(k0 + p.dpb, p.ell);
     uint32_t lo[8], hi[8];
     {
         uint64_t x[8];
@@ -386,12 +388,11 @@ __global__ __launch_bounds__(256) void fold_chain_kernel(Tables t, FoldChainPara
     // source s = (ct i', r, c) over [2*np][3][2]; operand layout D[i' % np][(i' / np)*m2 + r + 3k][c]  (as LD_SDIGIT)
     const uint32_t ct = s / 6u, rc = s - ct * 6u, row = rc >> 1, c = rc & 1u;
     const uint32_t m2 = 3u * p.ell, hi_half = ct / p.fold_np, i = ct - hi_half * p.fold_np;
-    const uint32_t k0 = LOOP ? 0u : b - s * p.ell, k1 = LOOP ? p.ell : k0 + 1u;
     for (uint32_t k = k0; k < k1; k++) {
         const SDigit sd = sdigit_setup(k, p.bits, p.ell);
 #pragma unroll
         for (int r = 0; r < 8; r++) sdigit_of(v[r], sd, lo[r], hi[r]);
-        if (LOOP && k > k0) __syncthreads();  // the previous transform's last LDS reads
+        if (k > k0) __syncthreads();  // the previous transform's last LDS reads
         ntt_forward_block(lo, hi, sh, t.fwd, tid);
         uint64_t x[8];
         pk_pack8(lo, hi, x);
@@ -450,13 +451,10 @@ void launch_ntt_inverse(const DeviceTables& t, const InvParams& p, uint32_t stor
         hipLaunchKernelGGL((ntt_inverse_kernel<IST_LIMBS>), dim3(nblocks), dim3(256), 0, s, tb, p);
 }
 
-void launch_fold_chain(const DeviceTables& t, const FoldChainParams& p, uint32_t n_src, bool loop, hipStream_t s) {
+void launch_fold_chain(const DeviceTables& t, const FoldChainParams& p, uint32_t n_src, hipStream_t s) {
     if (n_src == 0) return;
     Tables tb{t.fwd, t.inv};
-    if (loop)
-        hipLaunchKernelGGL((fold_chain_kernel<true>), dim3(n_src), dim3(256), 0, s, tb, p);
-    else
-        hipLaunchKernelGGL((fold_chain_kernel<false>), dim3(n_src * p.ell), dim3(256), 0, s, tb, p);
+    hipLaunchKernelGGL(fold_chain_kernel, dim3(n_src * ((p.ell + p.dpb - 1u) / p.dpb)), dim3(256), 0, s, tb, p);
 }
 
 void launch_ref_to_pk(const uint64_t* ref, uint64_t* pk, uint32_t npolys, IndexMap pk_map, hipStream_t s) {

@@ -41,11 +41,11 @@ struct spiral_gpu_server {
     bool overlap = false, side_pending = false;
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // fold chain (fold_chain_kernel): a round with n_src source polynomials runs one workgroup per (polynomial, digit)
-    // when n_src*ell <= fold_dmax, one per polynomial when n_src >= fold_lmin, and the separate lift + digit
-    // transforms otherwise.  SPIRAL_FOLD_CHAIN / SPIRAL_FOLD_DMAX / SPIRAL_FOLD_LMIN override (tuning only).
+    // fold chain (fold_chain_kernel): a block lifts one source polynomial and transforms dpb of its digits; dpb is halved
+    // from ell until the round has at least fold_blocks blocks.  SPIRAL_FOLD_CHAIN=0 (separate lift + digit transforms) and
+    // SPIRAL_FOLD_BLOCKS override (tuning / tests).
     bool fold_chain = true;
-    uint32_t fold_dmax = 512, fold_lmin = 768;
+    uint32_t fold_blocks = 768;
     uint32_t fold_g_log = 0;  // distributed fold over 2^fold_g_log ranks: the sweep groups its output by ii mod G
 };
 
@@ -503,8 +503,7 @@ int spiral_gpu_server_create(const spiral_gpu_params* p, int device, uint32_t j_
     S->j1 = j_end;
     S->dim0_shard = j_end - j_begin;
     if (const char* e = getenv("SPIRAL_FOLD_CHAIN")) S->fold_chain = atoi(e) != 0;
-    if (const char* e = getenv("SPIRAL_FOLD_DMAX")) S->fold_dmax = (uint32_t)strtoul(e, nullptr, 10);
-    if (const char* e = getenv("SPIRAL_FOLD_LMIN")) S->fold_lmin = (uint32_t)strtoul(e, nullptr, 10);
+    if (const char* e = getenv("SPIRAL_FOLD_BLOCKS")) S->fold_blocks = (uint32_t)strtoul(e, nullptr, 10);
     if (p->direct_upload || s.stopround == 0) {
         S->pos_stride = 1;
         S->pos_first = 0;
@@ -803,7 +802,7 @@ int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t ro
     for (uint32_t d = d0; d < d0 + rounds; d++) {
         np /= 2;
         const uint32_t n_src = 2 * np * 6;
-        if (src_pk && S->fold_chain && (n_src * s.ell <= S->fold_dmax || n_src >= S->fold_lmin)) {
+        if (src_pk && S->fold_chain) {
             FoldChainParams cp{};
             cp.src = src_pk;
             cp.dst = S->fold_d.p;
@@ -811,7 +810,11 @@ int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t ro
             cp.bits = get_bits_per(s.ell);
             cp.fold_np = np;
             cp.pre_reduce = pre_reduce ? 1 : 0;
-            launch_fold_chain(S->tb, cp, n_src, n_src * s.ell > S->fold_dmax, S->stream);
+            // digits per block: as few blocks as keep the chip busy (every block repeats the inverse transform once)
+            uint32_t dpb = s.ell;
+            while (dpb > 1 && n_src * ((s.ell + dpb - 1) / dpb) < S->fold_blocks) dpb = (dpb + 1) / 2;
+            cp.dpb = dpb;
+            launch_fold_chain(S->tb, cp, n_src, S->stream);
         } else {
             if (src_pk) lift(n_src);
             FwdParams fp{};

@@ -295,10 +295,10 @@ def test_load_db_in_several_staging_passes(sa, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [
-    {"SPIRAL_FOLD_CHAIN": "0"},                                  # separate lift + digit transforms every round
-    {"SPIRAL_FOLD_DMAX": "0", "SPIRAL_FOLD_LMIN": "0"},          # fold_chain_kernel<LOOP> every round
-    {"SPIRAL_FOLD_DMAX": "100000", "SPIRAL_FOLD_LMIN": "0"},     # fold_chain_kernel per (polynomial, digit) every round
-    {"SPIRAL_FOLD_DMAX": "96", "SPIRAL_FOLD_LMIN": "384"},       # all three in one fold
+    {"SPIRAL_FOLD_CHAIN": "0"},          # separate lift + digit transforms every round
+    {"SPIRAL_FOLD_BLOCKS": "0"},         # fold_chain_kernel, one block per polynomial (all digits) every round
+    {"SPIRAL_FOLD_BLOCKS": "1000000"},   # fold_chain_kernel, one block per (polynomial, digit) every round
+    {"SPIRAL_FOLD_BLOCKS": "300"},       # mixed chunk sizes
 ])
 def test_fold_chain_schedules(sa, oracle, env, monkeypatch):
     """the fold's schedule variants (read from the environment when the server is created) all give the oracle's answer"""
