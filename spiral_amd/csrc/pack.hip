@@ -49,13 +49,18 @@ __device__ __forceinline__ void mac4_packed(uint64_t (&a)[4], uint4 q, const uin
     a[2] += (uint64_t)q.z * bh;
     a[3] += (uint64_t)q.w * bh;
 }
-// WIDE (num_per >= 64): a wave is one slot z and 64 plaintext columns, query records wave-uniform.  !WIDE: a wave is
-// P = 64/num_per consecutive slots x num_per columns, every lane reads the records of its own z.
-template <bool WIDE>
+// MODE 0 (num_per >= 64): a wave is one slot z and 64 plaintext columns, query records wave-uniform.  MODE 1, 2: a wave is
+// P = 64/num_per consecutive slots x num_per columns and every lane needs the records of its own z: loaded per lane
+// (MODE 1) or staged per wave in LDS (MODE 2, P <= 8), as sweep.hip.
+constexpr uint32_t kQ1Stage = 8 * 16;  // uint4 per wave: up to 8 slots x 16 j
+template <int MODE>
 __global__ __launch_bounds__(kSweep1Z * 64) void sweep1_kernel(const uint64_t* __restrict__ db, const uint32_t* __restrict__ qs,
                                                                uint64_t* __restrict__ acc, uint32_t num_per, uint32_t dim0, size_t db_stride,
                                                                size_t acc_stride) {
-    __shared__ uint64_t sh[kSweep1Z * kSweep1Row];
+    constexpr bool WIDE = MODE == 0;
+    constexpr uint32_t kShWords = MODE == 2 ? (kSweep1Z * kQ1Stage * 2 > kSweep1Z * kSweep1Row ? kSweep1Z * kQ1Stage * 2 : kSweep1Z * kSweep1Row)
+                                            : kSweep1Z * kSweep1Row;
+    __shared__ __attribute__((aligned(16))) uint64_t sh[kShWords];  // results; MODE 2: first the record staging (aliased)
     db += (size_t)blockIdx.y * db_stride;  // blockIdx.y = trial: all trials of a query in one launch (same query records)
     acc += (size_t)blockIdx.y * acc_stride;
     const uint32_t lane = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -85,6 +90,19 @@ __global__ __launch_bounds__(kSweep1Z * 64) void sweep1_kernel(const uint64_t* _
                 d[4 * k + 3] = v.w;
             }
             const uint4* qg = q + (size_t)g * 16u;
+            if constexpr (MODE == 2) {
+                uint4* qst = reinterpret_cast<uint4*>(sh) + wv * kQ1Stage;
+                const uint4* qsrc = reinterpret_cast<const uint4*>(qs);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();  // the previous group's reads of the staging area
+                for (uint32_t t = lane; t < pz * 16u; t += 64u) {
+                    const uint32_t zi = t >> 4, off = t & 15u;
+                    qst[t] = qsrc[(size_t)(ztile * pz + zi) * dim0 + (size_t)g * 16u + off];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                qg = qst + (lane / w) * 16u;
+            }
             mac4_packed<0>(a, qg[0], d);
             mac4_packed<1>(a, qg[1], d);
             mac4_packed<2>(a, qg[2], d);
@@ -104,6 +122,7 @@ __global__ __launch_bounds__(kSweep1Z * 64) void sweep1_kernel(const uint64_t* _
         }
         reduce4(a);
     }
+    if constexpr (MODE == 2) __syncthreads();  // every wave is done with its staging area before results overwrite it
     sh[wv * kSweep1Row + lane * 2u] = pack((uint32_t)a[0], (uint32_t)a[2]);
     sh[wv * kSweep1Row + lane * 2u + 1u] = pack((uint32_t)a[1], (uint32_t)a[3]);
     __syncthreads();
@@ -143,10 +162,13 @@ void launch_sweep1(const uint64_t* db, const uint32_t* qs1, uint64_t* acc, uint3
     if (trials == 0) return;
     if (db1_packed(num_per, dim0)) {
         if (num_per >= 64)
-            hipLaunchKernelGGL(sweep1_kernel<true>, dim3((kN / kSweep1Z) * (num_per >> 6), trials), dim3(kSweep1Z * 64), 0, s, db, qs1, acc, num_per, dim0,
+            hipLaunchKernelGGL(sweep1_kernel<0>, dim3((kN / kSweep1Z) * (num_per >> 6), trials), dim3(kSweep1Z * 64), 0, s, db, qs1, acc, num_per, dim0,
                                db_stride, acc_stride);
-        else  // one workgroup per tile of 64/num_per slots, its waves split the j range
-            hipLaunchKernelGGL(sweep1_kernel<false>, dim3(kN / (64 / num_per), trials), dim3(kSweep1Z * 64), 0, s, db, qs1, acc, num_per, dim0, db_stride,
+        else if (num_per >= 8)  // one workgroup per tile of 64/num_per <= 8 slots, its waves split the j range; records staged in LDS
+            hipLaunchKernelGGL(sweep1_kernel<2>, dim3(kN / (64 / num_per), trials), dim3(kSweep1Z * 64), 0, s, db, qs1, acc, num_per, dim0, db_stride,
+                               acc_stride);
+        else
+            hipLaunchKernelGGL(sweep1_kernel<1>, dim3(kN / (64 / num_per), trials), dim3(kSweep1Z * 64), 0, s, db, qs1, acc, num_per, dim0, db_stride,
                                acc_stride);
     } else {
         for (uint32_t t = 0; t < trials; t++)

@@ -15,6 +15,7 @@
 // which are wave-uniform (a wave works on one z) and are fetched through the scalar cache into SGPRs,
 // so the vector memory pipe carries only the database stream.  Accumulation is v_mad_u64_u32 into six
 // u64 accumulators per lane, reduced every 256 terms (256 * (2^28)^2 = 2^64, include/values.h:57).
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 
@@ -97,13 +98,18 @@ __device__ __forceinline__ void mac_packed_j(uint64_t (&a)[6], const uint4* q, c
     a[4] += (uint64_t)qc.z * b1;
     a[5] += (uint64_t)qc.w * b1;
 }
-// WIDE (nic >= 64): a wave is one slot z and 64 columns, the query records are wave-uniform (SGPR operands).
-// !WIDE (nic = W < 64): a wave is P = 64/W consecutive slots x W columns, lane = (z % P) * W + column; every lane reads the
-// records of its own z (the W lanes of a slot read the same address), the rest is the same.
-template <bool WIDE>
+// MODE 0 (nic >= 64): a wave is one slot z and 64 columns, the query records are wave-uniform (SGPR operands).
+// MODE 1, 2 (nic = W < 64): a wave is P = 64/W consecutive slots x W columns, lane = (z % P) * W + column, and every lane
+// needs the records of its own z.  MODE 1: each lane loads them through the vector pipe (the W lanes of a slot read the
+// same address).  MODE 2 (P <= 8): the wave stages the P x 8 records of a group in LDS with two coalesced loads and the
+// lanes read them from there, which takes three quarters of the requests off the vector memory pipe.
+constexpr uint32_t kQStage = 8 * 24;  // uint4 per wave: up to 8 slots x (8 j x 3)
+template <int MODE>
 __global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __restrict__ db, const uint32_t* __restrict__ qs, uint64_t* __restrict__ acc,
                                                              uint32_t nic, uint32_t dim0, uint32_t g_log) {
-    __shared__ uint64_t sh[kSweepZ * kSweepRow];
+    constexpr bool WIDE = MODE == 0;
+    constexpr uint32_t kShWords = MODE == 2 ? (kSweepZ * kQStage * 2 > kSweepZ * kSweepRow ? kSweepZ * kQStage * 2 : kSweepZ * kSweepRow) : kSweepZ * kSweepRow;
+    __shared__ __attribute__((aligned(16))) uint64_t sh[kShWords];  // results; MODE 2: first the record staging (aliased)
     const uint32_t lane = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t w = WIDE ? 64u : nic, pz = 64u / w, nblk = nic / w;  // columns and slots per tile, column blocks per slot group
     // Workgroups go to the 8 XCDs round-robin by blockIdx, and each XCD has its own L2.  The nblk workgroups that share a
@@ -138,6 +144,19 @@ __global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __r
                 d[4 * k + 3] = v.w;
             }
             const uint4* qg = q + (size_t)g * 24u;
+            if constexpr (MODE == 2) {
+                uint4* qst = reinterpret_cast<uint4*>(sh) + wv * kQStage;
+                const uint4* qsrc = reinterpret_cast<const uint4*>(qs);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();  // the previous group's reads of the staging area
+                for (uint32_t t = lane; t < pz * 24u; t += 64u) {
+                    const uint32_t zi = t / 24u, off = t - zi * 24u;
+                    qst[t] = qsrc[((size_t)(ztile * pz + zi) * dim0 + (size_t)g * 8u) * 3u + off];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                qg = qst + (lane / w) * 24u;
+            }
             mac_packed_j<0>(a, qg, d);
             mac_packed_j<1>(a, qg + 3, d);
             mac_packed_j<2>(a, qg + 6, d);
@@ -149,6 +168,7 @@ __global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __r
         }
         reduce6(a);
     }
+    if constexpr (MODE == 2) __syncthreads();  // every wave is done with its staging area before results overwrite it
 #pragma unroll
     for (uint32_t r = 0; r < 3; r++) sh[wv * kSweepRow + lane * 3u + r] = pack((uint32_t)a[r], (uint32_t)a[3 + r]);
     __syncthreads();
@@ -200,10 +220,16 @@ void launch_sweep(const uint64_t* db, const uint32_t* qs, uint64_t* acc, uint32_
     const uint32_t nic = 2 * num_per, dim0 = jm_total / 2;
     if (dim0 == 0) return;
     if (db_packed(nic, dim0)) {
+        static const bool stage = [] {
+            const char* e = getenv("SPIRAL_SWEEP_STAGE");  // tuning only: 0 = narrow geometries load their records per lane
+            return e ? atoi(e) != 0 : true;
+        }();
         if (nic >= 64)
-            hipLaunchKernelGGL(sweep_kernel<true>, dim3((kN / kSweepZ) * (nic >> 6)), dim3(kSweepZ * 64), 0, s, db, qs, acc, nic, dim0, g_log);
-        else  // one workgroup per tile of 64/nic slots, its waves split the j range
-            hipLaunchKernelGGL(sweep_kernel<false>, dim3(kN / (64 / nic)), dim3(kSweepZ * 64), 0, s, db, qs, acc, nic, dim0, g_log);
+            hipLaunchKernelGGL(sweep_kernel<0>, dim3((kN / kSweepZ) * (nic >> 6)), dim3(kSweepZ * 64), 0, s, db, qs, acc, nic, dim0, g_log);
+        else if (nic >= 8 && stage)  // one workgroup per tile of 64/nic <= 8 slots, its waves split the j range; records staged in LDS
+            hipLaunchKernelGGL(sweep_kernel<2>, dim3(kN / (64 / nic)), dim3(kSweepZ * 64), 0, s, db, qs, acc, nic, dim0, g_log);
+        else
+            hipLaunchKernelGGL(sweep_kernel<1>, dim3(kN / (64 / nic)), dim3(kSweepZ * 64), 0, s, db, qs, acc, nic, dim0, g_log);
     } else {
         const uint32_t threads = kN * nic;
         hipLaunchKernelGGL(sweep_small_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, db, qs, acc, nic, dim0, g_log);
