@@ -239,6 +239,8 @@ void launch_sweep1(const uint64_t* db, const uint32_t* qs1, uint64_t* acc, uint3
 void launch_qs1_from_cv(const uint64_t* cv, uint32_t* qs1, uint32_t dim0, uint32_t idx_factor, hipStream_t s);
 void launch_qs1_from_reoriented(const uint64_t* re, uint32_t* qs1, uint32_t dim0, hipStream_t s);
 // convertDb layout (:316-340) z*(num_per*dim0) + ii*dim0 + j -> device layout
+// foldCiphertextsDim1 product for `count` ciphertexts: out[b][2] = key[2][K] * d[b][K]   (src/testing.cpp:596-624)
+void launch_pack_fold_mac(const uint64_t* key, const uint64_t* d, uint64_t* out, uint32_t K, uint32_t count, hipStream_t s);
 void launch_db1_relayout(const uint64_t* ref, uint64_t* dev, uint32_t num_per, uint32_t dim0, hipStream_t s);
 // gsw[i][r][2j] = tmp[i*ell+j][r], gsw[i][r][2j+1] = cv[2*(i*ell+j)+1][r]   (regevToSimpleGsw, :108-139)
 void launch_pack_gsw_assemble(const uint64_t* tmp, const uint64_t* cv, uint64_t* gsw, uint32_t ell, uint32_t nu2, hipStream_t s);

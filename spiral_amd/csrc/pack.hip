@@ -281,6 +281,67 @@ void launch_pack_mac(const uint64_t* v_w, const uint64_t* ginv, const uint64_t* 
     hipLaunchKernelGGL(pack_mac_kernel, dim3(kBpp, (out_n + 1) * out_n), dim3(kTpb), 0, s, v_w, ginv, ct2, result, out_n, t_conv);
 }
 
+// ---- foldCiphertextsDim1 product (src/testing.cpp:596-624): out[b][r] = sum_m key[r][m] * d[b][m], r < 2, m < K = 4*ell.
+// Split-K over 4 k-groups + LDS like the base path's fold_mac_kernel; B ciphertexts per workgroup share the key words; the
+// digit operand is streamed once (non-temporal loads).
+struct PackAcc {
+    uint64_t lo = 0, hi = 0;
+    __device__ __forceinline__ void mac(uint64_t a, uint64_t b) {
+        lo += (uint64_t)lo32(a) * lo32(b);
+        hi += (uint64_t)hi32(a) * hi32(b);
+    }
+};
+template <uint32_t B>
+__global__ __launch_bounds__(kTpb) void pack_fold_mac_kernel(const uint64_t* __restrict__ key, const uint64_t* __restrict__ d, uint64_t* __restrict__ out,
+                                                             uint32_t K) {
+    __shared__ uint64_t sh[3][64][4 * B];
+    const uint32_t zz = threadIdx.x & 63u, kg = threadIdx.x >> 6, z = blockIdx.x * 64u + zz, b0 = blockIdx.y * B;
+    const uint64_t* dp = d + (size_t)b0 * K * kN + z;
+    const uint64_t* kp = key + z;
+    PackAcc acc[B][2];
+#pragma unroll 4
+    for (uint32_t m = kg; m < K; m += 4) {
+        const uint64_t k0 = kp[(size_t)m * kN], k1 = kp[(size_t)(K + m) * kN];
+#pragma unroll
+        for (uint32_t b = 0; b < B; b++) {
+            const uint64_t dv = __builtin_nontemporal_load(&dp[((size_t)b * K + m) * kN]);
+            acc[b][0].mac(k0, dv);
+            acc[b][1].mac(k1, dv);
+        }
+    }
+    if (kg > 0) {
+#pragma unroll
+        for (uint32_t b = 0; b < B; b++)
+#pragma unroll
+            for (uint32_t r = 0; r < 2; r++) {
+                sh[kg - 1][zz][b * 4 + r * 2] = acc[b][r].lo;
+                sh[kg - 1][zz][b * 4 + r * 2 + 1] = acc[b][r].hi;
+            }
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+        for (uint32_t b = 0; b < B; b++)
+#pragma unroll
+            for (uint32_t r = 0; r < 2; r++) {
+                uint64_t lo = acc[b][r].lo, hi = acc[b][r].hi;
+#pragma unroll
+                for (int q = 0; q < 3; q++) {  // K <= 256 terms of < 2^56 in total
+                    lo += sh[q][zz][b * 4 + r * 2];
+                    hi += sh[q][zz][b * 4 + r * 2 + 1];
+                }
+                out[((size_t)(b0 + b) * 2 + r) * kN + z] = pack(mod_p(lo), mod_b(hi));
+            }
+    }
+}
+void launch_pack_fold_mac(const uint64_t* key, const uint64_t* d, uint64_t* out, uint32_t K, uint32_t count, hipStream_t s) {
+    if (count == 0) return;
+    if (count % 4 == 0 && count >= 64)
+        hipLaunchKernelGGL(pack_fold_mac_kernel<4>, dim3(kN / 64, count / 4), dim3(kTpb), 0, s, key, d, out, K);
+    else
+        hipLaunchKernelGGL(pack_fold_mac_kernel<1>, dim3(kN / 64, count), dim3(kTpb), 0, s, key, d, out, K);
+}
+
 // arbitrary valid words (benchmarks)
 __global__ __launch_bounds__(256) void fill_db1_random_kernel(uint64_t* db, uint32_t num_per, uint32_t dim0, uint64_t seed) {
     const uint64_t nwords = (uint64_t)kN * dim0 * num_per, stride = (uint64_t)gridDim.x * 256u;

@@ -348,8 +348,7 @@ int spiral_gpu_pack_server_answer(spiral_gpu_pack_server* S, const uint64_t* que
         fp.fold_np = np;
         fp.pk_num_per = s.num_per;
         launch_ntt_forward(S->tb, fp, LD_PDIGIT, ST_PK, s.trials * 2 * np * 2 * ell, st);
-        MatmulParams mp{S->key.p + (size_t)cur * 2 * 4 * ell * kN, S->fold_d.p, S->fold_c.p, 2, 4 * ell, 1, 0, 4 * ell, 2};
-        launch_matmul(mp, s.trials * np, st);
+        launch_pack_fold_mac(S->key.p + (size_t)cur * 2 * 4 * ell * kN, S->fold_d.p, S->fold_c.p, 4 * ell, s.trials * np, st);
         InvParams ip{};
         ip.src = S->fold_c.p;
         ip.dst = S->raw.p;
