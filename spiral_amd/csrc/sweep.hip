@@ -7,13 +7,14 @@
 // (ii, c) and JM = 2*dim0 terms (j, m): 6 integer MADs per 8-byte database word, so the kernel is bound
 // by streaming the database once from HBM.  MFMA does not apply (32x32->64-bit modular integer MACs).
 //
-// Device database layout (built at load time, any re-layout is internal; common.h): tiles (z, block of 64 columns), each
-// one sequential stream; a word is stored in 7 bytes (two 28-bit residues), 8 j of a lane = 112 bytes = 7 x 16-byte loads,
-// so one wave reads 64 lanes x 16 B = 1 KiB per instruction and 7/8 of the reference's database bytes per query.
+// Device database layout (built at load time, any re-layout is internal; common.h): 64-lane tiles -- (z, block of 64
+// columns), or 64/nic slots z x nic columns when there are fewer than 64 columns -- each one sequential stream; a word is
+// stored in 7 bytes (two 28-bit residues), 8 j of a lane = 112 bytes = 7 x 16-byte loads, so one wave reads 64 lanes x
+// 16 B = 1 KiB per instruction and 7/8 of the reference's database bytes per query.
 // The query is stored as one 48-byte record per (z, j):
 //     {p-limb rows 0..2 | b-limb rows 0..2} for m = 0, then the same for m = 1      (12 u32)
-// which are wave-uniform (a wave works on one z) and are fetched through the scalar cache into SGPRs,
-// so the vector memory pipe carries only the database stream.  Accumulation is v_mad_u64_u32 into six
+// With >= 64 columns they are wave-uniform (a wave works on one z) and are fetched through the scalar cache into SGPRs,
+// so the vector memory pipe carries only the database stream; narrower geometries stage them in LDS per wave.  Accumulation is v_mad_u64_u32 into six
 // u64 accumulators per lane, reduced every 256 terms (256 * (2^28)^2 = 2^64, include/values.h:57).
 #include <cstdlib>
 #include "common.h"
@@ -55,8 +56,8 @@ __device__ __forceinline__ void store_acc(uint64_t* acc, const uint64_t (&a)[6],
     for (uint32_t r = 0; r < 3; r++) acc[((size_t)(6u * ii + 2u * r + c)) * kN + z] = pack((uint32_t)a[r], (uint32_t)a[3 + r]);
 }
 
-// ---- fast path: packed database (nic >= 64, dim0 % 8 == 0) ---------------------------------------------------------------
-// One wave per (z, block of 64 output columns).  A workgroup is kSweepZ waves on CONSECUTIVE z of the same column block: a
+// ---- fast path: packed database (dim0 % 8 == 0) ----------------------------------------------------------------------------
+// MODE 0: one wave per (z, block of 64 output columns).  A workgroup is kSweepZ waves on CONSECUTIVE z of the same column block: a
 // lane's three results belong to three different accumulator polynomials, 16 KiB apart; the waves of a workgroup trade
 // results through LDS and write full 128-byte lines instead of 1.5 M scattered 8-byte words per launch.
 // What the probes in tools/sweep_tune.hip say (config 2, one MI355X): streaming an 8-byte-per-word database alone takes
