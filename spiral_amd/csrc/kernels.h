@@ -107,6 +107,9 @@ struct FoldChainParams {
     uint32_t ell, bits, fold_np;
     uint32_t pre_reduce;  // 1: fields are lazy sums (< 2^32), reduce mod m first
     uint32_t dpb;         // digits per block, 1 .. ell
+    // SpiralPack fold (foldCiphertextsDim1): sources are [trial][2*np][2] 2 x 1 ciphertexts with a trial stride of src_stride
+    // ciphertexts, unsigned digits, operand layout as LD_PDIGIT / PM_FOLD
+    uint32_t pack, src_stride;
 };
 void launch_fold_chain(const DeviceTables& t, const FoldChainParams& p, uint32_t n_src, hipStream_t s);
 

@@ -369,9 +369,12 @@ __global__ __launch_bounds__(256) void fold_chain_kernel(Tables t, FoldChainPara
     const uint32_t cpp = (p.ell + p.dpb - 1u) / p.dpb;  // chunks per polynomial
     const uint32_t s = b / cpp, k0 = (b - s * cpp) * p.dpb, k1 = min(k0 + p.dpb, p.ell);
     uint32_t lo[8], hi[8];
+    // SpiralPack (p.pack): s = (trial t, ct i' < 2np, row) over 2 x 1 ciphertexts, trial stride p.src_stride cts in the source
+    const uint32_t per_t = 4u * p.fold_np, pt = s / per_t, prem = s - pt * per_t, pip = prem >> 1, prow = prem & 1u;
     {
         uint64_t x[8];
-        pk_load8(p.src + (size_t)s * kN, tid, x);
+        const size_t sp = p.pack ? ((size_t)pt * p.src_stride + pip) * 2u + prow : (size_t)s;
+        pk_load8(p.src + sp * kN, tid, x);
         pk_unpack8(x, lo, hi);
     }
     if (p.pre_reduce) {
@@ -388,15 +391,28 @@ __global__ __launch_bounds__(256) void fold_chain_kernel(Tables t, FoldChainPara
     // source s = (ct i', r, c) over [2*np][3][2]; operand layout D[i' % np][(i' / np)*m2 + r + 3k][c]  (as LD_SDIGIT)
     const uint32_t ct = s / 6u, rc = s - ct * 6u, row = rc >> 1, c = rc & 1u;
     const uint32_t m2 = 3u * p.ell, hi_half = ct / p.fold_np, i = ct - hi_half * p.fold_np;
+    const uint32_t phh = pip / p.fold_np, pi = pip - phh * p.fold_np;
+    const uint64_t mask = (1ull << p.bits) - 1;
     for (uint32_t k = k0; k < k1; k++) {
-        const SDigit sd = sdigit_setup(k, p.bits, p.ell);
+        if (p.pack) {  // unsigned digits (src/testing.cpp:596-624), operand layout D[t][i' % np][(i' / np)*2ell + row + 2k]
 #pragma unroll
-        for (int r = 0; r < 8; r++) sdigit_of(v[r], sd, lo[r], hi[r]);
+            for (int r = 0; r < 8; r++) {
+                const uint32_t d = (uint32_t)digit_of(v[r], k, p.bits, mask);
+                lo[r] = digit_residue(d, kP);
+                hi[r] = digit_residue(d, kB);
+            }
+        } else {
+            const SDigit sd = sdigit_setup(k, p.bits, p.ell);
+#pragma unroll
+            for (int r = 0; r < 8; r++) sdigit_of(v[r], sd, lo[r], hi[r]);
+        }
         if (k > k0) __syncthreads();  // the previous transform's last LDS reads
         ntt_forward_block(lo, hi, sh, t.fwd, tid);
+        const size_t di = p.pack ? (size_t)(((pt * p.fold_np + pi) * 2u + phh) * (2u * p.ell) + 2u * k + prow)
+                                 : (size_t)(((i * 2u + hi_half) * m2 + row + 3u * k) * 2u + c);
         uint64_t x[8];
         pk_pack8(lo, hi, x);
-        pk_store8(p.dst + (size_t)(((i * 2u + hi_half) * m2 + row + 3u * k) * 2u + c) * kN, tid, x);
+        pk_store8(p.dst + di * kN, tid, x);
     }
 }
 

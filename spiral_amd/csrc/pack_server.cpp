@@ -326,34 +326,37 @@ int spiral_gpu_pack_server_answer(spiral_gpu_pack_server* S, const uint64_t* que
     // ---- first dimension for every trial (:1049-1051), then one INTT + CRT lift (:1055-1057)
     launch_sweep1(S->db.p, (const uint32_t*)S->qs1.p, S->acc.p, s.num_per, s.dim0, s.trials, S->db_words, (size_t)s.num_per * 2 * kN, st);
     HIP_OK(hipEventRecord(S->ev[3], st));
-    {
-        InvParams ip{};
-        ip.src = S->acc.p;
-        ip.dst = S->raw.p;
-        ip.src_map = ip.dst_map = identity_map();
-        launch_ntt_inverse(S->tb, ip, IST_CRT, s.trials * s.num_per * 2, st);
-    }
-    HIP_OK(hipEventRecord(S->ev[4], st));
-    // ---- foldCiphertextsDim1 (:596-624), all trials batched
+    HIP_OK(hipEventRecord(S->ev[4], st));  // (the lift is chained into the first fold round's digit transforms)
+    // ---- foldCiphertextsDim1 (:596-624), all trials batched: each round = fold_chain_kernel (lift of the previous
+    // product or of the accumulators + unsigned digits + forward transforms) and one product; a last lift to raw
     uint32_t np = s.num_per;
+    const uint64_t* src = S->acc.p;
+    uint32_t src_stride = s.num_per;
     for (uint32_t cur = 0; cur < p.nu2; cur++) {
         np /= 2;
-        FwdParams fp{};
-        fp.src = S->raw.p;
-        fp.dst = S->fold_d.p;
-        fp.src_map = fp.dst_map = identity_map();
-        fp.n_digits = ell;
-        fp.bits = get_bits_per(ell);
-        fp.pmode = PM_FOLD;
-        fp.fold_np = np;
-        fp.pk_num_per = s.num_per;
-        launch_ntt_forward(S->tb, fp, LD_PDIGIT, ST_PK, s.trials * 2 * np * 2 * ell, st);
+        FoldChainParams cp{};
+        cp.src = src;
+        cp.dst = S->fold_d.p;
+        cp.ell = ell;
+        cp.bits = get_bits_per(ell);
+        cp.fold_np = np;
+        cp.pack = 1;
+        cp.src_stride = src_stride;
+        const uint32_t n_src = s.trials * 2 * np * 2;
+        uint32_t dpb = ell;
+        while (dpb > 1 && n_src * ((ell + dpb - 1) / dpb) < 768u) dpb = (dpb + 1) / 2;
+        cp.dpb = dpb;
+        launch_fold_chain(S->tb, cp, n_src, st);
         launch_pack_fold_mac(S->key.p + (size_t)cur * 2 * 4 * ell * kN, S->fold_d.p, S->fold_c.p, 4 * ell, s.trials * np, st);
+        src = S->fold_c.p;
+        src_stride = np;
+    }
+    {
         InvParams ip{};
-        ip.src = S->fold_c.p;
+        ip.src = src;
         ip.dst = S->raw.p;
-        ip.src_map = identity_map();
-        ip.dst_map = IndexMap{2 * np, 2 * s.num_per, 0};
+        ip.src_map = p.nu2 ? identity_map() : IndexMap{2 * s.num_per, 2 * s.num_per, 0};
+        ip.dst_map = IndexMap{2 * np, 2 * s.num_per, 0};  // the trial's surviving np cts at the head of its num_per slots
         launch_ntt_inverse(S->tb, ip, IST_CRT, s.trials * np * 2, st);
     }
     HIP_OK(hipEventRecord(S->ev[5], st));
