@@ -180,9 +180,11 @@ def main():
         torch.cuda.synchronize()
 
     with torch.cuda.stream(stream):
-        warm_ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        if not args.no_graphs:  # priming, not a step of the run: each step flavour once, so that no hipGraph is captured later
+            step([torch.cuda.Event(enable_timing=True) for _ in range(4)])
+            step(None)
         for i in range(args.warmup):
-            step(warm_ev if i == 0 else None)  # both step flavours run (and capture their graphs) before the timed region
+            step(None)
         fence()
         t0 = time.perf_counter()
         for k in range(args.steps):
