@@ -325,21 +325,18 @@ __global__ __launch_bounds__(256) void ntt_inverse_kernel(Tables t, InvParams p)
         // store the automorphed polynomial a(x^t) (scatter form of src/poly.cpp:240-261: coefficient i goes to i*t mod N,
         // negated as Q - a when i*t mod 2N >= N), so that the t_exp .. t_exp_right digit transforms that follow read it
         // in order instead of each gathering it
-        uint64_t* dst = p.dst + (size_t)b * kN;
+        // (through LDS, so that the global stores are four contiguous 16-byte pieces per thread instead of 8 scattered words)
+        __syncthreads();  // the transform's last LDS reads
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-#ifdef EXP_ABL_PLAIN_STORE
-            const uint32_t e = ix_a(tid, r);
-#else
             const uint32_t e = (ix_a(tid, r) * p.auto_t) & (2u * kN - 1u);
-#endif
-#ifdef EXP_ABL_NO_CRT
-            const uint64_t v = pack(lo[r], hi[r]);
-#else
             const uint64_t v = crt_compose(lo[r], hi[r]);
-#endif
-            dst[e & (kN - 1u)] = (e & kN) ? kQ - v : v;
+            sh[lds_ix(e & (kN - 1u))] = (e & kN) ? kQ - v : v;
         }
+        __syncthreads();
+        pk_u64x2* dst = reinterpret_cast<pk_u64x2*>(p.dst + (size_t)b * kN) + tid;
+#pragma unroll
+        for (int q = 0; q < 4; q++) dst[q * 256] = pk_u64x2{sh[lds_ix(512u * q + 2u * tid)], sh[lds_ix(512u * q + 2u * tid + 1u)]};
     } else if constexpr (STORE == IST_CRT) {
         uint64_t* dst = p.dst + (size_t)p.dst_map(b) * kN;
 #pragma unroll
