@@ -30,7 +30,7 @@ def assert_eq(got, exp, what):
         raise AssertionError(f"{what}: {len(bad)} of {got.size} words differ, first at {bad[:5].tolist()}")
 
 
-@pytest.mark.parametrize("dim0,num_per", [(4, 2), (8, 32), (64, 64), (2, 128), (16, 128), (512, 64)])  # the last three: packed layout
+@pytest.mark.parametrize("dim0,num_per", [(4, 2), (8, 32), (64, 64), (2, 128), (16, 128), (512, 64), (16, 2), (256, 8), (512, 32)])  # dim0 % 16 == 0: packed layout (wide, per-lane records, staged records)
 def test_sweep_dim1(sa, oracle, dim0, num_per):
     O = oracle
     rng = np.random.default_rng(dim0 * 1000 + num_per)

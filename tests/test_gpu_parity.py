@@ -108,7 +108,10 @@ def test_rescale(sa, oracle):
 
 
 # ---- L5 seams -------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("nu1,nu2", [(2, 1), (1, 3), (3, 5), (5, 6), (2, 7)])
+# (3,0) (4,1): fewer than 8 columns, per-lane query records; (3,2) (7,3) (9,4): 8..32 columns, records staged in LDS, the waves of
+# a workgroup split the j range ((7,3): one group of 8 j per wave, (9,4): 4 per wave); (3,5) (5,6): 64+ columns; (2,1) (1,3)
+# (2,7): dim0 < 8, plain layout
+@pytest.mark.parametrize("nu1,nu2", [(2, 1), (1, 3), (3, 5), (5, 6), (2, 7), (3, 0), (4, 1), (3, 2), (7, 3), (9, 4)])
 def test_multiply_query_by_database(sa, oracle, nu1, nu2):
     O = oracle
     dim0, num_per = 1 << nu1, 1 << nu2
