@@ -83,7 +83,10 @@ int spiral_gpu_mul_by_const(uint64_t *out, const uint64_t *single_poly, const ui
 /* automorph, invert, src/poly.cpp:240,269 (raw form; negation is Q - a) */
 int spiral_gpu_automorph(uint64_t *out, const uint64_t *in, size_t npolys, uint64_t t);
 int spiral_gpu_invert(uint64_t *out, const uint64_t *in, size_t npolys);
-/* gadget_invert, src/util.cpp:114 : raw [rdim][cols][N] -> raw [mx][cols][N] */
+/* gadget_invert, src/util.cpp:114 : raw [rdim][cols][N] -> raw [mx][cols][N].  A digit whose shift count k*bits is >= 64
+ * is defined as 0 here (and in every fused digit loader); the reference shifts a uint64_t by that count (src/util.cpp:136),
+ * which is undefined behaviour -- x86 would yield the low digit again.  Unreachable for every published parameter set
+ * (k*bits < 64 for all t in all_parameter_choices.txt). */
 int spiral_gpu_gadget_invert(uint64_t *out, const uint64_t *in, size_t mx, size_t rdim, size_t cols);
 /* getRescaled, src/poly.cpp:593 : element-wise rescale(a % Q, inp_mod, out_mod) */
 int spiral_gpu_get_rescaled(uint64_t *out, const uint64_t *in, size_t n, uint64_t inp_mod, uint64_t out_mod);
@@ -132,6 +135,22 @@ int spiral_gpu_server_load_db(spiral_gpu_server *s, const uint64_t *database /* 
 /* explicit DB generated on the device: plaintext coefficient k of item i is
  * splitmix64(seed ^ (i*4N + k)) % p_db (the rand() % p_db of :25-29 with a counter-based generator) */
 int spiral_gpu_server_gen_db(spiral_gpu_server *s, uint64_t seed);
+/* Raw ingest: the whole of load_db on the device -- plaintext coefficients in, device database out
+ * (centred lift :1116-1127, to_ntt, layout :1139-1153), so the host ships log2(p_db) bits per coefficient instead of
+ * the 8x larger NTT form.  `items` holds n_items consecutive plaintexts starting at item first_item (item i = database
+ * entry (ii = i % num_per, j = i / num_per); a sharded server keeps the items of its own j-range and skips the rest);
+ * one plaintext = n0*n2*2048 coefficients in [0, p_db), polynomial (m, c) at (m*n2 + c)*2048, each coeff_bits wide and
+ * bit-packed little-endian like read_arbitrary_bits (src/core.cpp:20-30) -- coeff_bits = log2(p_db) is the item size
+ * of select_params.py:297 (8192 B at p = 256, 15360 B at p = 2^15) -- or coeff_bits = 64: the reference's raw MatPoly
+ * words.  Fails if a coefficient is >= p_db (the reference asserts).  May be called several times (streaming a database
+ * larger than host memory). */
+int spiral_gpu_server_load_db_items(spiral_gpu_server *s, const void *items, uint32_t coeff_bits, uint64_t first_item,
+                                    uint64_t n_items);
+/* read the device database back in reference layouts (tests): plaintext `item` as its n0 x n2 NTT-form MatPoly
+ * (pts_encd, :1128), or slabs z_begin .. z_begin+nz-1 of load_db's layout restricted to this server's j-range:
+ * word (z, ii, c, j, m) at ((((z - z_begin)*num_per + ii)*n2 + c)*(j_end - j_begin) + (j - j_begin))*n0 + m */
+int spiral_gpu_server_read_db_item(spiral_gpu_server *s, uint64_t item, uint64_t *out);
+int spiral_gpu_server_read_db_slots(spiral_gpu_server *s, uint32_t z_begin, uint32_t nz, uint64_t *out);
 /* --random-data analogue: arbitrary valid NTT-form words, timing only */
 int spiral_gpu_server_fill_db_random(spiral_gpu_server *s, uint64_t seed);
 
@@ -246,6 +265,10 @@ void spiral_gpu_pack_server_destroy(spiral_gpu_pack_server *s);
 int spiral_gpu_pack_server_gen_db(spiral_gpu_pack_server *s, uint64_t seed);
 int spiral_gpu_pack_server_load_db(spiral_gpu_pack_server *s, uint32_t trial, const uint64_t *db);
 int spiral_gpu_pack_server_fill_db_random(spiral_gpu_pack_server *s, uint64_t seed);
+/* raw ingest of one trial (src/testing.cpp:845-869 + convertDb :316-340 on the device): 1 x 1 plaintexts of 2048
+ * coefficients, bit-packed as for spiral_gpu_server_load_db_items */
+int spiral_gpu_pack_server_load_db_items(spiral_gpu_pack_server *s, uint32_t trial, const void *items, uint32_t coeff_bits,
+                                         uint64_t first_item, uint64_t n_items);
 /* W_exp_left / W_exp_right (expansion only), V base_dim x base_dim*t_conv (expansion only), v_W out_n x ((out_n+1) x t_conv) */
 int spiral_gpu_pack_server_set_pub_params(spiral_gpu_pack_server *s, const uint64_t *w_left, const uint64_t *w_right,
                                           const uint64_t *v, const uint64_t *v_w);

@@ -229,6 +229,15 @@ def multiply_query_by_database(reoriented, db, dim0, num_per):
     return out
 
 
+def multiply_query_by_database_slots(reoriented_slabs, db_slabs, dim0, num_per):
+    """the sweep on a subset of NTT slots: reoriented_slabs [nz][dim0][2][4], db_slabs [nz][num_per*2*dim0*2] -> [num_per][3][2][2][nz]"""
+    nz = reoriented_slabs.shape[0]
+    out = u64(num_per, 3, 2, 2, nz)
+    lib().orc_multiply_query_by_database_slots(_p(out), _p(np.ascontiguousarray(reoriented_slabs)), _p(np.ascontiguousarray(db_slabs)), C.c_size_t(dim0),
+                                               C.c_size_t(num_per), C.c_uint32(nz))
+    return out
+
+
 def expand_improved(cv, g, t_exp, w_left, t_exp_right, w_right, n_right, max_bits_right, stopround):
     cv = np.ascontiguousarray(cv, dtype=np.uint64).copy()
     lib().orc_expand_improved(_p(cv), C.c_uint32(g), C.c_uint32(t_exp), _p(w_left), C.c_uint32(t_exp_right), _p(w_right),
@@ -314,6 +323,27 @@ def db_item(p, seed, item):
     out = u64(2, 2, N)
     lib().orc_db_item(C.byref(p), C.c_uint64(seed), C.c_uint64(item), _p(out))
     return out
+
+
+def encode_item(p, pt):
+    """plaintext (n0 x n2 raw coefficients in [0, p_db)) -> its NTT-form encoding: centred lift + to_ntt (src/spiral.cpp:1116-1128)"""
+    out = u64(2, 2, 2, N)
+    lib().orc_encode_item(C.byref(p), _p(np.ascontiguousarray(pt, dtype=np.uint64)), _p(out))
+    return out
+
+
+def pack_items(pts, coeff_bits):
+    """plaintext coefficients (any shape, values < 2^coeff_bits) -> the bit-packed item stream of spiral_gpu_server_load_db_items:
+    little-endian bit order, coefficient k at bits [k*coeff_bits, (k+1)*coeff_bits) (read_arbitrary_bits, src/core.cpp:20-30)"""
+    v = np.ascontiguousarray(pts, dtype=np.uint64).reshape(-1)
+    bits = ((v[:, None] >> np.arange(coeff_bits, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(np.uint8).reshape(-1)
+    return np.packbits(bits, bitorder="little")
+
+
+def set_threads(n):
+    """threads of the OpenMP (`make native`) build; the default build ignores it and returns 1"""
+    lib().orc_set_threads.restype = C.c_int
+    return lib().orc_set_threads(C.c_int(n))
 
 
 def fill_db_random(seed, nwords):

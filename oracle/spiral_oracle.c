@@ -21,6 +21,27 @@
 
 typedef unsigned __int128 u128;
 
+/* Threading (bench.py's all-cores CPU baseline only): the loops below over independent polynomials / NTT slots / ciphertexts
+ * carry `#pragma omp parallel for if (g_threads > 1)`.  The default build (Makefile target liboracle.so, what the parity tests
+ * load) has no -fopenmp, so the pragmas are ignored there; the `native` target adds -fopenmp -march=native and
+ * orc_set_threads(n) turns them on.  The reference itself is single-threaded (src/spiral.cpp:1231). */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+static int g_threads = 1;
+static void build_tables(void);
+int orc_set_threads(int n) {
+    build_tables(); /* lazily built otherwise: not from inside a parallel region */
+#ifdef _OPENMP
+    g_threads = n < 1 ? 1 : n;
+    omp_set_num_threads(g_threads);
+    return g_threads;
+#else
+    (void)n;
+    return 1;
+#endif
+}
+
 static const uint64_t MODS[2] = {ORC_P, ORC_B};
 /* minimal primitive 4096-th roots of unity mod p, b; checked against src/constants.cpp by
  * tests/test_oracle_tables.py (tests/golden/ntt_tables.json) */
@@ -155,6 +176,7 @@ void orc_ntt_inverse(uint64_t *op) {
 static inline uint64_t red(uint64_t x, int n) { return x % MODS[n]; }
 
 void orc_to_ntt(uint64_t *out, const uint64_t *in, size_t npolys) {
+#pragma omp parallel for if (g_threads > 1 && npolys > 1)
     for (size_t k = 0; k < npolys; k++) {
         uint64_t *o = out + k * NTTP;
         const uint64_t *a = in + k * N;
@@ -167,6 +189,7 @@ void orc_to_ntt(uint64_t *out, const uint64_t *in, size_t npolys) {
 }
 
 void orc_to_ntt_no_reduce(uint64_t *out, const uint64_t *in, size_t npolys) {
+#pragma omp parallel for if (g_threads > 1 && npolys > 1)
     for (size_t k = 0; k < npolys; k++) {
         uint64_t *o = out + k * NTTP;
         const uint64_t *a = in + k * N;
@@ -184,8 +207,9 @@ uint64_t orc_crt_compose(uint64_t x, uint64_t y) {
 }
 
 void orc_from_ntt(uint64_t *out, const uint64_t *in, size_t npolys) {
-    uint64_t tmp[NTTP];
+#pragma omp parallel for if (g_threads > 1 && npolys > 1)
     for (size_t k = 0; k < npolys; k++) {
+        uint64_t tmp[NTTP];
         memcpy(tmp, in + k * NTTP, sizeof(tmp));
         orc_ntt_inverse(tmp);
         for (uint32_t z = 0; z < N; z++) out[k * N + z] = orc_crt_compose(tmp[z], tmp[N + z]);
@@ -210,6 +234,7 @@ void orc_multiply(uint64_t *out, const uint64_t *a, const uint64_t *b, size_t rs
 }
 
 void orc_add(uint64_t *out, const uint64_t *a, const uint64_t *b, size_t npolys) {
+#pragma omp parallel for if (g_threads > 1 && npolys > 8)
     for (size_t k = 0; k < npolys; k++)
         for (int n = 0; n < 2; n++)
             for (uint32_t z = 0; z < N; z++) {
@@ -299,6 +324,7 @@ void orc_split_and_crt(uint64_t *out, const uint64_t *in, size_t num_per, uint32
     uint32_t ell = t_gsw, m2 = t_gsw * N1, half = ell / 2;
     uint32_t bits = orc_get_bits_per(ell);
     uint64_t mask = (1ull << bits) - 1, base = 1ull << bits, thresh = base / 2;
+#pragma omp parallel for collapse(3) if (g_threads > 1)
     for (size_t i = 0; i < num_per; i++)
         for (uint32_t r = 0; r < N1; r++)
             for (uint32_t c = 0; c < N2; c++) {
@@ -327,6 +353,7 @@ void orc_split_and_crt(uint64_t *out, const uint64_t *in, size_t num_per, uint32
 
 /* src/spiral.cpp:345-384: (i, m, c, n, z) -> packed (z, i, c, m) */
 void orc_reorient_C(uint64_t *out, const uint64_t *in, size_t num_per, uint32_t m2) {
+#pragma omp parallel for if (g_threads > 1)
     for (size_t i = 0; i < num_per; i++)
         for (uint32_t m = 0; m < m2; m++)
             for (uint32_t c = 0; c < N2; c++) {
@@ -348,6 +375,7 @@ void orc_reorient_Q(uint64_t *out, const uint64_t *in, uint32_t m2) {
 /* src/spiral.cpp:410-433: (j, r, m, n, z) -> packed (z, j, m, r padded to 4) */
 void orc_reorient_ciphertexts(uint64_t *out, const uint64_t *in, size_t dim0) {
     memset(out, 0, dim0 * 2 * 4 * N * sizeof(uint64_t));
+#pragma omp parallel for if (g_threads > 1)
     for (size_t j = 0; j < dim0; j++)
         for (uint32_t r = 0; r < N1; r++)
             for (uint32_t m = 0; m < 2; m++) {
@@ -359,9 +387,22 @@ void orc_reorient_ciphertexts(uint64_t *out, const uint64_t *in, size_t dim0) {
 
 /* src/spiral.cpp:628-999, scalar semantics (:932-998): out[i][r][c][n][z] =
  * (sum_{j,m} ct[z][j][m][r].n * db[z][i][c][j][m].n) mod m_n */
+static void sweep_slabs(uint64_t *out, const uint64_t *cts, const uint64_t *db, size_t dim0, size_t num_per, uint32_t nz, size_t N_out);
 void orc_multiply_query_by_database(uint64_t *out, const uint64_t *cts, const uint64_t *db, size_t dim0,
                                     size_t num_per) {
-    for (uint32_t z = 0; z < N; z++) {
+    sweep_slabs(out, cts, db, dim0, num_per, N, N);
+}
+/* the same for nz slabs only (the sweep is independent per NTT slot z): cts and db hold the nz slabs of the chosen slots in
+ * the reference's z-major layouts, out is [num_per][n1][n2][2][nz].  Lets a test check a 32 or 64 GiB database on a sample
+ * of slots. */
+void orc_multiply_query_by_database_slots(uint64_t *out, const uint64_t *cts, const uint64_t *db, size_t dim0, size_t num_per,
+                                          uint32_t nz) {
+    sweep_slabs(out, cts, db, dim0, num_per, nz, nz);
+}
+static void sweep_slabs(uint64_t *out, const uint64_t *cts, const uint64_t *db, size_t dim0, size_t num_per, uint32_t nz, size_t N_out) {
+    const size_t NTTP_out = 2 * N_out;
+#pragma omp parallel for if (g_threads > 1)
+    for (uint32_t z = 0; z < nz; z++) {
         const uint64_t *a = cts + (size_t)z * (dim0 * 2 * 4);
         const uint64_t *bz = db + (size_t)z * (num_per * N2 * dim0 * N0);
         for (size_t i = 0; i < num_per; i++)
@@ -377,9 +418,9 @@ void orc_multiply_query_by_database(uint64_t *out, const uint64_t *cts, const ui
                     }
                 }
                 for (uint32_t r = 0; r < 3; r++) {
-                    uint64_t *o = out + ((i * N1 + r) * N2 + c) * NTTP;
+                    uint64_t *o = out + ((i * N1 + r) * N2 + c) * NTTP_out;
                     o[z] = (uint64_t)(s0[r] % ORC_P);
-                    o[N + z] = (uint64_t)(s1[r] % ORC_B);
+                    o[N_out + z] = (uint64_t)(s1[r] % ORC_B);
                 }
             }
     }
@@ -388,6 +429,7 @@ void orc_multiply_query_by_database(uint64_t *out, const uint64_t *cts, const ui
 /* src/spiral.cpp:464-582: Cn[i][r][c][n][z] = (sum_m Q[z][r][m].n * C[z][i][c][m].n) mod m_n, u64 sums */
 void orc_cpu_mul_query_by_ct(uint64_t *c_next, const uint64_t *q, const uint64_t *cm, size_t num_per,
                              uint32_t m2) {
+#pragma omp parallel for if (g_threads > 1)
     for (uint32_t z = 0; z < N; z++)
         for (size_t i = 0; i < num_per; i++)
             for (uint32_t r = 0; r < N1; r++)
@@ -444,15 +486,18 @@ void orc_expand_improved(uint64_t *cv, uint32_t g, uint32_t t_exp, const uint64_
     uint32_t tmax = t_exp > t_exp_right ? t_exp : t_exp_right;
     const size_t CT = (size_t)N0 * NTTP; /* one n0 x 1 NTT ciphertext */
     uint64_t *neg1 = malloc(NTTP * sizeof(uint64_t));
-    uint64_t *c = malloc(N0 * N * sizeof(uint64_t)), *ca = malloc(N0 * N * sizeof(uint64_t));
-    uint64_t *ca1_ntt = malloc(NTTP * sizeof(uint64_t));
-    uint64_t *gi = malloc((size_t)tmax * N * sizeof(uint64_t));
-    uint64_t *gi_ntt = malloc((size_t)tmax * NTTP * sizeof(uint64_t));
-    uint64_t *wg = malloc(CT * sizeof(uint64_t));
+    /* scratch of one iteration: c, ca (N0*N each), ca1_ntt (NTTP), gi (tmax*N), gi_ntt (tmax*NTTP), wg (CT); one set per thread */
+    const size_t per = (size_t)2 * N0 * N + NTTP + (size_t)tmax * N + (size_t)tmax * NTTP + CT;
+    uint64_t *scratch = malloc(per * (size_t)g_threads * sizeof(uint64_t));
     for (uint32_t r = 0; r < g; r++) {
         uint32_t num_in = 1u << r, num_out = 2 * num_in;
         uint64_t t = (N >> r) + 1;
         make_neg1(neg1, r);
+        /* the reference creates cv[num_in + i] = neg1 * cv[i] at the top of iteration i < num_in (:1709), before that
+         * iteration updates cv[i] and before iteration num_in + i reads it; done up front here so that the iterations of a
+         * round are independent (same values) */
+        for (uint32_t i = 0; i < num_in; i++) orc_mul_by_const(cv + (size_t)(num_in + i) * CT, neg1, cv + (size_t)i * CT, N0);
+#pragma omp parallel for schedule(dynamic, 1) if (g_threads > 1)
         for (uint32_t i = 0; i < num_out; i++) {
             int odd = i & 1;
             if (stopround > 0 && r > stopround && odd) continue;
@@ -465,8 +510,13 @@ void orc_expand_improved(uint64_t *cv, uint32_t g, uint32_t t_exp, const uint64_
             } else {
                 W = w_left + (size_t)r * N0 * t_exp * NTTP;
             }
+            int tid = 0;
+#ifdef _OPENMP
+            tid = omp_get_thread_num();
+#endif
+            uint64_t *c = scratch + per * (size_t)tid, *ca = c + N0 * N, *ca1_ntt = ca + N0 * N, *gi = ca1_ntt + NTTP;
+            uint64_t *gi_ntt = gi + (size_t)tmax * N, *wg = gi_ntt + (size_t)tmax * NTTP;
             uint64_t *cvi = cv + (size_t)i * CT;
-            if (i < num_in) orc_mul_by_const(cv + (size_t)(num_in + i) * CT, neg1, cvi, N0);
             orc_from_ntt(c, cvi, N0);
             orc_automorph(ca, c, N0, t);
             orc_to_ntt(ca1_ntt, ca + N, 1);
@@ -481,7 +531,7 @@ void orc_expand_improved(uint64_t *cv, uint32_t g, uint32_t t_exp, const uint64_
                     }
         }
     }
-    free(neg1); free(c); free(ca); free(ca1_ntt); free(gi); free(gi_ntt); free(wg);
+    free(neg1); free(scratch);
 }
 
 /* prod(n1 x n0) = W (n1 x 2*t_conv) * special_distribute(g) (src/spiral.cpp:1834-1848):
@@ -630,8 +680,10 @@ int orc_stage_convert(const orc_params *p, const uint64_t *cv, const uint64_t *w
     orc_shape s;
     if (orc_get_shape(p, &s)) return -1;
     const size_t CT = (size_t)N0 * NTTP;
+#pragma omp parallel for if (g_threads > 1)
     for (uint32_t i = 0; i < s.dim0; i++) /* :2230-2253 */
         orc_scal_to_mat(cts_out + (size_t)i * N1 * N0 * NTTP, cv + (size_t)i * CT, w, p->t_conv);
+#pragma omp parallel for if (g_threads > 1)
     for (uint32_t i = 0; i < p->nu2; i++) /* :2315-2331, stored reversed */
         orc_regev_to_gsw(gsw_out + (size_t)(p->nu2 - 1 - i) * N1 * s.m2 * NTTP, cv + (size_t)(s.dim0 + i * s.ell) * CT,
                          w, v, p->t_conv, s.ell);
@@ -735,14 +787,27 @@ void orc_db_item(const orc_params *p, uint64_t seed, uint64_t item, uint64_t *pt
     for (uint64_t k = 0; k < 4ull * N; k++) pt[k] = orc_db_coeff(seed, item, k, p->p_db);
 }
 
+/* one plaintext (n0 x n2 raw, coefficients in [0, p_db)) -> pts_encd: centred lift (:1116-1127) + to_ntt (:1128) */
+void orc_encode_item(const orc_params *p, const uint64_t *pt, uint64_t *enc) {
+    uint64_t lifted[4 * N];
+    for (uint32_t k = 0; k < 4 * N; k++) {
+        int64_t v = (int64_t)pt[k];
+        if (v >= (int64_t)(p->p_db / 2)) v -= (int64_t)p->p_db;
+        if (v < 0) v += (int64_t)Q;
+        lifted[k] = (uint64_t)v;
+    }
+    orc_to_ntt(enc, lifted, 4);
+}
+
 /* src/spiral.cpp:1083-1171: centred lift (:1116-1127), to_ntt, packed word at
  * z*(num_per*n2*dim0*n0) + ii*(n2*dim0*n0) + c*(dim0*n0) + j*n0 + m, item i -> (ii = i % num_per, j = i / num_per) */
 void orc_gen_db(const orc_params *p, uint64_t seed, uint64_t *db) {
     orc_shape s;
     if (orc_get_shape(p, &s)) return;
     uint64_t total = (uint64_t)s.dim0 * s.num_per;
-    uint64_t pt[4 * N], enc[4 * NTTP];
+#pragma omp parallel for if (g_threads > 1)
     for (uint64_t i = 0; i < total; i++) {
+        uint64_t pt[4 * N], enc[4 * NTTP];
         orc_db_item(p, seed, i, pt);
         for (uint32_t k = 0; k < 4 * N; k++) {
             int64_t v = (int64_t)pt[k];

@@ -129,6 +129,13 @@ int orc_answer(const orc_params *p, const uint64_t *query, const uint64_t *w_lef
 /* coefficient of plaintext `item`, position k in [0, 4*N): splitmix64(seed ^ (item*4N + k)) % p_db */
 uint64_t orc_db_coeff(uint64_t seed, uint64_t item, uint64_t k, uint64_t p_db);
 void orc_gen_db(const orc_params *p, uint64_t seed, uint64_t *db /* dim0*num_per*4*N u64 */);
+/* one plaintext (raw n0 x n2, coefficients in [0, p_db)) -> its NTT-form encoding pts_encd (:1116-1128) */
+void orc_encode_item(const orc_params *p, const uint64_t *pt, uint64_t *enc /* [2][2][2][N] */);
+/* the sweep on nz chosen NTT slots only: cts / db hold those slots' slabs, out is [num_per][n1][n2][2][nz] */
+void orc_multiply_query_by_database_slots(uint64_t *out, const uint64_t *reoriented_cts, const uint64_t *db, size_t dim0,
+                                          size_t num_per, uint32_t nz);
+/* threads for the `native` (-fopenmp) build used by bench.py's all-cores CPU baseline; a no-op returning 1 otherwise */
+int orc_set_threads(int n);
 void orc_db_item(const orc_params *p, uint64_t seed, uint64_t item, uint64_t *pt /* raw [2][2][N] */);
 /* timing-only DB: pseudo-random residues directly in NTT form (valid input, no meaning) */
 void orc_fill_db_random(uint64_t seed, uint64_t *db, size_t nwords);

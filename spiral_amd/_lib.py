@@ -84,6 +84,9 @@ PROTOTYPES = {
     "spiral_gpu_server_load_db": (C.c_int, [C.c_void_p, U64P]),
     "spiral_gpu_server_gen_db": (C.c_int, [C.c_void_p, C.c_uint64]),
     "spiral_gpu_server_fill_db_random": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "spiral_gpu_server_load_db_items": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]),
+    "spiral_gpu_server_read_db_item": (C.c_int, [C.c_void_p, C.c_uint64, U64P]),
+    "spiral_gpu_server_read_db_slots": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, U64P]),
     "spiral_gpu_server_set_pub_params": (C.c_int, [C.c_void_p, U64P, U64P, U64P, U64P]),
     "spiral_gpu_server_set_query": (C.c_int, [C.c_void_p, U64P]),
     "spiral_gpu_server_expand": (C.c_int, [C.c_void_p]),
@@ -121,6 +124,7 @@ PROTOTYPES = {
     "spiral_gpu_pack_server_gen_db": (C.c_int, [C.c_void_p, C.c_uint64]),
     "spiral_gpu_pack_server_load_db": (C.c_int, [C.c_void_p, C.c_uint32, U64P]),
     "spiral_gpu_pack_server_fill_db_random": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "spiral_gpu_pack_server_load_db_items": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]),
     "spiral_gpu_pack_server_set_pub_params": (C.c_int, [C.c_void_p, U64P, U64P, U64P, U64P]),
     "spiral_gpu_pack_server_answer": (C.c_int, [C.c_void_p, U64P, U64P, U64P, C.POINTER(C.c_double)]),
     "spiral_gpu_pack_server_sweep_bytes": (C.c_uint64, [C.c_void_p]),

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <iomanip>
 #include <iostream>
+#include <random>
 #include <string>
 
 #include "client.hpp"
@@ -138,7 +139,10 @@ int main(int argc, char** argv) {
     const uint64_t total_n = (1ull << nu1) * (1ull << nu2);
     const uint64_t idx_target = strtoull(argv[3], nullptr, 10);
     bool nonoise = false, random_data = false, show_diff = false, direct_flag = false, high_rate = false;
-    uint64_t seed = std::chrono::steady_clock::now().time_since_epoch().count();  // reference: random_device (src/core.cpp:202)
+    // as the reference (random_device, src/core.cpp:202; it labels its own generator NOT SECURE): two words of it.
+    // This client is a test harness for the server path, not a hardened client.
+    std::random_device rd;
+    uint64_t seed = ((uint64_t)rd() << 32) ^ (uint64_t)rd();
     for (int i = 5; i < argc; i++) {  // flags are only parsed after the db filename (src/spiral.cpp:1250-1303)
         if (!strcmp(argv[i], "--nonoise")) { cout << "Using no noise" << endl; nonoise = true; }
         if (!strcmp(argv[i], "--high-rate")) { cout << "Using high rate variant..." << endl; high_rate = true; }

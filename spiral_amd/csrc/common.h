@@ -98,6 +98,32 @@ __device__ __forceinline__ void db_put_word(uint64_t* db, uint32_t z, uint32_t j
     }
 }
 
+// read one database word back (the inverse of db_put_word): tests and the read_db_* entry points
+__device__ __forceinline__ uint64_t db_get_word(const uint64_t* db, uint32_t z, uint32_t j, uint32_t ic, uint32_t m, uint32_t nic, uint32_t dim0) {
+    if (db_packed(nic, dim0)) {
+        const uint8_t* bytes = reinterpret_cast<const uint8_t*>(db);
+        uint64_t f = 0;
+#pragma unroll
+        for (uint32_t by = 0; by < 7; by++) f |= (uint64_t)bytes[db_packed_byte(z, j, ic, m, by, nic, dim0)] << (8u * by);
+        return (f & 0xFFFFFFFull) | ((f >> 28) << 32);
+    }
+    return db[db_word_index(z, j, ic, m, nic, dim0)];
+}
+
+// Plaintext coefficient number ci of a bit-packed item stream (raw database ingest): coefficients are coeff_bits wide,
+// little-endian bit order as the reference's read_arbitrary_bits (src/core.cpp:20-30); coeff_bits == 64: plain u64 words
+// (the reference's raw MatPoly).  The staging buffer carries 16 bytes of padding, so the 12-byte window may over-read.
+__device__ __forceinline__ uint64_t packed_coeff(const uint8_t* items, uint64_t ci, uint32_t coeff_bits) {
+    if (coeff_bits == 64) return reinterpret_cast<const uint64_t*>(items)[ci];
+    const uint64_t bit = ci * coeff_bits;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(items) + (bit >> 5);
+    const uint32_t sh = (uint32_t)(bit & 31u);
+    const uint64_t lo = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+    uint64_t v = lo >> sh;
+    if (sh + coeff_bits > 64u) v |= (uint64_t)w[2] << (64u - sh);
+    return v & ((1ull << coeff_bits) - 1ull);
+}
+
 // response modulus switch of one coefficient (src/poly.cpp:578-601):
 // round(centre(a) * out_mod / inp_mod) mod out_mod with the reference's round-half-away-from-zero and
 // truncating division; the 128-bit quotient is a double estimate corrected exactly.

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -195,6 +196,45 @@ inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_
     }
 }
 
+
+// Raw database ingest shared by the two servers (the first half of load_db, src/spiral.cpp:1083-1171, on the
+// device): items [lo, hi) of a host stream whose first item is `first` are staged a chunk at a time and handed to `launch`
+// (items_dev, first_item_of_chunk, n_items_of_chunk), which runs the centred lift + batched transform + layout scatter.
+// polys_per_item: n0*n2 = 4 (base) or 1 (SpiralPack).  The error word is set by the kernels when a coefficient is >= p_db.
+template <class Launch>
+inline int ingest_items(const void* items, uint32_t coeff_bits, uint64_t first, uint64_t lo, uint64_t hi, uint32_t polys_per_item, uint64_t p_db,
+                        hipStream_t st, Launch launch) {
+    if (!items) return fail("null item stream");
+    if (coeff_bits != 64 && (coeff_bits < 1 || coeff_bits > 40)) return fail("coefficient width %u not in 1..40 or 64", coeff_bits);
+    if (coeff_bits < 64 && (1ull << coeff_bits) < p_db) return fail("%u-bit coefficients cannot hold values below p_db", coeff_bits);
+    if (lo >= hi) return 0;
+    const size_t item_bytes = (size_t)polys_per_item * kN * coeff_bits / 8;
+    size_t stage_bytes = (size_t)64 << 20;
+    if (const char* e = getenv("SPIRAL_DB_STAGE_BYTES")) stage_bytes = strtoull(e, nullptr, 10);  // tests: force several passes
+    const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>({stage_bytes / item_bytes, (uint64_t)(1u << 16), hi - lo}));
+    uint8_t* d_items = nullptr;
+    uint32_t* d_err = nullptr;
+    HIP_OK(hipMalloc(&d_items, chunk * item_bytes + 16));
+    if (hipMalloc(&d_err, sizeof(uint32_t)) != hipSuccess || hipMemsetAsync(d_err, 0, sizeof(uint32_t), st) != hipSuccess) {
+        (void)hipFree(d_items);
+        return fail("device allocation failed");
+    }
+    hipError_t e = hipMemsetAsync(d_items + chunk * item_bytes, 0, 16, st);
+    for (uint64_t done = lo; done < hi && e == hipSuccess; done += chunk) {
+        const uint64_t n = std::min(chunk, hi - done);
+        e = hipMemcpyAsync(d_items, (const uint8_t*)items + (size_t)(done - first) * item_bytes, (size_t)n * item_bytes, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) break;
+        launch(d_items, d_err, done, n);
+        e = hipStreamSynchronize(st);  // the staging buffer is reused by the next pass
+    }
+    uint32_t err = 0;
+    if (e == hipSuccess) e = hipMemcpy(&err, d_err, sizeof(err), hipMemcpyDeviceToHost);
+    (void)hipFree(d_items);
+    (void)hipFree(d_err);
+    if (e != hipSuccess) return fail("database ingest failed: %s", hipGetErrorString(e));
+    if (err) return fail("a plaintext coefficient is not below p_db (the reference asserts, src/spiral.cpp:1117)");
+    return 0;
+}
 
 // upload reference NTT-form polynomials and convert to PK / the converse
 inline uint64_t* upload_pk(Scratch& sc, const uint64_t* host_ref, size_t npolys) {

@@ -65,6 +65,13 @@ struct FwdParams {
     uint64_t total_n;
     // LD_EXPAND: active ct a < cnt_e is even (t_e digits), the rest odd (t_o digits); jobs per ct = t
     uint32_t cnt_e, t_e, t_o;
+    // LD_DBGEN / LD_DBGEN1: plaintext coefficients come from the seeded generator, or (items != null) from a staged
+    // stream of bit-packed items whose first item is items_first (common.h packed_coeff); err: set to 1 when a
+    // coefficient is not below p_db (the reference asserts, src/spiral.cpp:1117)
+    const uint8_t* items;
+    uint32_t coeff_bits;
+    uint64_t items_first;
+    uint32_t* err;
     // LD_DBGEN / ST_DB
     uint64_t seed, p_db;
     uint64_t item_base;                 // first item handled by this launch
@@ -200,6 +207,11 @@ void launch_db_relayout(const uint64_t* db_ref, uint64_t* db_dev, uint32_t num_p
 // reference reorientCiphertexts layout (z, j, m, r_pad4) u64 -> sweep query records
 void launch_qs_from_reoriented(const uint64_t* reoriented, uint32_t* qs, uint32_t jm_total, hipStream_t s);
 void launch_fill_db_random(uint64_t* db_dev, uint32_t num_per, uint32_t dim0_shard, uint64_t seed, hipStream_t s);
+// read the device database back in the reference's layouts (tests, spiral_gpu_server_read_db_*): one plaintext item
+// (j local to the shard) as n0 x n2 reference NTT-form polynomials, or nz slabs z0.. of load_db's layout restricted to
+// the shard's j-range (z in the reference's slot order)
+void launch_db_read_item(const uint64_t* db_dev, uint64_t* out_ref, uint32_t num_per, uint32_t dim0_shard, uint32_t j_local, uint32_t ii, hipStream_t s);
+void launch_db_read_slots(const uint64_t* db_dev, uint64_t* out, uint32_t num_per, uint32_t dim0_shard, uint32_t z0, uint32_t nz, hipStream_t s);
 void launch_fill_db1_random(uint64_t* db_dev, uint32_t num_per, uint32_t dim0, uint64_t seed, hipStream_t s);
 
 // ---- SpiralPack (pack.hip; reference src/testing.cpp) -----------------------------------------------------------

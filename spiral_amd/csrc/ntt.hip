@@ -1,7 +1,7 @@
 // Batched NTT / INTT kernels with fused pre- and post-operations, gfx950.
-// One 256-thread workgroup per output polynomial.  See ntt.cuh for the transform itself.
+// One 256-thread workgroup per output polynomial.  See ntt_device.h for the transform itself.
 #include "kernels.h"
-#include "ntt.cuh"
+#include "ntt_device.h"
 
 namespace spiral {
 
@@ -87,7 +87,12 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             uint32_t idx = ix_a(tid, r);
-            uint64_t v = splitmix64(p.seed ^ (item * (4ull * kN) + (uint64_t)mc * kN + idx)) % p.p_db;
+            uint64_t v = p.items ? packed_coeff(p.items, (item - p.items_first) * (4ull * kN) + (uint64_t)mc * kN + idx, p.coeff_bits)
+                                 : splitmix64(p.seed ^ (item * (4ull * kN) + (uint64_t)mc * kN + idx)) % p.p_db;
+            if (v >= p.p_db) {  // only an ingested coefficient can be
+                *p.err = 1u;
+                v %= p.p_db;
+            }
             if (v >= half_p) {  // v - p_db + Q  ==  -(p_db - v) mod m
                 uint64_t d = p.p_db - v;
                 lo[r] = kP - mod_p(d);
@@ -103,7 +108,12 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             uint32_t idx = ix_a(tid, r);
-            uint64_t v = splitmix64(p.seed ^ (((uint64_t)p.trial * p.total_n + item) * kN + idx)) % p.p_db;
+            uint64_t v = p.items ? packed_coeff(p.items, (item - p.items_first) * (uint64_t)kN + idx, p.coeff_bits)
+                                 : splitmix64(p.seed ^ (((uint64_t)p.trial * p.total_n + item) * kN + idx)) % p.p_db;
+            if (v >= p.p_db) {
+                *p.err = 1u;
+                v %= p.p_db;
+            }
             if (v >= half_p) {
                 uint64_t d = p.p_db - v;
                 lo[r] = kP - mod_p(d);

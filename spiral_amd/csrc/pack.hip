@@ -259,15 +259,25 @@ void launch_pack_fold_key(const uint64_t* gsw, uint64_t* key, uint32_t ell, uint
 __global__ __launch_bounds__(kTpb) void pack_mac_kernel(const uint64_t* v_w, const uint64_t* ginv, const uint64_t* ct2, uint64_t* result, uint32_t out_n,
                                                         uint32_t t_conv) {
     const uint32_t z = blockIdx.x * kTpb + threadIdx.x, rc = blockIdx.y, row = rc / out_n, c = rc - row * out_n, rows = out_n + 1;
+    // the reference multiplies per r (t_conv <= 56 terms, one reduction, src/poly.cpp:62) and adds the out_n products mod m
+    // (src/testing.cpp:225-238); a u64 holds 256 terms of < 2^56, so the sum over r is reduced whenever the next r's terms
+    // would pass that (out_n * t_conv goes up to 16 * 56 = 896)
     uint64_t lo = 0, hi = 0;
+    uint32_t terms = 0;
     for (uint32_t r = 0; r < out_n; r++) {
         const uint64_t* w = v_w + (((size_t)r * rows + row) * t_conv) * kN + z;
         const uint64_t* g = ginv + ((size_t)(r * out_n + c) * t_conv) * kN + z;
+        if (terms + t_conv > 255u) {  // the reduced value counts as one term
+            lo = mod_p(lo);
+            hi = mod_b(hi);
+            terms = 1;
+        }
         for (uint32_t k = 0; k < t_conv; k++) {
             const uint64_t a = w[(size_t)k * kN], b = g[(size_t)k * kN];
             lo += (uint64_t)lo32(a) * lo32(b);
             hi += (uint64_t)hi32(a) * hi32(b);
         }
+        terms += t_conv;
     }
     uint32_t rp = mod_p(lo), rb = mod_b(hi);
     if (row >= 1) {

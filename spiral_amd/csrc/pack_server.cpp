@@ -237,6 +237,7 @@ int spiral_gpu_pack_server_gen_db(spiral_gpu_pack_server* S, uint64_t seed) {
 
 int spiral_gpu_pack_server_load_db(spiral_gpu_pack_server* S, uint32_t trial, const uint64_t* db) {
     if (!S || !db) return fail("null argument");
+    HIP_OK(hipSetDevice(S->device));
     if (trial >= S->s.trials) return fail("trial out of range");
     HIP_OK(hipSetDevice(S->device));
     DevBuf st;
@@ -249,6 +250,36 @@ int spiral_gpu_pack_server_load_db(spiral_gpu_pack_server* S, uint32_t trial, co
     }
     st.release();
     if (e != hipSuccess) return fail("database upload failed: %s", hipGetErrorString(e));
+    S->have_db = true;
+    return 0;
+}
+
+// raw ingest of one trial's 1 x 1 plaintexts (src/testing.cpp:845-869 + convertDb :316-340 on the device)
+int spiral_gpu_pack_server_load_db_items(spiral_gpu_pack_server* S, uint32_t trial, const void* items, uint32_t coeff_bits, uint64_t first_item,
+                                         uint64_t n_items) {
+    if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
+    if (trial >= S->s.trials) return fail("trial out of range");
+    const uint64_t total = (uint64_t)S->s.dim0 * S->s.num_per;
+    if (first_item > total || n_items > total - first_item) return fail("items outside the database");
+    FwdParams fp{};
+    fp.dst = S->db.p + (size_t)trial * S->db_words;
+    fp.src_map = fp.dst_map = identity_map();
+    fp.n_digits = 1;
+    fp.p_db = S->p.p_db;
+    fp.num_per = S->s.num_per;
+    fp.dim0_shard = S->s.dim0;
+    fp.trial = trial;
+    fp.total_n = total;
+    fp.coeff_bits = coeff_bits;
+    if (ingest_items(items, coeff_bits, first_item, first_item, first_item + n_items, 1, S->p.p_db, S->stream,
+                     [&](const uint8_t* d_items, uint32_t* d_err, uint64_t first, uint64_t n) {
+                         fp.items = d_items;
+                         fp.err = d_err;
+                         fp.items_first = fp.item_base = first;
+                         launch_ntt_forward(S->tb, fp, LD_DBGEN1, ST_DB1, (uint32_t)n, S->stream);
+                     }))
+        return -1;
     S->have_db = true;
     return 0;
 }
@@ -279,6 +310,7 @@ int spiral_gpu_pack_server_set_pub_params(spiral_gpu_pack_server* S, const uint6
 
 int spiral_gpu_pack_server_answer(spiral_gpu_pack_server* S, const uint64_t* query, uint64_t* response, uint64_t* packed_ct, double stage_us[8]) {
     if (!S || !query) return fail("null argument");
+    HIP_OK(hipSetDevice(S->device));
     if (!S->have_db || !S->have_pp) return fail("database and public parameters must be set first");
     HIP_OK(hipSetDevice(S->device));
     const spiral_gpu_params& p = S->p;

@@ -7,7 +7,7 @@
 
 namespace spiral {
 
-// w*y mod m in [0, 2m) from the Shoup companion ws = floor(w * 2^32 / m), any y < 2^32 (as ntt.cuh shoup)
+// w*y mod m in [0, 2m) from the Shoup companion ws = floor(w * 2^32 / m), any y < 2^32 (as ntt_device.h shoup)
 __device__ __forceinline__ uint32_t shoup32(uint32_t y, uint32_t w, uint32_t ws, uint32_t m) { return w * y - __umulhi(y, ws) * m; }
 
 constexpr uint32_t kTpb = 256;

@@ -616,6 +616,69 @@ int spiral_gpu_server_gen_db(spiral_gpu_server* S, uint64_t seed) {
     return 0;
 }
 
+int spiral_gpu_server_load_db_items(spiral_gpu_server* S, const void* items, uint32_t coeff_bits, uint64_t first_item, uint64_t n_items) {
+    if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
+    const uint64_t total = (uint64_t)S->s.dim0 * S->s.num_per;
+    if (first_item > total || n_items > total - first_item) return fail("items [%llu, +%llu) outside the database of %llu", (unsigned long long)first_item,
+                                                                         (unsigned long long)n_items, (unsigned long long)total);
+    // item i lives at (ii = i % num_per, j = i / num_per): this shard holds the items of j in [j0, j1)
+    const uint64_t lo = std::max<uint64_t>(first_item, (uint64_t)S->j0 * S->s.num_per), hi = std::min<uint64_t>(first_item + n_items, (uint64_t)S->j1 * S->s.num_per);
+    FwdParams fp{};
+    fp.dst = S->db.p;
+    fp.src_map = fp.dst_map = identity_map();
+    fp.n_digits = 1;
+    fp.p_db = S->p.p_db;
+    fp.num_per = S->s.num_per;
+    fp.dim0_shard = S->dim0_shard;
+    fp.j0 = S->j0;
+    fp.coeff_bits = coeff_bits;
+    if (ingest_items(items, coeff_bits, first_item, lo, hi, 4, S->p.p_db, S->stream, [&](const uint8_t* d_items, uint32_t* d_err, uint64_t first, uint64_t n) {
+            fp.items = d_items;
+            fp.err = d_err;
+            fp.items_first = fp.item_base = first;
+            launch_ntt_forward(S->tb, fp, LD_DBGEN, ST_DB, (uint32_t)(n * 4), S->stream);
+        }))
+        return -1;
+    S->have_db = true;
+    return 0;
+}
+
+int spiral_gpu_server_read_db_item(spiral_gpu_server* S, uint64_t item, uint64_t* out) {
+    if (!S || !out) return fail("null argument");
+    HIP_OK(hipSetDevice(S->device));
+    const uint64_t j = item / S->s.num_per;
+    if (j < S->j0 || j >= S->j1) return fail("item %llu is not in this shard", (unsigned long long)item);
+    Scratch sc;
+    uint64_t* d = sc.get(4 * kRefNtt);
+    if (!d) return fail("device allocation failed");
+    HIP_OK(hipStreamSynchronize(S->stream));
+    launch_db_read_item(S->db.p, d, S->s.num_per, S->dim0_shard, (uint32_t)(j - S->j0), (uint32_t)(item % S->s.num_per), S->stream);
+    HIP_OK(hipMemcpyAsync(out, d, 4 * kRefNtt * sizeof(uint64_t), hipMemcpyDeviceToHost, S->stream));
+    HIP_OK(hipStreamSynchronize(S->stream));
+    return 0;
+}
+
+int spiral_gpu_server_read_db_slots(spiral_gpu_server* S, uint32_t z_begin, uint32_t nz, uint64_t* out) {
+    if (!S || !out) return fail("null argument");
+    HIP_OK(hipSetDevice(S->device));
+    if (z_begin >= kN || nz == 0 || nz > kN - z_begin) return fail("slot range out of bounds");
+    const size_t per_z = (size_t)S->s.num_per * 2 * S->dim0_shard * 2;
+    const uint32_t zchunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(nz, ((size_t)256 << 20) / (per_z * sizeof(uint64_t))));
+    DevBuf st;
+    if (st.alloc(per_z * zchunk)) return -1;
+    hipError_t e = hipSuccess;
+    for (uint32_t z = 0; z < nz && e == hipSuccess; z += zchunk) {
+        const uint32_t n = std::min(zchunk, nz - z);
+        launch_db_read_slots(S->db.p, st.p, S->s.num_per, S->dim0_shard, z_begin + z, n, S->stream);
+        e = hipMemcpyAsync(out + (size_t)z * per_z, st.p, (size_t)n * per_z * sizeof(uint64_t), hipMemcpyDeviceToHost, S->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(S->stream);
+    }
+    st.release();
+    if (e != hipSuccess) return fail("database read-back failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
 int spiral_gpu_server_fill_db_random(spiral_gpu_server* S, uint64_t seed) {
     if (!S) return fail("null server");
     HIP_OK(hipSetDevice(S->device));
@@ -648,6 +711,7 @@ int spiral_gpu_server_set_query(spiral_gpu_server* S, const uint64_t* query) {
 
 int spiral_gpu_server_expand(spiral_gpu_server* S) {
     if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
     if (!S->have_query || !S->have_pp) return fail("query and public parameters must be set before expand");
     const spiral_gpu_params& p = S->p;
     if (p.direct_upload) {
@@ -749,6 +813,7 @@ extern "C" {
 
 int spiral_gpu_server_convert(spiral_gpu_server* S) {
     if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
     return convert_part(S, CONV_BOTH, S->stream, !S->use_graphs);
 }
 
@@ -763,6 +828,7 @@ int spiral_gpu_server_set_overlap(spiral_gpu_server* S, int on) {
 
 int spiral_gpu_server_first_dim(spiral_gpu_server* S) {
     if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
     if (!S->have_db) return fail("no database loaded");
     launch_sweep(S->db.p, (const uint32_t*)S->qs.p, S->acc, S->s.num_per, 2 * S->dim0_shard, S->fold_g_log, S->stream);
     return 0;
@@ -770,6 +836,7 @@ int spiral_gpu_server_first_dim(spiral_gpu_server* S) {
 
 int spiral_gpu_server_lift(spiral_gpu_server* S, int reduce_first) {
     if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
     InvParams ip{};
     ip.src = S->acc;
     ip.dst = S->raw.p;
@@ -843,12 +910,14 @@ int spiral_gpu_server_finish(spiral_gpu_server* S);
 
 int spiral_gpu_server_fold(spiral_gpu_server* S) {
     if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
     if (srv_join_side(S)) return -1;  // no-op inside run_post's capture: run_post joined before capturing
     return run_fold_rounds(S, S->s.num_per, 0, S->p.nu2, nullptr, false);  // src/spiral.cpp:1622-1626
 }
 
 int spiral_gpu_server_set_fold_ranks(spiral_gpu_server* S, uint32_t n_ranks) {
     if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
     if (n_ranks == 0 || (n_ranks & (n_ranks - 1)) || n_ranks > S->s.num_per) return fail("fold ranks must be a power of two <= num_per");
     S->fold_g_log = ceil_log2(n_ranks);
     srv_drop_graphs(S);
@@ -857,6 +926,7 @@ int spiral_gpu_server_set_fold_ranks(spiral_gpu_server* S, uint32_t n_ranks) {
 
 int spiral_gpu_server_finish(spiral_gpu_server* S) {
     if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
     // row 0 -> q', rows 1.. -> 4*p_db (src/spiral.cpp:1441-1447)
     launch_rescale2(S->raw.p, S->resp.p, 2 * kN, 6 * kN, kQ, S->s.qprime, 4 * S->p.p_db, S->stream);
     return 0;
@@ -864,6 +934,7 @@ int spiral_gpu_server_finish(spiral_gpu_server* S) {
 
 int spiral_gpu_server_sync(spiral_gpu_server* S) {
     if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
     if (srv_join_side(S)) return -1;
     HIP_OK(hipStreamSynchronize(S->stream));
     HIP_OK(hipGetLastError());
@@ -918,6 +989,7 @@ extern "C" {
 
 int spiral_gpu_server_run_pre(spiral_gpu_server* S) {
     if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
     if (!S->have_query || !S->have_pp) return fail("query and public parameters must be set first");
     if (!S->overlap) return run_group(S, 0, S->stream, [&]() { return expand_convert(S); });
     // overlap mode: expansion + ScalToMat on the main stream (the sweep needs only these); the Regev->GSW conversion
@@ -938,6 +1010,7 @@ int spiral_gpu_server_run_pre(spiral_gpu_server* S) {
 
 int spiral_gpu_server_run_query(spiral_gpu_server* S) {
     if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
     if (!S->have_query || !S->have_pp) return fail("query and public parameters must be set first");
     if (!S->have_db) return fail("no database loaded");
     if (srv_join_side(S)) return -1;
@@ -952,6 +1025,7 @@ int spiral_gpu_server_run_query(spiral_gpu_server* S) {
 // in are baked into the capture, so a graph is dropped when a different pointer arrives.
 int spiral_gpu_server_fold_local(spiral_gpu_server* S, const void* acc_chunk, void* out_ct) {
     if (!S || !acc_chunk || !out_ct) return fail("null argument");
+    HIP_OK(hipSetDevice(S->device));
     const uint32_t L = S->s.num_per >> S->fold_g_log;
     if (srv_join_side(S)) return -1;
     if (S->graph[5] && (S->cap_chunk != acc_chunk || S->cap_ct != out_ct)) {
@@ -969,6 +1043,7 @@ int spiral_gpu_server_fold_local(spiral_gpu_server* S, const void* acc_chunk, vo
 
 int spiral_gpu_server_fold_root(spiral_gpu_server* S, const void* gathered_cts) {
     if (!S || !gathered_cts) return fail("null argument");
+    HIP_OK(hipSetDevice(S->device));
     const uint32_t G = 1u << S->fold_g_log;
     if (srv_join_side(S)) return -1;
     if (S->graph[6] && S->cap_gathered != gathered_cts) {
@@ -985,6 +1060,7 @@ int spiral_gpu_server_fold_root(spiral_gpu_server* S, const void* gathered_cts) 
 // run_pre + first_dim as one group: what a rank does before the collective
 int spiral_gpu_server_run_pre_sweep(spiral_gpu_server* S) {
     if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
     if (!S->have_query || !S->have_pp) return fail("query and public parameters must be set first");
     if (!S->have_db) return fail("no database loaded");
     if (S->overlap) {
@@ -999,6 +1075,7 @@ int spiral_gpu_server_run_pre_sweep(spiral_gpu_server* S) {
 
 int spiral_gpu_server_run_post(spiral_gpu_server* S, int reduce_first) {
     if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
     if (srv_join_side(S)) return -1;
     return run_group(S, reduce_first ? 2 : 1, S->stream, [&]() {
         return run_fold_rounds(S, S->s.num_per, 0, S->p.nu2, S->acc, reduce_first != 0, true);  // lift chained into round 0, switch into the last
@@ -1061,6 +1138,7 @@ int spiral_gpu_server_answer_resident(spiral_gpu_server* S, double stage_us[8]) 
 
 int spiral_gpu_server_answer(spiral_gpu_server* S, const uint64_t* query, uint64_t* final_ct, uint64_t* response, double stage_us[8]) {
     if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
     if (spiral_gpu_server_set_query(S, query)) return -1;
     if (spiral_gpu_server_answer_resident(S, stage_us)) return -1;
     if (final_ct) HIP_OK(hipMemcpy(final_ct, S->raw.p, 6 * kPolyBytes, hipMemcpyDeviceToHost));
@@ -1070,10 +1148,12 @@ int spiral_gpu_server_answer(spiral_gpu_server* S, const uint64_t* query, uint64
 
 int spiral_gpu_server_keep_cts(spiral_gpu_server* S, int on) {
     if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
     if (on && !S->cts_keep.p) {
         HIP_OK(hipSetDevice(S->device));
         if (S->cts_keep.alloc((size_t)S->dim0_shard * 6 * kN)) return -1;
     }
+    if (S->keep_cts != (on != 0)) srv_drop_graphs(S);  // ScalToMat's output pointer is baked into the captured conversion
     S->keep_cts = on != 0;
     return 0;
 }
@@ -1127,6 +1207,7 @@ int spiral_gpu_server_write_raw(spiral_gpu_server* S, const uint64_t* raw_cts) {
 
 int spiral_gpu_server_time_sweep(spiral_gpu_server* S, int iters, float* avg_ms) {
     if (!S || !avg_ms || iters <= 0) return fail("bad argument");
+    HIP_OK(hipSetDevice(S->device));
     if (!S->have_db) return fail("no database loaded");
     HIP_OK(hipSetDevice(S->device));
     HIP_OK(hipEventRecord(S->ev[0], S->stream));

@@ -65,6 +65,13 @@ class PackServer:
     def load_db(self, trial: int, db):
         check(lib().spiral_gpu_pack_server_load_db(self.h, trial, _p(_c(db))))
 
+    def load_db_items(self, trial: int, items, coeff_bits: int, first_item: int = 0, n_items=None):
+        """raw ingest of one trial: bit-packed plaintext coefficients (coeff_bits each), 2048 per item"""
+        items = np.ascontiguousarray(items)
+        if n_items is None:
+            n_items = items.nbytes * 8 // (N * coeff_bits)
+        check(lib().spiral_gpu_pack_server_load_db_items(self.h, trial, items.ctypes.data_as(C.c_void_p), coeff_bits, first_item, n_items))
+
     def fill_db_random(self, seed: int):
         check(lib().spiral_gpu_pack_server_fill_db_random(self.h, seed))
 

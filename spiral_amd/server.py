@@ -27,6 +27,7 @@ class Server:
         h = C.c_void_p()
         check(lib().spiral_gpu_server_create(C.byref(params), device, j_begin, j_end, C.byref(h)))
         self.h = h
+        self.dim0_shard = (j_end - j_begin) if (j_begin or j_end) else self.shape.dim0
 
     def close(self):
         if getattr(self, "h", None):
@@ -48,6 +49,24 @@ class Server:
 
     def gen_db(self, seed: int):
         check(lib().spiral_gpu_server_gen_db(self.h, seed))
+
+    def load_db_items(self, items: np.ndarray, coeff_bits: int, first_item: int = 0, n_items: int | None = None):
+        """raw ingest: bit-packed plaintext coefficients (uint8 stream, coeff_bits each) or raw u64 MatPoly words (coeff_bits = 64)"""
+        items = np.ascontiguousarray(items)
+        if n_items is None:
+            n_items = items.nbytes * 8 // (4 * N * coeff_bits)
+        check(lib().spiral_gpu_server_load_db_items(self.h, items.ctypes.data_as(C.c_void_p), coeff_bits, first_item, n_items))
+
+    def read_db_item(self, item: int) -> np.ndarray:
+        out = np.zeros((2, 2, 2, N), dtype=np.uint64)
+        check(lib().spiral_gpu_server_read_db_item(self.h, item, _p(out)))
+        return out
+
+    def read_db_slots(self, z_begin: int, nz: int = 1) -> np.ndarray:
+        """load_db's layout restricted to this server's j-range: [nz][num_per][n2][j][n0] packed words"""
+        out = np.zeros((nz, self.shape.num_per, 2, self.dim0_shard, 2), dtype=np.uint64)
+        check(lib().spiral_gpu_server_read_db_slots(self.h, z_begin, nz, _p(out)))
+        return out
 
     def fill_db_random(self, seed: int):
         check(lib().spiral_gpu_server_fill_db_random(self.h, seed))

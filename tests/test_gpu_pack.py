@@ -50,6 +50,19 @@ def test_pack_seam(sa, oracle, out_n, t_conv):
     assert_eq(sa.pack(out_n, t_conv, v_ct, v_w), O.pack(v_ct, v_w, out_n, t_conv), "pack")
 
 
+def test_pack_seam_largest_sums(sa, oracle):
+    """out_n = 16, t_conv = 56 with every key residue m - 1: 896 products of ~2^56 per output word, far more than a u64
+    holds unreduced -- the reference reduces after each r's t_conv terms (multiply, src/poly.cpp:62) and adds mod m"""
+    O = oracle
+    out_n, t_conv = 16, 56
+    rng = np.random.default_rng(1656)
+    v_ct = rng.integers(0, O.Q, size=(out_n * out_n, 2, N), dtype=np.uint64)
+    v_w = np.zeros((out_n, out_n + 1, t_conv, 2, N), dtype=np.uint64)
+    v_w[..., 0, :] = O.P - 1
+    v_w[..., 1, :] = O.B - 1
+    assert_eq(sa.pack(out_n, t_conv, v_ct, v_w), O.pack(v_ct, v_w, out_n, t_conv), "pack, out_n = 16, t_conv = 56, keys m - 1")
+
+
 @pytest.mark.parametrize(
     "nu1,nu2,out_n,kw",
     [
