@@ -42,25 +42,78 @@ def synth_residues(rng, np, shape):
     return np.stack([rng.integers(0, m, size=shape + (sa.N,), dtype=np.uint64) for m in (sa.P, sa.B)], axis=-2)
 
 
-def cpu_baseline(params_kw, np):
-    """the oracle (CPU restatement, scalar C, 1 thread) timed on ONE full query of the same workload;
-    the database is arbitrary valid NTT-form words since only timing matters here"""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(params_kw, np, workload):
+    """the oracle (CPU restatement of the reference's algorithm, kind "port") timed on this box's host cores on ONE full
+    query of the same workload, twice: on 1 thread -- the reference is single-threaded (src/spiral.cpp:1231, no -fopenmp in
+    CMakeLists.txt:11) -- and on all cores (OpenMP over NTT slots in the sweep and over polynomials / ciphertexts in the
+    transforms).  Built here, on the machine it is timed on, with -O3 -march=native (oracle/Makefile
+    `native`).  The database is arbitrary valid NTT-form words since only timing matters."""
+    import shutil
+    import subprocess
+    import tempfile
+
     from oracle import pyoracle as O
 
-    O.build()
+    d = tempfile.mkdtemp(prefix="oracle_native_")
+    for f in ("spiral_oracle.c", "spiral_oracle_pack.c", "spiral_oracle.h", "Makefile"):
+        shutil.copy(os.path.join(ROOT, "oracle", f), d)
+    native = True
+    try:
+        subprocess.check_call(["make", "-C", d, "-s", "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        O.LIB_PATH = os.path.join(d, "liboracle_native.so")
+    except Exception:
+        native = False  # no compiler on this box: the prebuilt x86-64-v3 single-threaded library
+        O.build()
     po = O.make_params(**params_kw)
     s = O.shape_of(po)
     rng = np.random.default_rng(7)
     db = O.fill_db_random(99, O.db_words(po))
     mk = lambda shape: np.ascontiguousarray(np.stack([rng.integers(0, m, size=shape + (O.N,), dtype=np.uint64) for m in (O.P, O.B)], axis=-2))
-    wl, wr = mk((s.n_left, 2, po.t_exp)), mk((s.n_right, 2, po.t_exp_right))
+    wl, wr = mk((max(s.n_left, 1), 2, po.t_exp)), mk((max(s.n_right, 1), 2, po.t_exp_right))
     w, v = mk((3, 2 * po.t_conv)), mk((3, 2 * po.t_conv))
     q = mk((s.n_query_cts, 2))
-    t0 = time.perf_counter()
-    O.answer(po, q, wl, wr, w, v, db)
-    dt = time.perf_counter() - t0
-    return {"value": round(dt * 1e3, 1), "unit": "ms/query", "cores": 1, "kind": "port",
-            "sample": "1 full query (nu1=8, nu2=7, 2 GiB NTT-form DB of arbitrary valid words), oracle/liboracle.so scalar C, -O3"}
+
+    def timed(threads):
+        got = O.set_threads(threads)
+        t0 = time.perf_counter()
+        O.answer(po, q, wl, wr, w, v, db)
+        return got, (time.perf_counter() - t0) * 1e3
+
+    _, ms1 = timed(1)
+    out = {"value": round(ms1, 1), "unit": "ms/query", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
+           "build": "gcc -O3 -march=native -fopenmp on this box" if native else "prebuilt gcc -O3 -march=x86-64-v3",
+           "sample": f"1 full query of {workload} ({O.db_words(po) * 8 / 2**30:.0f} GiB NTT-form database of arbitrary valid words), oracle/ restatement"}
+    if native:
+        ncpu = os.cpu_count() or 1
+        timed(ncpu)  # thread pool start-up
+        got, msn = timed(ncpu)
+        out["all_cores"] = {"value": round(msn, 1), "unit": "ms/query", "cores": got, "logical_cpus": ncpu}
+    shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
+# BASELINE.json configs that run through the base server (bench.py --workload); parameter sets: all_parameter_choices.txt
+WORKLOADS = {
+    # configs[1] (= configs[0]'s geometry), "(20, 256)/spiral", all_parameter_choices.txt:67-81 -- the configuration the metric is quoted on
+    "config2": dict(nu1=8, nu2=7, t_gsw=8, t_conv=4, t_exp=8, t_exp_right=56, qprime_bits=20, p_db=256,
+                    label="configs[1]: Base Spiral 2^20 x 256B (nu1=8, nu2=7, p=256, t_GSW=8, t_conv=4, t_exp=8, t_exp_right=56, q'=2^20)"),
+    # configs[2]: 2^24 x 256 B = 32 GiB in the reference's layout; no published set, SURVEY.md 8d's choice
+    "config3": dict(nu1=9, nu2=10, t_gsw=10, t_conv=4, t_exp=8, t_exp_right=56, qprime_bits=22, p_db=256,
+                    label="configs[2]: Base Spiral 2^24 x 256B (nu1=9, nu2=10, p=256, t_GSW=10, t_conv=4, t_exp=8, t_exp_right=56, q'=2^22)"),
+    # configs[3]: "Streaming 20/spiralstream", all_parameter_choices.txt:1149-1163, one 64 GiB instance
+    "stream": dict(nu1=11, nu2=9, t_gsw=4, t_conv=56, t_exp=2, t_exp_right=56, qprime_bits=27, p_db=32768, direct_upload=1,
+                   label="configs[3]: SpiralStream (--direct-upload) 2^20 x 100KB (nu1=11, nu2=9, p=32768, t_GSW=4, t_conv=56, q'=27 bits)"),
+}
 
 
 def main():
@@ -68,8 +121,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--nu1", type=int, default=8)
-    ap.add_argument("--nu2", type=int, default=7)
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS), help="config2 = BASELINE.json configs[1], the one the metric is quoted on")
+    ap.add_argument("--nu1", type=int, default=None, help="override the workload's first-dimension size (tuning)")
+    ap.add_argument("--nu2", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     ap.add_argument("--overlap", type=int, default=0, help="1: Regev->GSW conversion on a side stream under the sweep (measured slower: the sweep loses "
@@ -111,7 +165,12 @@ def main():
         else:
             dist.init_process_group(backend=args.backend)
 
-    params_kw = dict(nu1=args.nu1, nu2=args.nu2, t_gsw=8, t_conv=4, t_exp=8, t_exp_right=56, qprime_bits=20, p_db=256)
+    params_kw = dict(WORKLOADS[args.workload])
+    label = params_kw.pop("label")
+    if args.nu1 is not None: params_kw["nu1"] = args.nu1
+    if args.nu2 is not None: params_kw["nu2"] = args.nu2
+    if (args.nu1, args.nu2) != (None, None): label += f" with nu1={params_kw['nu1']}, nu2={params_kw['nu2']}"
+    args.nu1, args.nu2 = params_kw["nu1"], params_kw["nu2"]
     pg = sa.make_params(**params_kw)
     shp = sa.get_shape(pg)
     j0, j1 = sdist.shard_range(rank, world, shp.dim0)
@@ -121,7 +180,7 @@ def main():
     srv.set_stream(stream.cuda_stream)
     srv.gen_db(1234)  # explicit database generated on the device, this rank's j-shard
     rng = np.random.default_rng(1)  # same synthetic inputs on every rank
-    srv.set_pub_params(synth_residues(rng, np, (shp.n_left, 2, pg.t_exp)), synth_residues(rng, np, (shp.n_right, 2, pg.t_exp_right)),
+    srv.set_pub_params(synth_residues(rng, np, (max(shp.n_left, 1), 2, pg.t_exp)), synth_residues(rng, np, (max(shp.n_right, 1), 2, pg.t_exp_right)),
                        synth_residues(rng, np, (3, 2 * pg.t_conv)), synth_residues(rng, np, (3, 2 * pg.t_conv)))
     srv.set_query(synth_residues(rng, np, (shp.n_query_cts, 2)))
     acc = torch.zeros(shp.num_per * 6 * sa.N, dtype=torch.int64, device=dev)
@@ -211,7 +270,7 @@ def main():
     achieved = bytes_sweep / (sweep_ms * 1e-3) / 1e9
     traffic, traffic_src = pmc_traffic(world, args.nu1, args.nu2)
     out = {
-        "metric": "server ms/query (2^20 x 256B, Base Spiral nu1=8 nu2=7) + first-dim sweep GB/s vs HBM roofline",
+        "metric": "server ms/query + DB GB/s vs HBM roofline" + (", 2^20 x 256B" if args.workload == "config2" else f" ({args.workload})"),
         "value": round(ms_per_step, 4),
         "unit": "ms/query",
         "n_gpus": world,
@@ -223,25 +282,36 @@ def main():
         "vs_baseline": None,
         "dtype": "u32 residues, 32x32->64-bit integer MAC (two 28-bit CRT primes)",
         "data": "synthetic",
-        "config": {"workload": "configs[1]: Base Spiral 2^20 x 256B (nu1=8, nu2=7, p=256, t_GSW=8, t_conv=4, t_exp=8, t_exp_right=56, q'=2^20), "
-                               "explicit DB generated on device, sharded by first-dimension index",
+        "config": {"workload": label + ", explicit DB generated on device, sharded by first-dimension index",
                    "db_bytes_ntt_form": int(shp.dim0) * int(shp.num_per) * 4 * sa.N * 8, "schedule": "GSW conversion overlapped with the sweep (side stream)" if args.overlap else "in order, one stream",
                    "parallelism": (f"j-shard x{world}, reduce-scatter + distributed fold + all-gather" if sharded_fold else f"j-shard x{world} + 1 reduce")},
         "queries_per_s": round(1e3 / ms_per_step, 2),
         "stages_us": {k: round(v, 1) for k, v in stages.items()},
         "reference_buckets_us_eager": ({k: round(v, 1) for k, v in detail.items() if k != "scaltomat_us"} if detail else None),
         "roofline": {"bound": "hbm", "kernel": "sweep_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(bytes_sweep),
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "frac_device_bytes": round(srv.sweep_device_bytes() / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(bytes_sweep),
                      "avg_launch_ms": round(sweep_ms, 4),
                      "device_bytes_per_launch": int(srv.sweep_device_bytes()), "achieved_device_bytes": round(srv.sweep_device_bytes() / (sweep_ms * 1e-3) / 1e9, 1),
-                     "note": "achieved = SURVEY 8d algorithmic bytes (8 B per database word) / launch time; the device keeps a word's two 28-bit residues in 7 bytes, so a launch moves device_bytes_per_launch (traffic = the PMC measurement of that)", "launches_timed": len(sampled), "shard": f"j in [{j0},{j1}) on rank 0"},
+                     "note": "achieved / frac = SURVEY 8d algorithmic bytes (8 B per database word) / launch time; the device keeps a word's two 28-bit residues in 7 bytes, so a launch physically moves device_bytes_per_launch: achieved_device_bytes / frac_device_bytes are the HBM utilisation in physical bytes (traffic = the PMC measurement of them)", "launches_timed": len(sampled), "shard": f"j in [{j0},{j1}) on rank 0"},
     }
+    # the transform kernels against their VALU bound (they are the rest of the query: ~29 k limb-pair transforms at config 2).
+    # Bound: the bare Harvey / Shoup butterfly = 3 integer multiplies (4.45 cycles each per wave instruction per SIMD, measured,
+    # profiles/r02_ubench_valu.txt) + 4 add / sub (2.9) = 25 cycles x 88 limb-butterflies per thread, 4 waves per polynomial on
+    # 4 SIMDs: 2200 cycles per polynomial per CU = 3.6 ns per polynomial over 256 CUs at 2.4 GHz.
+    roofline_ntt = None
+    if rank == 0 and world == 1:
+        fwd_ms, inv_ms = sa.time_ntt(16384, 10)
+        ns_f, ns_i = fwd_ms * 1e6 / 16384, inv_ms * 1e6 / 16384
+        roofline_ntt = {"bound": "valu", "unit": "ns per limb-pair transform (2048 points x 2 primes)", "peak": 3.6,
+                        "forward_to_ntt": round(ns_f, 2), "inverse_from_ntt": round(ns_i, 2), "frac_forward": round(3.6 / ns_f, 3), "frac_inverse": round(3.6 / ns_i, 3),
+                        "batch": 16384, "note": "standalone batched to_ntt (reduce mod p, b + forward) and from_ntt (inverse + CRT lift) launches, HIP events"}
     srv.close()
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(params_kw, np)
+        if roofline_ntt: out["roofline_ntt"] = roofline_ntt
+        if world == 1 and not args.no_cpu_baseline and args.workload == "config2":  # (the larger workloads' 32 / 64 GiB host databases are not built for a baseline)
+            out["cpu_baseline"] = cpu_baseline(params_kw, np, args.workload)
         import ctypes
 
         ctypes.CDLL(None).fflush(None)  # RCCL printf()s a banner into C stdio; get it out before the JSON

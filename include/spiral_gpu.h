@@ -75,6 +75,9 @@ int spiral_gpu_ntt_inverse(uint64_t *operand, size_t npolys);
 int spiral_gpu_to_ntt(uint64_t *out, const uint64_t *in, size_t npolys, int reduce);
 /* from_ntt, src/poly.cpp:357 : NTT -> raw in [0, Q) */
 int spiral_gpu_from_ntt(uint64_t *out, const uint64_t *in, size_t npolys);
+/* measurement helper: average duration (ms) of one batched to_ntt and one batched from_ntt launch over npolys polynomials
+ * resident in HBM (HIP events, default stream): the transform kernels' cost per limb-pair transform */
+int spiral_gpu_time_ntt(size_t npolys, int iters, float *fwd_ms, float *inv_ms);
 /* multiply, src/poly.cpp:34 : out(rs x cs) = a(rs x ms) * b(ms x cs), NTT form */
 int spiral_gpu_multiply(uint64_t *out, const uint64_t *a, const uint64_t *b, size_t rs, size_t ms, size_t cs);
 /* add, mul_by_const, src/poly.cpp:138,190 */
@@ -277,6 +280,9 @@ int spiral_gpu_pack_server_set_pub_params(spiral_gpu_pack_server *s, const uint6
  * (out_n^2 sweeps + lift) [3] folding [4] packing + modulus switch [5] the sweep kernels alone [6] total. */
 int spiral_gpu_pack_server_answer(spiral_gpu_pack_server *s, const uint64_t *query, uint64_t *response, uint64_t *packed_ct,
                                   double stage_us[8]);
+/* the first-dimension accumulators of one trial of the last answer (fastMultiplyQueryByDatabaseDim1's output, :1050):
+ * num_per ciphertexts base_dim x 1, NTT form (tests) */
+int spiral_gpu_pack_server_read_acc(spiral_gpu_pack_server *s, uint32_t trial, uint64_t *out);
 uint64_t spiral_gpu_pack_server_sweep_bytes(spiral_gpu_pack_server *s); /* algorithmic bytes of ONE trial's sweep */
 
 #ifdef __cplusplus

@@ -336,6 +336,8 @@ def pack_items(pts, coeff_bits):
     """plaintext coefficients (any shape, values < 2^coeff_bits) -> the bit-packed item stream of spiral_gpu_server_load_db_items:
     little-endian bit order, coefficient k at bits [k*coeff_bits, (k+1)*coeff_bits) (read_arbitrary_bits, src/core.cpp:20-30)"""
     v = np.ascontiguousarray(pts, dtype=np.uint64).reshape(-1)
+    if coeff_bits in (8, 16, 32, 64):
+        return np.ascontiguousarray(v.astype({8: "<u1", 16: "<u2", 32: "<u4", 64: "<u8"}[coeff_bits])).view(np.uint8)
     bits = ((v[:, None] >> np.arange(coeff_bits, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(np.uint8).reshape(-1)
     return np.packbits(bits, bitorder="little")
 
@@ -402,6 +404,13 @@ def pack_gen_db(p, out_n, seed):
     s = pack_shape_of(p, out_n)
     db = u64(s.trials, s.dim0 * s.num_per * N)
     lib().orc_pack_gen_db(C.byref(p), C.c_uint32(out_n), C.c_uint64(seed), _p(db))
+    return db
+
+
+def pack_gen_db_trial(p, out_n, seed, trial):
+    s = pack_shape_of(p, out_n)
+    db = u64(s.dim0 * s.num_per * N)
+    lib().orc_pack_gen_db_trial(C.byref(p), C.c_uint32(out_n), C.c_uint64(seed), C.c_uint32(trial), _p(db))
     return db
 
 

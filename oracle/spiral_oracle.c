@@ -30,6 +30,7 @@ typedef unsigned __int128 u128;
 #endif
 static int g_threads = 1;
 static void build_tables(void);
+int orc_get_threads(void) { return g_threads; }
 int orc_set_threads(int n) {
     build_tables(); /* lazily built otherwise: not from inside a parallel region */
 #ifdef _OPENMP

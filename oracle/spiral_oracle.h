@@ -200,6 +200,7 @@ int orc_pack_answer(const orc_params *p, uint32_t out_n, const uint64_t *query, 
 /* seeded database: coefficient z of item i of trial t */
 uint64_t orc_pack_db_coeff(uint64_t seed, uint64_t trial, uint64_t item, uint64_t z, uint64_t total_n, uint64_t p_db);
 void orc_pack_gen_db(const orc_params *p, uint32_t out_n, uint64_t seed, uint64_t *db);
+void orc_pack_gen_db_trial(const orc_params *p, uint32_t out_n, uint64_t seed, uint32_t trial, uint64_t *db_trial);
 void orc_pack_db_item(const orc_params *p, uint32_t out_n, uint64_t seed, uint64_t item, uint64_t *pt /* raw [out_n][out_n][N] */);
 
 typedef struct orc_pack_client orc_pack_client;

@@ -9,6 +9,9 @@
 #include <string.h>
 
 #include "spiral_oracle.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define N ORC_N
 #define Q ORC_Q
@@ -85,7 +88,12 @@ void orc_pack_fold_neg(uint64_t *neg, const uint64_t *gsw, uint32_t ell, uint32_
     free(g); free(g_ntt); free(raw); free(inv); free(inv_ntt);
 }
 
+/* bench.py / full-size tests only: orc_set_threads(n) of the `native` OpenMP build (spiral_oracle.c); 1 otherwise */
+int orc_get_threads(void);
+#define g_threads orc_get_threads()
+
 void orc_reorient_dim1(uint64_t *out, const uint64_t *cts, size_t dim0, size_t idx_factor) {
+#pragma omp parallel for if (g_threads > 1)
     for (size_t j = 0; j < dim0; j++)
         for (uint32_t r = 0; r < BD; r++) {
             const uint64_t *p = cts + ((j * idx_factor) * BD + r) * NTTP;
@@ -94,6 +102,7 @@ void orc_reorient_dim1(uint64_t *out, const uint64_t *cts, size_t dim0, size_t i
 }
 
 void orc_sweep_dim1(uint64_t *out, const uint64_t *db, const uint64_t *re, size_t dim0, size_t num_per) {
+#pragma omp parallel for if (g_threads > 1)
     for (uint32_t z = 0; z < N; z++) {
         const uint64_t *a = re + (size_t)z * dim0 * BD, *bz = db + (size_t)z * num_per * dim0;
         for (size_t i = 0; i < num_per; i++) {
@@ -117,12 +126,19 @@ void orc_sweep_dim1(uint64_t *out, const uint64_t *db, const uint64_t *re, size_
 void orc_fold_dim1(uint64_t *cts, size_t num_per, const uint64_t *folding, const uint64_t *folding_neg, uint32_t ell, uint32_t nu2) {
     const size_t CTR = (size_t)BD * N, gsw_words = (size_t)BD * BD * ell * NTTP;
     uint32_t k = BD * ell;
-    uint64_t *gi = malloc((size_t)k * N * 8), *gi_ntt = malloc((size_t)k * NTTP * 8);
-    uint64_t *prod = malloc(BD * NTTP * 8), *sum = malloc(BD * NTTP * 8);
+    const int nthr = g_threads;
+    const size_t per = (size_t)k * N + (size_t)k * NTTP + 2 * BD * NTTP; /* scratch of one iteration, one set per thread */
+    uint64_t *scratch = malloc(per * (size_t)nthr * 8);
     for (uint32_t cur = 0; cur < nu2; cur++) {
         num_per /= 2;
         const uint64_t *f = folding + (size_t)(nu2 - 1 - cur) * gsw_words, *fn = folding_neg + (size_t)(nu2 - 1 - cur) * gsw_words;
+#pragma omp parallel for if (nthr > 1)
         for (size_t i = 0; i < num_per; i++) {
+            int tid = 0;
+#ifdef _OPENMP
+            tid = omp_get_thread_num();
+#endif
+            uint64_t *gi = scratch + per * (size_t)tid, *gi_ntt = gi + (size_t)k * N, *prod = gi_ntt + (size_t)k * NTTP, *sum = prod + BD * NTTP;
             orc_gadget_invert(gi, cts + i * CTR, k, BD, 1);
             orc_to_ntt(gi_ntt, gi, k);
             orc_multiply(prod, fn, gi_ntt, BD, k, 1);
@@ -133,7 +149,7 @@ void orc_fold_dim1(uint64_t *cts, size_t num_per, const uint64_t *folding, const
             orc_from_ntt(cts + i * CTR, sum, BD);
         }
     }
-    free(gi); free(gi_ntt); free(prod); free(sum);
+    free(scratch);
 }
 
 void orc_pack(uint64_t *result, uint32_t out_n, uint32_t t_conv, const uint64_t *v_ct, const uint64_t *v_w) {
@@ -220,9 +236,11 @@ uint64_t orc_pack_db_coeff(uint64_t seed, uint64_t trial, uint64_t item, uint64_
 void orc_pack_gen_db(const orc_params *p, uint32_t out_n, uint64_t seed, uint64_t *db) {
     orc_pack_shape s;
     if (orc_pack_get_shape(p, out_n, &s)) return;
-    uint64_t total = (uint64_t)s.dim0 * s.num_per, pt[N], enc[NTTP];
+    uint64_t total = (uint64_t)s.dim0 * s.num_per;
     for (uint32_t t = 0; t < s.trials; t++)
+#pragma omp parallel for if (g_threads > 1)
         for (uint64_t i = 0; i < total; i++) {
+            uint64_t pt[N], enc[NTTP];
             for (uint32_t z = 0; z < N; z++) {
                 int64_t v = (int64_t)orc_pack_db_coeff(seed, t, i, z, total, p->p_db);
                 if (v >= (int64_t)(p->p_db / 2)) v -= (int64_t)p->p_db;
@@ -234,6 +252,26 @@ void orc_pack_gen_db(const orc_params *p, uint32_t out_n, uint64_t seed, uint64_
             uint64_t *d = db + (size_t)t * total * N;
             for (uint32_t z = 0; z < N; z++) d[(size_t)z * total + ii * s.dim0 + j] = enc[z] | (enc[N + z] << 32);
         }
+}
+
+/* one trial of the above (a 4 GiB slice of config 5's 64 GiB) */
+void orc_pack_gen_db_trial(const orc_params *p, uint32_t out_n, uint64_t seed, uint32_t t, uint64_t *d) {
+    orc_pack_shape s;
+    if (orc_pack_get_shape(p, out_n, &s)) return;
+    uint64_t total = (uint64_t)s.dim0 * s.num_per;
+#pragma omp parallel for if (g_threads > 1)
+    for (uint64_t i = 0; i < total; i++) {
+        uint64_t pt[N], enc[NTTP];
+        for (uint32_t z = 0; z < N; z++) {
+            int64_t v = (int64_t)orc_pack_db_coeff(seed, t, i, z, total, p->p_db);
+            if (v >= (int64_t)(p->p_db / 2)) v -= (int64_t)p->p_db;
+            if (v < 0) v += (int64_t)Q;
+            pt[z] = (uint64_t)v;
+        }
+        orc_to_ntt(enc, pt, 1);
+        uint64_t ii = i % s.num_per, j = i / s.num_per;
+        for (uint32_t z = 0; z < N; z++) d[(size_t)z * total + ii * s.dim0 + j] = enc[z] | (enc[N + z] << 32);
+    }
 }
 
 void orc_pack_db_item(const orc_params *p, uint32_t out_n, uint64_t seed, uint64_t item, uint64_t *pt) {

@@ -65,6 +65,7 @@ PROTOTYPES = {
     "spiral_gpu_ntt_inverse": (C.c_int, [U64P, C.c_size_t]),
     "spiral_gpu_to_ntt": (C.c_int, [U64P, U64P, C.c_size_t, C.c_int]),
     "spiral_gpu_from_ntt": (C.c_int, [U64P, U64P, C.c_size_t]),
+    "spiral_gpu_time_ntt": (C.c_int, [C.c_size_t, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "spiral_gpu_multiply": (C.c_int, [U64P, U64P, U64P, C.c_size_t, C.c_size_t, C.c_size_t]),
     "spiral_gpu_add": (C.c_int, [U64P, U64P, U64P, C.c_size_t]),
     "spiral_gpu_mul_by_const": (C.c_int, [U64P, U64P, U64P, C.c_size_t]),
@@ -127,6 +128,7 @@ PROTOTYPES = {
     "spiral_gpu_pack_server_load_db_items": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]),
     "spiral_gpu_pack_server_set_pub_params": (C.c_int, [C.c_void_p, U64P, U64P, U64P, U64P]),
     "spiral_gpu_pack_server_answer": (C.c_int, [C.c_void_p, U64P, U64P, U64P, C.POINTER(C.c_double)]),
+    "spiral_gpu_pack_server_read_acc": (C.c_int, [C.c_void_p, C.c_uint32, U64P]),
     "spiral_gpu_pack_server_sweep_bytes": (C.c_uint64, [C.c_void_p]),
 }
 

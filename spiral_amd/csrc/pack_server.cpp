@@ -427,6 +427,15 @@ int spiral_gpu_pack_server_answer(spiral_gpu_pack_server* S, const uint64_t* que
     return 0;
 }
 
+int spiral_gpu_pack_server_read_acc(spiral_gpu_pack_server* S, uint32_t trial, uint64_t* out) {
+    if (!S || !out) return fail("null argument");
+    HIP_OK(hipSetDevice(S->device));
+    if (trial >= S->s.trials) return fail("trial out of range");
+    HIP_OK(hipStreamSynchronize(S->stream));
+    Scratch sc;
+    return download_pk(sc, S->acc.p + (size_t)trial * S->s.num_per * 2 * kN, identity_map(), out, (size_t)S->s.num_per * 2);
+}
+
 uint64_t spiral_gpu_pack_server_sweep_bytes(spiral_gpu_pack_server* S) {
     if (!S) return 0;
     // SURVEY.md 8d, pack form: 2^(nu1+nu2)*N*8 + 2^nu1*2*N*8 + 2^nu2*2*2*N*8 per trial

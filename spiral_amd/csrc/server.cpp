@@ -256,6 +256,44 @@ int spiral_gpu_from_ntt(uint64_t* out, const uint64_t* in, size_t npolys) {
 }
 
 
+// measurement helper: average duration of one batched forward (to_ntt: raw -> packed NTT form) and one batched inverse
+// (from_ntt: packed NTT form -> CRT-lifted raw) launch over npolys polynomials, HIP events on the default stream
+int spiral_gpu_time_ntt(size_t npolys, int iters, float* fwd_ms, float* inv_ms) {
+    if (!fwd_ms || !inv_ms || iters <= 0 || npolys == 0) return fail("bad argument");
+    DeviceTables tb;
+    if (current_tables(&tb)) return -1;
+    Scratch sc;
+    uint64_t* d_raw = sc.get(npolys * kN);
+    uint64_t* d_pk = sc.get(npolys * kN);
+    if (!d_raw || !d_pk) return fail("device allocation failed");
+    HIP_OK(hipMemset(d_raw, 0x5a, npolys * kN * sizeof(uint64_t)));
+    hipEvent_t e[3];
+    for (auto& x : e) HIP_OK(hipEventCreate(&x));
+    FwdParams fp{};
+    fp.src = d_raw;
+    fp.dst = d_pk;
+    fp.src_map = fp.dst_map = identity_map();
+    fp.n_digits = 1;
+    InvParams ip{};
+    ip.src = d_pk;
+    ip.dst = d_raw;
+    ip.src_map = ip.dst_map = identity_map();
+    launch_ntt_forward(tb, fp, LD_RAW, ST_PK, (uint32_t)npolys, 0);  // warm
+    launch_ntt_inverse(tb, ip, IST_CRT, (uint32_t)npolys, 0);
+    HIP_OK(hipEventRecord(e[0], 0));
+    for (int i = 0; i < iters; i++) launch_ntt_forward(tb, fp, LD_RAW, ST_PK, (uint32_t)npolys, 0);
+    HIP_OK(hipEventRecord(e[1], 0));
+    for (int i = 0; i < iters; i++) launch_ntt_inverse(tb, ip, IST_CRT, (uint32_t)npolys, 0);
+    HIP_OK(hipEventRecord(e[2], 0));
+    HIP_OK(hipEventSynchronize(e[2]));
+    HIP_OK(hipEventElapsedTime(fwd_ms, e[0], e[1]));
+    HIP_OK(hipEventElapsedTime(inv_ms, e[1], e[2]));
+    *fwd_ms /= iters;
+    *inv_ms /= iters;
+    for (auto& x : e) (void)hipEventDestroy(x);
+    return 0;
+}
+
 int spiral_gpu_multiply(uint64_t* out, const uint64_t* a, const uint64_t* b, size_t rs, size_t ms, size_t cs) {
     Scratch sc;
     uint64_t* da = upload_pk(sc, a, rs * ms);

@@ -168,3 +168,10 @@ def regevToGSW(m_conv, t, cv_v, W, V) -> np.ndarray:
     out = np.zeros((3, 3 * t, 2, N), dtype=np.uint64)
     check(lib().spiral_gpu_regev_to_gsw(_p(out), _p(_c(cv_v)), _p(_c(W)), _p(_c(V)), m_conv, t))
     return out
+
+
+def time_ntt(npolys: int, iters: int = 10):
+    """average ms of one batched to_ntt / from_ntt launch over npolys polynomials resident in HBM -> (fwd_ms, inv_ms)"""
+    f, i = C.c_float(), C.c_float()
+    check(lib().spiral_gpu_time_ntt(npolys, iters, C.byref(f), C.byref(i)))
+    return f.value, i.value

@@ -72,6 +72,12 @@ class PackServer:
             n_items = items.nbytes * 8 // (N * coeff_bits)
         check(lib().spiral_gpu_pack_server_load_db_items(self.h, trial, items.ctypes.data_as(C.c_void_p), coeff_bits, first_item, n_items))
 
+    def read_acc(self, trial: int) -> np.ndarray:
+        """first-dimension accumulators of one trial of the last answer: [num_per][2][2][N] NTT form"""
+        out = np.zeros((self.shape.num_per, 2, 2, N), dtype=np.uint64)
+        check(lib().spiral_gpu_pack_server_read_acc(self.h, trial, _p(out)))
+        return out
+
     def fill_db_random(self, seed: int):
         check(lib().spiral_gpu_pack_server_fill_db_random(self.h, seed))
 

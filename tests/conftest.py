@@ -19,3 +19,25 @@ def oracle():
 
     pyoracle.build()
     return pyoracle
+
+
+@pytest.fixture(scope="session")
+def oracle_mt(tmp_path_factory):
+    """the same oracle sources built ON this machine with -march=native -fopenmp (oracle/Makefile `native`) and run on
+    many threads: what the full-size parity tests use so that a 2 .. 64 GiB reference computation takes seconds.  A second
+    instance of the pyoracle module bound to that library; identical results (tests/test_oracle.py checks it)."""
+    import importlib.util
+    import shutil
+    import subprocess
+
+    d = tmp_path_factory.mktemp("oracle_native")
+    src = os.path.join(ROOT, "oracle")
+    for f in ("spiral_oracle.c", "spiral_oracle_pack.c", "spiral_oracle.h", "Makefile"):
+        shutil.copy(os.path.join(src, f), d)
+    subprocess.check_call(["make", "-C", str(d), "-s", "native"])
+    spec = importlib.util.spec_from_file_location("pyoracle_mt", os.path.join(src, "pyoracle.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.LIB_PATH = os.path.join(str(d), "liboracle_native.so")
+    mod.n_threads = mod.set_threads(max(1, min(os.cpu_count() or 1, 96)))
+    return mod

@@ -116,3 +116,21 @@ def test_bench_two_rank_flow_on_one_gpu():
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["value"] > 0 and out["scaling"] == "strong"
     assert out["roofline"]["bound"] == "hbm" and out["roofline"]["achieved"] > 0
     assert "reduce-scatter" in out["config"]["parallelism"]
+
+
+@pytest.mark.parametrize("extra", [[], ["--root-fold"]])
+def test_bench_rccl_world_size_one(extra):
+    """RCCL itself on hardware: bench.py with torch.distributed initialised on the nccl (= RCCL) backend and a world of one
+    rank, so that init_process_group(device_id=...), reduce_scatter_tensor / all_gather_into_tensor / reduce on the int64
+    accumulator tensors, the barrier and the max-over-ranks all-reduce all execute through RCCL, in the step loop the
+    N-GPU runs use (the collectives are identities at world size 1; what is tested is that they run on this stack)"""
+    import json
+    import subprocess
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--force-dist", "--backend", "nccl", "--no-cpu-baseline"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["roofline"]["achieved"] > 0
+    assert ("1 reduce" in out["config"]["parallelism"]) == bool(extra)

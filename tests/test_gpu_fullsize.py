@@ -1,0 +1,230 @@
+"""Bit-exact parity at BASELINE.json's full sizes, through the C ABI (`-m gpu`, marked slow).
+
+The oracle side runs on the `oracle_mt` fixture: the same oracle sources built on the test machine with OpenMP
+(tests/test_oracle.py proves that build equal to the default one), so that a 2 GiB database and a full-size query are
+seconds of host time.  What is compared bit for bit:
+
+* configs[1] / configs[0] (nu1=8, nu2=7, 2^20 x 256 B): every stage output -- expanded ciphertexts, ScalToMat outputs, GSW
+  matrices, the 24 MiB of sweep accumulators, the lifted and folded ciphertexts, the 96 KiB response -- from the stage
+  API, from answer() and from the whole-query hipGraph; with the database generated on the device, uploaded in the
+  reference's NTT layout, and ingested from raw plaintext bytes (SURVEY.md 8c asked for the SHA-256 of the sweep
+  output and of the response: printed, and equal because the arrays are).
+* configs[2] geometry (nu1=9, nu2=10, 32 GiB) and configs[3] (SpiralStream nu1=11, nu2=9, 64 GiB): the database does not
+  fit a host-side reference computation, and the sweep is independent per NTT slot, so the device database is read
+  back for a sample of slots, the oracle runs the sweep on exactly those slots, and the accumulators must agree there;
+  sampled items of the device database must equal the oracle's encoding of the seeded plaintexts; everything
+  database-independent (expansion, conversion) is compared in full; the response must decode to the item.
+* configs[4] (SpiralPack nu1=10, nu2=8, n=4, 64 GiB): trial 0's sweep accumulators against the oracle's sweep of that
+  trial's 4 GiB database; with enough host memory, all 16 trials, the packed ciphertext and the response.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = [pytest.mark.gpu, pytest.mark.slow]
+N = 2048
+
+
+@pytest.fixture(scope="module")
+def sa():
+    import torch  # torch first: it ships its own HIP runtime
+
+    torch.cuda.is_available()
+    import spiral_amd
+
+    assert spiral_amd.lib().spiral_gpu_device_count() > 0, "GPU tests need a device"
+    return spiral_amd
+
+
+def assert_eq(got, exp, what):
+    if not (got.shape == exp.shape and (got == exp).all()):
+        bad = np.argwhere(got != exp) if got.shape == exp.shape else []
+        raise AssertionError(f"{what}: shapes {got.shape} / {exp.shape}, {len(bad)} of {got.size} words differ, first at {bad[:5].tolist() if len(bad) else '-'}")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype="<u8").tobytes()).hexdigest()[:16]
+
+
+def host_gib_available():
+    import psutil
+
+    return psutil.virtual_memory().available / 2**30
+
+
+def test_config2_every_stage_bit_exact(sa, oracle_mt):
+    """configs[1] (= configs[0]'s geometry): the whole path at 2^20 x 256 B against the oracle, stage by stage"""
+    M = oracle_mt
+    from spiral_amd import server as SV
+
+    po, pg = M.make_params(8, 7), sa.make_params(8, 7)
+    s = M.shape_of(po)
+    cl = M.Client(po, seed=1)
+    wl, wr, w, v = cl.pub_params()
+    idx = 1234
+    q = cl.query(idx)
+    db = M.gen_db(po, 1234)  # 2 GiB, the reference's layout
+    cv = M.stage_expand(po, q, wl, wr)
+    cts, gsw = M.stage_convert(po, cv, w, v)
+    acc = M.multiply_query_by_database(M.reorient_ciphertexts(cts), db, s.dim0, s.num_per)
+    raw = M.from_ntt(acc)
+    fin = M.stage_fold(po, raw, gsw)
+    resp = M.stage_rescale(po, fin)
+    print(f"config 2 oracle ({M.n_threads} threads): sha256 sweep output {sha(acc)} response {sha(resp)}")
+
+    srv = sa.Server(pg)
+    srv.keep_cts(True)
+    srv.gen_db(1234)
+    srv.set_pub_params(wl, wr, w, v)
+    srv.set_query(q)
+    srv.expand()
+    assert_eq(srv.read(SV.BUF_EXPANDED), cv, "expanded ciphertexts")
+    srv.convert()
+    assert_eq(srv.read(SV.BUF_CTS), cts, "scalToMat outputs")
+    assert_eq(srv.read(SV.BUF_GSW), gsw, "regevToGSW outputs")
+    srv.first_dim()
+    got_acc = srv.read(SV.BUF_ACC)
+    assert_eq(got_acc, acc, "first-dimension accumulators (24 MiB)")
+    srv.lift()
+    assert_eq(srv.read(SV.BUF_RAW), raw, "lifted first-dimension result")
+    srv.fold()
+    assert_eq(srv.read(SV.BUF_FINAL), fin, "folded ciphertext")
+    srv.finish()
+    got_resp = srv.read(SV.BUF_RESPONSE)
+    assert_eq(got_resp, resp, "response")
+    print(f"config 2 device: sha256 sweep output {sha(got_acc)} response {sha(got_resp)}")
+    assert_eq(cl.decode(got_resp), M.db_item(po, 1234, idx), "decoded plaintext")
+
+    # answer() in one call, and the whole query replayed as one hipGraph, for other indices too
+    for i2 in (0, (1 << 15) - 1):
+        q2 = cl.query(i2)
+        want = M.answer(po, q2, wl, wr, w, v, db)
+        f2, r2, _ = srv.answer(q2)
+        assert_eq(f2, want, f"answer() idx={i2}")
+        assert_eq(r2, M.stage_rescale(po, want), f"answer() response idx={i2}")
+    srv.keep_cts(False)
+    srv.use_graphs(True)
+    for rep in range(2):
+        srv.set_query(q)
+        srv.run_query()
+        srv.sync()
+        assert_eq(srv.read(SV.BUF_ACC), acc, "run_query graph: accumulators")
+        assert_eq(srv.read(SV.BUF_FINAL), fin, "run_query graph: folded ciphertext")
+        assert_eq(srv.read(SV.BUF_RESPONSE), resp, "run_query graph: response")
+    srv.use_graphs(False)
+
+    # the same database uploaded in the reference's NTT layout (load_db), then ingested from raw plaintext bytes
+    assert_eq(srv.read_db_slots(5, 2).reshape(2, -1), db.reshape(N, -1)[5:7], "device-generated database, slots 5..6")
+    srv.load_db(db)
+    srv.set_query(q)
+    srv.expand()
+    srv.convert()
+    srv.first_dim()
+    assert_eq(srv.read(SV.BUF_ACC), acc, "accumulators from the uploaded database")
+    pts = np.stack([M.db_item(po, 1234, i) for i in range(s.dim0 * s.num_per)])  # 256 MiB of plaintext bytes at p = 256
+    srv.fill_db_random(1)  # make sure the ingest really rebuilds it
+    srv.load_db_items(M.pack_items(pts, 8), 8)
+    srv.first_dim()
+    assert_eq(srv.read(SV.BUF_ACC), acc, "accumulators from the database ingested from plaintext bytes")
+    srv.close()
+
+
+def sampled_checks(sa, M, po, pg, seed, idx, cl, label, n_slots=6, n_items=12):
+    """the size-independent checks for a database too large for a host-side reference: see the module docstring"""
+    from spiral_amd import server as SV
+
+    s = M.shape_of(po)
+    total = s.dim0 * s.num_per
+    wl, wr, w, v = cl.pub_params()
+    q = cl.query(idx)
+    srv = sa.Server(pg)
+    srv.keep_cts(True)
+    srv.gen_db(seed)
+    srv.set_pub_params(wl, wr, w, v)
+    fin, resp, us = srv.answer(q)
+    assert_eq(cl.decode(resp), M.db_item(po, seed, idx), f"{label}: decoded plaintext")
+    # database-independent stages in full
+    cv = M.stage_expand(po, q, wl, wr)
+    cts, gsw = M.stage_convert(po, cv, w, v)
+    assert_eq(srv.read(SV.BUF_EXPANDED), cv, f"{label}: expanded ciphertexts")
+    assert_eq(srv.read(SV.BUF_CTS), cts, f"{label}: scalToMat outputs")
+    assert_eq(srv.read(SV.BUF_GSW), gsw, f"{label}: regevToGSW outputs")
+    # sampled items of the device database == the oracle's encoding of the seeded plaintexts
+    rng = np.random.default_rng(seed)
+    for item in [0, total - 1, idx] + [int(x) for x in rng.integers(0, total, size=n_items)]:
+        assert_eq(srv.read_db_item(item), M.encode_item(po, M.db_item(po, seed, item)), f"{label}: database item {item}")
+    # the sweep on sampled slots: the oracle evaluates exactly those slots on the device's own database slabs
+    got_acc = srv.read(SV.BUF_ACC)
+    re = M.reorient_ciphertexts(cts)
+    zs = sorted({0, N - 1} | {int(x) for x in rng.integers(0, N, size=n_slots)})
+    slabs = np.concatenate([srv.read_db_slots(z, 1) for z in zs]).reshape(len(zs), -1)
+    want = M.multiply_query_by_database_slots(re[zs], slabs, s.dim0, s.num_per)
+    assert_eq(got_acc[..., zs], want, f"{label}: first-dimension accumulators on slots {zs}")
+    # and everything after the sweep from the device's full accumulators
+    raw = M.from_ntt(got_acc)
+    want_fin = M.stage_fold(po, raw, gsw)
+    assert_eq(fin, want_fin, f"{label}: folded ciphertext (from the device's accumulators)")
+    assert_eq(resp, M.stage_rescale(po, want_fin), f"{label}: response")
+    gbps = srv.sweep_bytes() / us["sweep_kernel_us"] / 1e3
+    print(f"{label}: stage us {({k: round(x) for k, x in us.items()})}, sweep {gbps:.0f} GB/s of algorithmic bytes = {gbps / 80:.1f} % of the 8 TB/s HBM peak")
+    srv.close()
+
+
+def test_config3_geometry_sampled_slots(sa, oracle_mt):
+    """configs[2]'s geometry on one MI355X: 2^24 x 256 B, nu1=9, nu2=10, t_GSW=10, q'=2^22, 32 GiB"""
+    M = oracle_mt
+    kw = dict(t_gsw=10, t_conv=4, t_exp=8, t_exp_right=56, qprime_bits=22, p_db=256)
+    po, pg = M.make_params(9, 10, **kw), sa.make_params(9, 10, **kw)
+    sampled_checks(sa, M, po, pg, 99, 424242 % (1 << 19), M.Client(po, seed=6), "config 3 geometry (32 GiB)")
+
+
+def test_configs3_spiralstream_2_20_x_100KB(sa, oracle_mt):
+    """configs[3]: SpiralStream (--direct-upload), 2^20 x 100 KB -- the published "Streaming 20/spiralstream" set
+    (all_parameter_choices.txt:1149-1163: nu1=11, nu2=9, p=32768, q'=27 bits, t_GSW=4, t_conv=56, t_exp=2; direct upload =
+    QNUMFIRST 2^nu1, QNUMREST t_GSW*nu2, src/spiral.cpp:2060-2061): 2048 + 36 uploaded ciphertexts, no expansion, one
+    64 GiB instance of the database on the device, the sweep HBM-bound"""
+    M = oracle_mt
+    kw = dict(t_gsw=4, t_conv=56, t_exp=2, t_exp_right=56, qprime_bits=27, p_db=32768, direct_upload=1)
+    po, pg = M.make_params(11, 9, **kw), sa.make_params(11, 9, **kw)
+    s = M.shape_of(po)
+    assert (s.n_query_cts, s.dim0, s.num_per) == (2048 + 36, 2048, 512)
+    sampled_checks(sa, M, po, pg, 777, 31337 % (1 << 20), M.Client(po, seed=4), "configs[3] SpiralStream 2^20 x 100KB (64 GiB)", n_slots=4, n_items=8)
+
+
+def test_config5_pack_bit_exact(sa, oracle_mt):
+    """configs[4]: SpiralPack 2^18 x 30 KB (all_parameter_choices.txt:610-624: nu1=10, nu2=8, n=4, p=256, q'=2^20, t_GSW=8,
+    t_conv=4, t_exp=16), 16 trial databases of 4 GiB"""
+    M = oracle_mt
+    kw = dict(t_gsw=8, t_conv=4, t_exp=16, t_exp_right=56, qprime_bits=20, p_db=256)
+    po, pg = M.make_params(10, 8, **kw), sa.make_params(10, 8, **kw)
+    out_n, seed = 4, 2024
+    s = M.pack_shape_of(po, out_n)
+    cl = M.PackClient(po, out_n, seed=12)
+    wl, wr, v, vw = cl.pub_params()
+    srv = sa.PackServer(pg, out_n)
+    srv.gen_db(seed)
+    srv.set_pub_params(wl, wr, v, vw)
+    idx = 123456 % (1 << 18)
+    q = cl.query(idx)
+    resp, packed, us = srv.answer(q)
+    assert_eq(cl.decode(resp), M.pack_db_item(po, out_n, seed, idx), "decoded items (config 5)")
+    # trial 0: the sweep accumulators against the oracle's sweep of that trial's 4 GiB database
+    cv = np.zeros((1 << s.g, 2, 2, N), dtype=np.uint64)
+    cv[0] = q.reshape(2, 2, N)
+    cv = M.expand_improved(cv, s.g, po.t_exp, wl, po.t_exp_right, wr, s.n_right, s.ell * po.nu2, s.stopround)
+    re = M.reorient_dim1(cv, s.dim0, 2)
+    db0 = M.pack_gen_db_trial(po, out_n, seed, 0)
+    assert_eq(srv.read_acc(0), M.sweep_dim1(db0, re, s.dim0, s.num_per), "config 5, trial 0: first-dimension accumulators")
+    del db0
+    if host_gib_available() > 160:  # all 16 trials (64 GiB of reference-layout database on the host)
+        db = np.empty((s.trials, s.dim0 * s.num_per * N), dtype=np.uint64)
+        for t in range(s.trials):
+            db[t] = M.pack_gen_db_trial(po, out_n, seed, t)
+        want_resp, want_packed = M.pack_answer(po, out_n, q, wl, wr, v, vw, db)
+        assert_eq(packed, want_packed, "config 5: packed ciphertext")
+        assert_eq(resp, want_resp, "config 5: response")
+        print(f"config 5: packed ciphertext and response bit-exact over all {s.trials} trials; sha256 response {sha(resp)}")
+    else:
+        print("config 5: < 160 GiB of host memory available, the all-trials comparison was skipped (trial 0 compared)")
+    srv.close()

@@ -1,6 +1,6 @@
 """GPU parity of the SpiralPack / SpiralStreamPack path (reference src/testing.cpp) against the oracle, through the
 C ABI: the two function seams, the resident server (packed ciphertext and response bit-exact, response decodes to
-the out_n x out_n items), and BASELINE.json config 5 at full size as a decode property."""
+the out_n x out_n items)).  BASELINE.json config 5 at full size: tests/test_gpu_fullsize.py."""
 import numpy as np
 import pytest
 
@@ -105,23 +105,26 @@ def test_pack_server_matches_oracle(sa, oracle, nu1, nu2, out_n, kw):
     srv2.close()
 
 
-@pytest.mark.slow
-def test_full_size_config5_pack(sa, oracle):
-    """BASELINE.json config 5: SpiralPack 2^18 x 30KB (all_parameter_choices.txt:610-624: nu1=10, nu2=8, n=4, p=256, q'=2^20,
-    t_GSW=8, t_conv=4, t_exp=16): 16 trial databases of 4 GiB each, generated on the device.  Property: decodes to the items."""
+def test_pack_raw_ingest(sa, oracle):
+    """raw ingest of the trial databases (1 x 1 plaintexts, src/testing.cpp:845-869 + convertDb :316-340 on the device):
+    same answers as the device-generated and as the uploaded database"""
     O = oracle
-    kw = dict(t_gsw=8, t_conv=4, t_exp=16, t_exp_right=56, qprime_bits=20, p_db=256)
-    po, pg = O.make_params(10, 8, **kw), sa.make_params(10, 8, **kw)
-    out_n = 4
-    cl = O.PackClient(po, out_n, seed=12)
+    kw = dict(t_gsw=4)
+    nu1, nu2, out_n = 5, 2, 2
+    po, pg = O.make_params(nu1, nu2, **kw), sa.make_params(nu1, nu2, **kw)
+    s = O.pack_shape_of(po, out_n)
+    total = s.dim0 * s.num_per
+    cl = O.PackClient(po, out_n, seed=8)
     wl, wr, v, vw = cl.pub_params()
+    db = O.pack_gen_db(po, out_n, 31)
     srv = sa.PackServer(pg, out_n)
-    srv.gen_db(2024)
+    all_pts = np.stack([O.pack_db_item(po, out_n, 31, i).reshape(s.trials, N) for i in range(total)])  # [item][trial][N]
+    for t in range(s.trials):
+        srv.load_db_items(t, O.pack_items(all_pts[:, t], 8), 8)
     srv.set_pub_params(wl, wr, v, vw)
-    idx = 123456 % (1 << 18)
-    resp, _, us = srv.answer(cl.query(idx), want_packed=False)
-    resp, _, us = srv.answer(cl.query(idx), want_packed=False)
-    assert_eq(cl.decode(resp), O.pack_db_item(po, out_n, 2024, idx), "decoded items (config 5)")
-    gbps = 16 * srv.sweep_bytes() / us["sweep_kernels_us"] / 1e3
-    print("config 5 stage us:", {k: round(x) for k, x in us.items()}, "sweep GB/s:", round(gbps))
+    q = cl.query(total - 1)
+    resp, packed, _ = srv.answer(q)
+    want_resp, want_packed = O.pack_answer(po, out_n, q, wl, wr, v, vw, db)
+    assert_eq(packed, want_packed, "packed ciphertext from the ingested database")
+    assert_eq(resp, want_resp, "response from the ingested database")
     srv.close()

@@ -452,23 +452,6 @@ def test_distributed_fold_emulated_on_one_gpu(sa, oracle, G, graphs):
 
 
 @pytest.mark.slow
-def test_full_size_config2_end_to_end(sa, oracle):
-    """BASELINE.json config 2 (nu1=8, nu2=7, 2^20 x 256 B): size-independent property -- the response decodes
-    to the database item (the reference's Is correct?), database generated on the device."""
-    O = oracle
-    po, pg = O.make_params(8, 7), sa.make_params(8, 7)
-    cl = O.Client(po, seed=1)
-    wl, wr, w, v = cl.pub_params()
-    srv = sa.Server(pg)
-    srv.gen_db(1234)
-    srv.set_pub_params(wl, wr, w, v)
-    for idx in (1234, (1 << 15) - 1):
-        fin, resp, us = srv.answer(cl.query(idx))
-        assert_eq(cl.decode(resp), O.db_item(po, 1234, idx), "decoded plaintext at full size")
-    srv.close()
-
-
-@pytest.mark.slow
 def test_full_size_stream_direct_upload(sa, oracle):
     """SpiralStream-style direct upload at the published "(20, 256)/spiralstream" parameters
     (all_parameter_choices.txt:82-97: nu1=9, nu2=6, p=256, q'=2^19, t_GSW=5, t_conv=4): 512 + 30 uploaded
@@ -487,20 +470,54 @@ def test_full_size_stream_direct_upload(sa, oracle):
     srv.close()
 
 
-@pytest.mark.slow
-def test_full_size_config3_on_one_gpu(sa, oracle):
-    """BASELINE.json config 3 geometry (2^24 x 256 B: nu1=9, nu2=10, t_GSW=10, q'=2^22) held on ONE
-    MI355X: 32 GiB NTT-form database generated on the device.  Property: the response decodes to the item."""
+@pytest.mark.parametrize("nu1,nu2,p_db,bits", [(3, 5, 256, 8), (4, 2, 32768, 15), (3, 3, 512, 9), (2, 1, 256, 64), (4, 4, 1 << 20, 20)])
+def test_raw_ingest_matches_load_db(sa, oracle, nu1, nu2, p_db, bits, monkeypatch):
+    """plaintext coefficients in (bit-packed, the item size of select_params.py:297), device database out --
+    the centred lift, the transforms and the layout of load_db (src/spiral.cpp:1083-1171) on the device.  Must give the
+    database the reference's load_db builds: compared through read_db_slots / read_db_item and through the accumulators.
+    Several staging passes, a sharded server fed the whole stream, and an out-of-range coefficient are covered."""
     O = oracle
-    kw = dict(t_gsw=10, t_conv=4, t_exp=8, t_exp_right=56, qprime_bits=22, p_db=256)
-    po, pg = O.make_params(9, 10, **kw), sa.make_params(9, 10, **kw)
-    cl = O.Client(po, seed=6)
-    wl, wr, w, v = cl.pub_params()
+    from spiral_amd import server as SV
+
+    kw = dict(t_gsw=8, p_db=p_db, qprime_bits=27 if p_db > 4096 else 20)
+    po, pg = O.make_params(nu1, nu2, **kw), sa.make_params(nu1, nu2, **kw)
+    s = O.shape_of(po)
+    total = s.dim0 * s.num_per
+    pts = np.stack([O.db_item(po, 41, i) for i in range(total)])
+    pts[0, 0, 0, :4] = [0, p_db - 1, p_db // 2, p_db // 2 - 1]  # both sides of the centring threshold
+    db = np.zeros(O.db_words(po), dtype=np.uint64).reshape(N, s.num_per, 2, s.dim0, 2)
+    for i in range(total):
+        enc = O.encode_item(po, pts[i])  # [m][c][limb][z]
+        db[:, i % s.num_per, :, i // s.num_per, :] = (enc[:, :, 0, :] | (enc[:, :, 1, :] << np.uint64(32))).transpose(2, 1, 0)
+    items = O.pack_items(pts, bits)
+    assert items.nbytes == total * 4 * N * bits // 8
+    monkeypatch.setenv("SPIRAL_DB_STAGE_BYTES", str(5 * 4 * N * bits // 8))  # 5 items per staging pass
     srv = sa.Server(pg)
-    srv.gen_db(99)
+    srv.load_db_items(items, bits)
+    assert_eq(srv.read_db_slots(0, N), db, "ingested database == load_db's")
+    for i in (0, total - 1, total // 2 + 1):
+        assert_eq(srv.read_db_item(i), O.encode_item(po, pts[i]), f"item {i}")
+    cl = O.Client(po, seed=3)
+    wl, wr, w, v = cl.pub_params()
     srv.set_pub_params(wl, wr, w, v)
-    idx = 424242 % (1 << 19)
-    fin, resp, us = srv.answer(cl.query(idx))
-    assert_eq(cl.decode(resp), O.db_item(po, 99, idx), "decoded plaintext (config 3, 32 GiB)")
-    print("config 3 on one GPU, stage us:", {k: round(x) for k, x in us.items()}, "sweep GB/s:", round(srv.sweep_bytes() / us["sweep_kernel_us"] / 1e3))
+    q = cl.query(total - 2)
+    fin, resp, _ = srv.answer(q)
+    assert_eq(fin, O.answer(po, q, wl, wr, w, v, db.reshape(-1)), "answer from the ingested database")
+    if p_db <= 512:  # (the larger plaintext moduli are bit-exact too but these toy parameter sets are too noisy to decode them)
+        assert_eq(cl.decode(resp), pts[total - 2], "decoded plaintext")
+    # a second server on the upper half of the first dimension, fed the whole stream in two calls: keeps its own items
+    half = sa.Server(pg, 0, s.dim0 // 2, s.dim0)
+    cut = total // 3
+    item_bytes = 4 * N * bits // 8
+    half.load_db_items(items[:cut * item_bytes], bits, 0, cut)
+    half.load_db_items(items[cut * item_bytes:], bits, cut, total - cut)
+    assert_eq(half.read_db_slots(3, 2), db[3:5, :, :, s.dim0 // 2:, :], "sharded ingest")
+    with pytest.raises(sa.SpiralGpuError):
+        half.read_db_item(0)  # not in this shard
+    if bits != 64 and (1 << bits) > p_db or bits == 64:
+        bad = pts.copy()
+        bad[1, 1, 1, 7] = p_db  # the reference asserts val < p_db (src/spiral.cpp:1117)
+        with pytest.raises(sa.SpiralGpuError):
+            srv.load_db_items(O.pack_items(bad, bits), bits)
     srv.close()
+    half.close()

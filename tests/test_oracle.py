@@ -178,3 +178,38 @@ def test_staged_pipeline_equals_answer(oracle):
     raw = O.stage_first_dim(p, cts, db)
     fin = O.stage_fold(p, raw, gsw)
     assert (fin == O.answer(p, q, wl, wr, w, v, db)).all()
+
+
+def test_threaded_native_build_gives_identical_results(oracle, oracle_mt):
+    """the -fopenmp -march=native build on many threads (full-size parity tests, bench.py's all-cores baseline) must be
+    the same function as the default single-threaded build: base path with expansion + stopround, and the pack path"""
+    O, M = oracle, oracle_mt
+    assert M.n_threads >= 1
+    kw = dict(t_gsw=4)
+    po = O.make_params(4, 3, **kw)
+    cl = O.Client(po, seed=12)
+    wl, wr, w, v = cl.pub_params()
+    q = cl.query(77)
+    db = O.gen_db(po, 5)
+    assert np.array_equal(M.gen_db(M.make_params(4, 3, **kw), 5), db)
+    assert np.array_equal(M.answer(M.make_params(4, 3, **kw), q, wl, wr, w, v, db), O.answer(po, q, wl, wr, w, v, db))
+    pk = dict(t_gsw=4)
+    pp = O.make_params(5, 2, **pk)
+    pc = O.PackClient(pp, 2, seed=3)
+    pwl, pwr, pv, pvw = pc.pub_params()
+    pq = pc.query(9)
+    pdb = O.pack_gen_db(pp, 2, 31)
+    assert np.array_equal(M.pack_gen_db(M.make_params(5, 2, **pk), 2, 31), pdb)
+    r0, f0 = O.pack_answer(pp, 2, pq, pwl, pwr, pv, pvw, pdb)
+    r1, f1 = M.pack_answer(M.make_params(5, 2, **pk), 2, pq, pwl, pwr, pv, pvw, pdb)
+    assert np.array_equal(r0, r1) and np.array_equal(f0, f1)
+    # the slot-subset sweep is the full sweep restricted to those slots
+    rng = np.random.default_rng(3)
+    dim0, num_per = 8, 4
+    cts = np.stack([rng.integers(0, m, size=(dim0, 3, 2, O.N), dtype=np.uint64) for m in (O.P, O.B)], axis=-2)
+    re = O.reorient_ciphertexts(cts)
+    dbr = O.fill_db_random(1, dim0 * num_per * 4 * O.N)
+    full = O.multiply_query_by_database(re, dbr, dim0, num_per)
+    zs = [0, 5, 2047, 1024]
+    sub = O.multiply_query_by_database_slots(re[zs], dbr.reshape(O.N, -1)[zs], dim0, num_per)
+    assert np.array_equal(sub, full[..., zs])
