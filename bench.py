@@ -94,10 +94,21 @@ def cpu_baseline(params_kw, np, workload):
            "build": "gcc -O3 -march=native -fopenmp on this box" if native else "prebuilt gcc -O3 -march=x86-64-v3",
            "sample": f"1 full query of {workload} ({O.db_words(po) * 8 / 2**30:.0f} GiB NTT-form database of arbitrary valid words), oracle/ restatement"}
     if native:
+        # all cores: this restatement (per-call scratch allocation like the reference's MatPoly, many small parallel regions)
+        # stops scaling well before a 2 x 64-core box is full, so the thread count is swept and the best one reported
         ncpu = os.cpu_count() or 1
-        timed(ncpu)  # thread pool start-up
-        got, msn = timed(ncpu)
-        out["all_cores"] = {"value": round(msn, 1), "unit": "ms/query", "cores": got, "logical_cpus": ncpu}
+        O.set_threads(min(ncpu, 16))
+        db = O.fill_db_random(99, O.db_words(po))  # first touch spread over the threads' NUMA nodes
+        timed(min(ncpu, 16))  # thread pool start-up
+        ladder, best = {}, None
+        for th in sorted({t for t in (8, 16, 32, 64, 128, ncpu) if t <= ncpu}):
+            got, ms = timed(th)
+            ladder[str(got)] = round(ms, 1)
+            if best is None or ms < best[1]:
+                best = (got, ms)
+            elif ms > 3 * best[1]:
+                break
+        out["all_cores"] = {"value": round(best[1], 1), "unit": "ms/query", "cores": best[0], "logical_cpus": ncpu, "ms_by_threads": ladder}
     shutil.rmtree(d, ignore_errors=True)
     return out
 

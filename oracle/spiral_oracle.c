@@ -26,6 +26,7 @@ typedef unsigned __int128 u128;
  * load) has no -fopenmp, so the pragmas are ignored there; the `native` target adds -fopenmp -march=native and
  * orc_set_threads(n) turns them on.  The reference itself is single-threaded (src/spiral.cpp:1231). */
 #ifdef _OPENMP
+#include <malloc.h>
 #include <omp.h>
 #endif
 static int g_threads = 1;
@@ -34,6 +35,11 @@ int orc_get_threads(void) { return g_threads; }
 int orc_set_threads(int n) {
     build_tables(); /* lazily built otherwise: not from inside a parallel region */
 #ifdef _OPENMP
+    /* the restated functions malloc their scratch per call like the reference's MatPoly does (include/poly.h:32-58); above
+     * glibc's mmap threshold every such block is an mmap / munmap pair, and hundreds of threads doing that serialise on the
+     * address-space lock: keep those blocks in the per-thread arenas */
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
     g_threads = n < 1 ? 1 : n;
     omp_set_num_threads(g_threads);
     return g_threads;
@@ -831,6 +837,7 @@ void orc_gen_db(const orc_params *p, uint64_t seed, uint64_t *db) {
 }
 
 void orc_fill_db_random(uint64_t seed, uint64_t *db, size_t nwords) {
+#pragma omp parallel for if (g_threads > 1)
     for (size_t i = 0; i < nwords; i++) {
         uint64_t r = splitmix64(seed + i);
         db[i] = ((r & 0xffffffffull) % ORC_P) | (((r >> 32) % ORC_B) << 32);

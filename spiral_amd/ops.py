@@ -16,7 +16,7 @@ Q = P * B
 __all__ = [
     "N", "P", "B", "Q", "make_params", "get_shape", "get_tables", "ntt_forward", "ntt_inverse", "to_ntt", "to_ntt_no_reduce", "from_ntt",
     "multiply", "add", "mul_by_const", "automorph", "invert", "gadget_invert", "getRescaled", "multiplyQueryByDatabase", "split_and_crt",
-    "foldOneFurtherDimension", "expandImproved", "scalToMat", "regevToGSW",
+    "foldOneFurtherDimension", "expandImproved", "scalToMat", "regevToGSW", "time_ntt",
 ]
 
 

@@ -39,5 +39,5 @@ def oracle_mt(tmp_path_factory):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.LIB_PATH = os.path.join(str(d), "liboracle_native.so")
-    mod.n_threads = mod.set_threads(max(1, min(os.cpu_count() or 1, 96)))
+    mod.n_threads = mod.set_threads(max(1, min(os.cpu_count() or 1, 32)))  # (scaling of this code peaks at 16-32 threads)
     return mod

@@ -1,0 +1,26 @@
+import sys, time, os
+"""per-stage time of the oracle's threaded native build on this machine: tools/cpu_oracle_scaling.py 1 16 64 128 ..."""
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import shutil, subprocess, tempfile
+import numpy as np
+from oracle import pyoracle as O
+d = tempfile.mkdtemp(prefix="onat_")
+for f in ("spiral_oracle.c", "spiral_oracle_pack.c", "spiral_oracle.h", "Makefile"):
+    shutil.copy(os.path.join(ROOT, "oracle", f), d)
+subprocess.check_call(["make", "-C", d, "-s", "native"])
+O.LIB_PATH = os.path.join(d, "liboracle_native.so")
+po = O.make_params(8, 7); s = O.shape_of(po)
+rng = np.random.default_rng(7)
+db = O.fill_db_random(99, O.db_words(po))
+mk = lambda shape: np.ascontiguousarray(np.stack([rng.integers(0, m, size=shape + (O.N,), dtype=np.uint64) for m in (O.P, O.B)], axis=-2))
+wl, wr = mk((s.n_left, 2, po.t_exp)), mk((s.n_right, 2, po.t_exp_right))
+w, v = mk((3, 8)), mk((3, 8)); q = mk((1, 2))
+for th in [int(x) for x in sys.argv[1:]]:
+    O.set_threads(th)
+    for stage in range(1):
+        t0 = time.perf_counter(); cv = O.stage_expand(po, q, wl, wr); t1 = time.perf_counter()
+        cts, gsw = O.stage_convert(po, cv, w, v); t2 = time.perf_counter()
+        raw = O.stage_first_dim(po, cts, db); t3 = time.perf_counter()
+        fin = O.stage_fold(po, raw, gsw); t4 = time.perf_counter()
+    print(th, "threads: expand %.0f convert %.0f first_dim %.0f fold %.0f total %.0f ms" % ((t1-t0)*1e3, (t2-t1)*1e3, (t3-t2)*1e3, (t4-t3)*1e3, (t4-t0)*1e3))
