@@ -1,5 +1,7 @@
 // Batched NTT / INTT kernels with fused pre- and post-operations, gfx950.
 // One 256-thread workgroup per output polynomial.  See ntt_device.h for the transform itself.
+#include <type_traits>
+
 #include "kernels.h"
 #include "ntt_device.h"
 
@@ -27,8 +29,23 @@ __device__ __forceinline__ uint64_t digit_of(uint64_t v, uint32_t k, uint32_t bi
 }
 
 // a gadget digit is < 2^bits <= 2^32 (bits = 32 only through the to_ntt_no_reduce seam, whose contract is
-// values < 2^29); the forward transform wants its inputs below 2m
-__device__ __forceinline__ uint32_t digit_residue(uint32_t d, uint32_t m) { return d < (1u << 28) ? d : d % m; }
+// values < 2^29); the forward transform wants its inputs below 2m.
+// SMALL: the digit width is at most 27 bits -- every published parameter set (bits = floor(56/t) + 1 <= 15 for t >= 4; 29 only
+// for t = 2) -- so a digit, and a balanced piece <= 2^bits, is already below 2^28 < 2m and needs no reduction.  The loaders
+// branch on that once per workgroup (it is a launch parameter) instead of carrying a compare + remainder per coefficient.
+template <bool SMALL>
+__device__ __forceinline__ uint32_t digit_residue(uint32_t d, uint32_t m) {
+    if constexpr (SMALL) return d;
+    return d < (1u << 28) ? d : d % m;
+}
+constexpr uint32_t kSmallDigitBits = 27;
+#define DIGIT_WIDTH_DISPATCH(bits, body) \
+    do {                                 \
+        if ((bits) <= kSmallDigitBits)   \
+            body(std::true_type{});      \
+        else                             \
+            body(std::false_type{});     \
+    } while (0)
 
 // balanced digit k of v under split_and_crt's two carry chains (src/spiral.cpp:283-292, 313-322): digits 0..ell/2-1 and
 // ell/2..ell-1 each propagate a carry (piece > 2^bits/2 borrows 2^bits from the next digit), the first chain's last digit
@@ -58,17 +75,26 @@ __device__ __forceinline__ SDigit sdigit_setup(uint32_t k, uint32_t bits, uint32
     return d;
 }
 // returned as residues (mod p, mod b); a borrowed digit is piece + Q - 2^bits == piece - 2^bits (mod m)
+template <bool SMALL>
 __device__ __forceinline__ void sdigit_of(uint64_t v, const SDigit& d, uint32_t& rp, uint32_t& rb) {
     const uint64_t dig = d.sh_digit >= 64 ? 0ull : ((v >> d.sh_digit) & d.mask);  // shift counts >= 64: 0, as digit_of
     const uint64_t low = d.sh_chain >= 64 ? 0ull : ((v >> d.sh_chain) & d.low_mask);
-    const uint64_t piece = dig + ((d.has_in && low > d.thresh_in) ? 1u : 0u);
-    if (piece > d.thresh && d.may) {
-        const uint32_t x = (uint32_t)(d.base - piece);  // in [0, 2^bits/2)
-        rp = kP - x;
-        rb = kB - x;
+    if constexpr (SMALL) {  // everything fits 32 bits and both outcomes are cheap: select instead of branching
+        const uint32_t piece = (uint32_t)dig + ((d.has_in && low > d.thresh_in) ? 1u : 0u);
+        const uint32_t x = (uint32_t)d.base - piece;  // in [0, 2^bits/2) when borrowed
+        const bool borrow = piece > (uint32_t)d.thresh && d.may;
+        rp = borrow ? kP - x : piece;
+        rb = borrow ? kB - x : piece;
     } else {
-        rp = digit_residue((uint32_t)piece, kP);
-        rb = digit_residue((uint32_t)piece, kB);
+        const uint64_t piece = dig + ((d.has_in && low > d.thresh_in) ? 1u : 0u);
+        if (piece > d.thresh && d.may) {
+            const uint32_t x = (uint32_t)(d.base - piece);  // in [0, 2^bits/2)
+            rp = kP - x;
+            rb = kB - x;
+        } else {
+            rp = digit_residue<false>((uint32_t)piece, kP);
+            rb = digit_residue<false>((uint32_t)piece, kB);
+        }
     }
 }
 
@@ -135,12 +161,15 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
         }
         const uint64_t* src = p.src + (size_t)sp * kN;
         const uint64_t mask = (1ull << p.bits) - 1;
+        auto body = [&](auto small) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            uint32_t d = (uint32_t)digit_of(src[ix_a(tid, r)], k, p.bits, mask);
-            lo[r] = digit_residue(d, kP);
-            hi[r] = digit_residue(d, kB);
-        }
+            for (int r = 0; r < 8; r++) {
+                uint32_t d = (uint32_t)digit_of(src[ix_a(tid, r)], k, p.bits, mask);
+                lo[r] = digit_residue<decltype(small)::value>(d, kP);
+                hi[r] = digit_residue<decltype(small)::value>(d, kB);
+            }
+        };
+        DIGIT_WIDTH_DISPATCH(p.bits, body);
     } else if constexpr (LOAD == LD_EXPAND) {
         // job b -> (active ct a, digit k of automorph(c)[0])
         const uint32_t je = p.cnt_e * p.t_e;
@@ -159,12 +188,15 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
         const uint64_t* src = p.src + (size_t)a * 2u * kN;
         const uint32_t bits = get_bits_per(tdim);
         const uint64_t mask = (1ull << bits) - 1;
+        auto body = [&](auto small) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const uint32_t d = (uint32_t)digit_of(src[ix_a(tid, r)], k, bits, mask);  // already automorphed by the inverse pass
-            lo[r] = digit_residue(d, kP);
-            hi[r] = digit_residue(d, kB);
-        }
+            for (int r = 0; r < 8; r++) {
+                const uint32_t d = (uint32_t)digit_of(src[ix_a(tid, r)], k, bits, mask);  // already automorphed by the inverse pass
+                lo[r] = digit_residue<decltype(small)::value>(d, kP);
+                hi[r] = digit_residue<decltype(small)::value>(d, kB);
+            }
+        };
+        DIGIT_WIDTH_DISPATCH(bits, body);
         s = b;
     } else if constexpr (LOAD == LD_LIMBS) {
         const uint64_t* src = p.src + (size_t)p.src_map(s) * (2 * kN);
@@ -179,21 +211,27 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
         const uint64_t mask = (1ull << p.bits) - 1;
         SDigit sd{};
         if constexpr (LOAD == LD_SDIGIT) sd = sdigit_setup(k, p.bits, p.ell);
+        auto body = [&](auto small) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            uint32_t idx = ix_a(tid, r);
-            uint64_t v = load_raw(src, idx, p.tinv);
-            if constexpr (LOAD == LD_RAW) {
-                lo[r] = mod_p(v);
-                hi[r] = mod_b(v);
-            } else if constexpr (LOAD == LD_DIGIT) {
-                uint32_t d = (uint32_t)digit_of(v, k, p.bits, mask);
-                lo[r] = digit_residue(d, kP);
-                hi[r] = digit_residue(d, kB);
-            } else {
-                sdigit_of(v, sd, lo[r], hi[r]);
+            for (int r = 0; r < 8; r++) {
+                uint32_t idx = ix_a(tid, r);
+                uint64_t v = load_raw(src, idx, p.tinv);
+                if constexpr (LOAD == LD_RAW) {
+                    lo[r] = mod_p(v);
+                    hi[r] = mod_b(v);
+                } else if constexpr (LOAD == LD_DIGIT) {
+                    uint32_t d = (uint32_t)digit_of(v, k, p.bits, mask);
+                    lo[r] = digit_residue<decltype(small)::value>(d, kP);
+                    hi[r] = digit_residue<decltype(small)::value>(d, kB);
+                } else {
+                    sdigit_of<decltype(small)::value>(v, sd, lo[r], hi[r]);
+                }
             }
-        }
+        };
+        if constexpr (LOAD == LD_RAW)
+            body(std::false_type{});
+        else
+            DIGIT_WIDTH_DISPATCH(p.bits, body);
     }
 
     ntt_forward_block(lo, hi, sh, t.fwd, tid);
@@ -401,18 +439,21 @@ __global__ __launch_bounds__(256) void fold_chain_kernel(Tables t, FoldChainPara
     const uint32_t phh = pip / p.fold_np, pi = pip - phh * p.fold_np;
     const uint64_t mask = (1ull << p.bits) - 1;
     for (uint32_t k = k0; k < k1; k++) {
-        if (p.pack) {  // unsigned digits (src/testing.cpp:596-624), operand layout D[t][i' % np][(i' / np)*2ell + row + 2k]
+        auto digits = [&](auto small) {
+            if (p.pack) {  // unsigned digits (src/testing.cpp:596-624), operand layout D[t][i' % np][(i' / np)*2ell + row + 2k]
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const uint32_t d = (uint32_t)digit_of(v[r], k, p.bits, mask);
-                lo[r] = digit_residue(d, kP);
-                hi[r] = digit_residue(d, kB);
+                for (int r = 0; r < 8; r++) {
+                    const uint32_t d = (uint32_t)digit_of(v[r], k, p.bits, mask);
+                    lo[r] = digit_residue<decltype(small)::value>(d, kP);
+                    hi[r] = digit_residue<decltype(small)::value>(d, kB);
+                }
+            } else {
+                const SDigit sd = sdigit_setup(k, p.bits, p.ell);
+#pragma unroll
+                for (int r = 0; r < 8; r++) sdigit_of<decltype(small)::value>(v[r], sd, lo[r], hi[r]);
             }
-        } else {
-            const SDigit sd = sdigit_setup(k, p.bits, p.ell);
-#pragma unroll
-            for (int r = 0; r < 8; r++) sdigit_of(v[r], sd, lo[r], hi[r]);
-        }
+        };
+        DIGIT_WIDTH_DISPATCH(p.bits, digits);
         if (k > k0) __syncthreads();  // the previous transform's last LDS reads
         ntt_forward_block(lo, hi, sh, t.fwd, tid);
         const size_t di = p.pack ? (size_t)(((pt * p.fold_np + pi) * 2u + phh) * (2u * p.ell) + 2u * k + prow)

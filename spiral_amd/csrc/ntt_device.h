@@ -7,6 +7,10 @@
 // 8 coefficients x 2 limbs in VGPRs and runs three radix-2 stages per pass with lazy u32 Harvey
 // butterflies; passes exchange data through a 16 KiB LDS tile (3 exchanges for 11 stages).
 // Outputs are canonical residues in [0, m).
+// (Round 2 measured the alternative with 16 coefficients per thread -- 128 threads per polynomial, passes of 4 + 4 + 3 stages,
+// two LDS exchanges instead of three, tools/ntt16_core.h: 4.5 % fewer VALU instructions per polynomial, but 114 VGPRs (4 waves
+// per SIMD instead of 8) and twice the serial work per thread: 9 % slower on wide batches (9.6 vs 8.8 ns per transform on the
+// same box) and +2 us per launch in the latency-bound narrow rounds.  This 8-coefficient form stays.)
 #pragma once
 #include "common.h"
 #ifndef TWI
@@ -37,6 +41,8 @@ __device__ __forceinline__ uint32_t shoup(uint32_t y, uint32_t w, uint32_t ws, u
 }
 // [0, 14m] -> [0, 2m): x - floor(x / 2^28) * m  (m > 0.9296 * 2^28, so the quotient is off by at most one)
 __device__ __forceinline__ uint32_t lazy_reduce(uint32_t x, uint32_t m) { return x - (x >> 28) * m; }
+// [0, 2m) -> [0, m) without a compare / select pair: x - m wraps to a huge value exactly when x < m
+__device__ __forceinline__ uint32_t csub_min(uint32_t x, uint32_t m) { return min(x, x - m); }
 // forward (Cooley-Tukey): bound grows by 2m per stage
 __device__ __forceinline__ void ct_bfly(uint32_t& x, uint32_t& y, uint32_t w, uint32_t ws, uint32_t m) {
 #ifdef NTT_ABLATE_ALU
@@ -293,8 +299,8 @@ __device__ __forceinline__ void ntt_forward_block(uint32_t* lo, uint32_t* hi, ui
 #endif
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        lo[k] = csub(lazy_reduce(lo[k], kP), kP);
-        hi[k] = csub(lazy_reduce(hi[k], kB), kB);
+        lo[k] = csub_min(lazy_reduce(lo[k], kP), kP);
+        hi[k] = csub_min(lazy_reduce(hi[k], kB), kB);
     }
 }
 
@@ -322,8 +328,8 @@ __device__ __forceinline__ void ntt_inverse_block(uint32_t* lo, uint32_t* hi, ui
     gs_radix8_pre(lo, hi, wa);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        lo[k] = csub(lazy_reduce(lo[k], kP), kP);
-        hi[k] = csub(lazy_reduce(hi[k], kB), kB);
+        lo[k] = csub_min(lazy_reduce(lo[k], kP), kP);
+        hi[k] = csub_min(lazy_reduce(hi[k], kB), kB);
     }
     return;
 #endif
@@ -344,8 +350,8 @@ __device__ __forceinline__ void ntt_inverse_block(uint32_t* lo, uint32_t* hi, ui
     gs_radix8(lo, hi, tw, 1, 2, 4);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        lo[k] = csub(lazy_reduce(lo[k], kP), kP);
-        hi[k] = csub(lazy_reduce(hi[k], kB), kB);
+        lo[k] = csub_min(lazy_reduce(lo[k], kP), kP);
+        hi[k] = csub_min(lazy_reduce(hi[k], kB), kB);
     }
 }
 

@@ -13,7 +13,7 @@ enum Op : int {
     FMA_F64, MUL_F64, ADD_F64, RNDNE_F64, FLOOR_F64, CVT_F64_U32, CVT_U32_F64,
     FMA_F32, PK_FMA_F32, PK_MUL_LO_U16, PK_MAD_U16, DOT4_U32_U8,
     DPP_QUAD, DPP_ROW_SHR, DPP_ROW_ROR, DPP_ROW_MIRROR, DPP_BCAST15, PERMLANE32_SWAP, PERMLANE16_SWAP, DS_BPERMUTE, DS_SWIZZLE,
-    DS_WRITE_B64, DS_READ_B64, DS_WRITE_B128, DS_READ_B128, N_OPS
+    DS_WRITE_B64, DS_READ_B64, DS_WRITE_B128, DS_READ_B128, DEP_ADD, DEP_MUL_LO, DEP_MAD_U64, DEP_SHOUP, DEP2_SHOUP, DEP4_SHOUP, N_OPS
 };
 
 template <int OP>
@@ -209,6 +209,37 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, uint32_t seed) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else if constexpr (OP == DS_WRITE_B128) {
             asm volatile("ds_write_b128 %0, %1\n ds_write_b128 %0, %2\n ds_write_b128 %0, %1\n ds_write_b128 %0, %2\n ds_write_b128 %0, %1\n ds_write_b128 %0, %2\n ds_write_b128 %0, %1\n ds_write_b128 %0, %2\n s_waitcnt lgkmcnt(0)" : : "v"(lds_addr16), "v"(q0), "v"(q1) : "memory");
+        } else if constexpr (OP == DEP_ADD) {  // ONE dependent chain: cycles per instruction = issue-to-issue latency of dependent VALU
+#define X(r) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a0) : "v"(b));
+            ALL8(X)
+#undef X
+        } else if constexpr (OP == DEP_MUL_LO) {
+#define X(r) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a0) : "v"(b));
+            ALL8(X)
+#undef X
+        } else if constexpr (OP == DEP_MAD_U64) {
+#define X(r, s) asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %2, %0" : "+v"(w0) : "v"(a0), "v"(b) : "s20", "s21");
+            ALLW(X)
+#undef X
+        } else if constexpr (OP == DEP_SHOUP) {  // the butterfly's dependent chain: mul_lo + mul_hi -> mad -> add / sub -> add (6 instructions), one butterfly at a time
+#define X(x, y) asm volatile("v_mul_lo_u32 v100, %2, %1\n v_mul_hi_u32 v101, %3, %1\n v_mad_u64_u32 v[100:101], s[20:21], v101, %4, v[100:101]\n v_add_u32 %0, v100, %0\n v_sub_u32 %1, %0, v100\n v_add_u32 %1, %5, %1" : "+v"(x), "+v"(y) : "v"(b), "v"(c), "v"(a7), "v"(a6) : "v100", "v101", "s20", "s21");
+            X(a0, a1) X(a0, a1) X(a0, a1) X(a0, a1) X(a0, a1) X(a0, a1) X(a0, a1) X(a0, a1)
+#undef X
+        } else if constexpr (OP == DEP2_SHOUP) {  // two butterflies interleaved instruction by instruction
+#define X(x, y, u, v) asm volatile("v_mul_lo_u32 v100, %4, %1\n v_mul_lo_u32 v102, %4, %3\n v_mul_hi_u32 v101, %5, %1\n v_mul_hi_u32 v103, %5, %3\n v_mad_u64_u32 v[100:101], s[20:21], v101, %6, v[100:101]\n v_mad_u64_u32 v[102:103], s[20:21], v103, %6, v[102:103]\n v_add_u32 %0, v100, %0\n v_add_u32 %2, v102, %2\n v_sub_u32 %1, %0, v100\n v_sub_u32 %3, %2, v102\n v_add_u32 %1, %7, %1\n v_add_u32 %3, %7, %3" : "+v"(x), "+v"(y), "+v"(u), "+v"(v) : "v"(b), "v"(c), "v"(a7), "v"(a6) : "v100", "v101", "v102", "v103", "s20", "s21");
+            X(a0, a1, a2, a3) X(a0, a1, a2, a3) X(a0, a1, a2, a3) X(a0, a1, a2, a3)
+#undef X
+        } else if constexpr (OP == DEP4_SHOUP) {  // four butterflies interleaved
+#define X(x0, y0, x1, y1, x2, y2, x3, y3) asm volatile( \
+    "v_mul_lo_u32 v100, %8, %1\n v_mul_lo_u32 v102, %8, %3\n v_mul_lo_u32 v104, %8, %5\n v_mul_lo_u32 v106, %8, %7\n" \
+    "v_mul_hi_u32 v101, %9, %1\n v_mul_hi_u32 v103, %9, %3\n v_mul_hi_u32 v105, %9, %5\n v_mul_hi_u32 v107, %9, %7\n" \
+    "v_mad_u64_u32 v[100:101], s[20:21], v101, %10, v[100:101]\n v_mad_u64_u32 v[102:103], s[20:21], v103, %10, v[102:103]\n v_mad_u64_u32 v[104:105], s[20:21], v105, %10, v[104:105]\n v_mad_u64_u32 v[106:107], s[20:21], v107, %10, v[106:107]\n" \
+    "v_add_u32 %0, v100, %0\n v_add_u32 %2, v102, %2\n v_add_u32 %4, v104, %4\n v_add_u32 %6, v106, %6\n" \
+    "v_sub_u32 %1, %0, v100\n v_sub_u32 %3, %2, v102\n v_sub_u32 %5, %4, v104\n v_sub_u32 %7, %6, v106\n" \
+    "v_add_u32 %1, %11, %1\n v_add_u32 %3, %11, %3\n v_add_u32 %5, %11, %5\n v_add_u32 %7, %11, %7" \
+    : "+v"(x0), "+v"(y0), "+v"(x1), "+v"(y1), "+v"(x2), "+v"(y2), "+v"(x3), "+v"(y3) : "v"(b), "v"(c), "v"(f0), "v"(f1) : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "s20", "s21");
+            X(a0, a1, a2, a3, a4, a5, a6, a7) X(a0, a1, a2, a3, a4, a5, a6, a7)
+#undef X
         } else if constexpr (OP == DS_READ_B128) {
             u32x4 t0, t1;
             asm volatile("ds_read_b128 %0, %2\n ds_read_b128 %1, %2\n ds_read_b128 %0, %2\n ds_read_b128 %1, %2\n ds_read_b128 %0, %2\n ds_read_b128 %1, %2\n ds_read_b128 %0, %2\n ds_read_b128 %1, %2\n s_waitcnt lgkmcnt(0)" : "=&v"(t0), "=&v"(t1) : "v"(lds_addr16) : "memory");
@@ -253,5 +284,9 @@ int main() {
     R(FMA_F32) R(PK_FMA_F32) R(PK_MUL_LO_U16) R(PK_MAD_U16) R(DOT4_U32_U8)
     R(DPP_QUAD) R(DPP_ROW_SHR) R(DPP_ROW_ROR) R(DPP_ROW_MIRROR) R(DPP_BCAST15) R(PERMLANE32_SWAP) R(PERMLANE16_SWAP) R(DS_BPERMUTE) R(DS_SWIZZLE)
     R(DS_WRITE_B64) R(DS_READ_B64) R(DS_WRITE_B128) R(DS_READ_B128)
+    printf("dependent chains (8 instructions of ONE chain per iteration: the figure is issue-to-issue latency when one wave runs alone):\n");
+    R(DEP_ADD) R(DEP_MUL_LO) R(DEP_MAD_U64)
+    printf("Shoup butterflies, 48 instructions per iteration (cycles per INSTRUCTION = figure / 6):\n");
+    R(DEP_SHOUP) R(DEP2_SHOUP) R(DEP4_SHOUP)
     return 0;
 }
