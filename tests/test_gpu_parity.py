@@ -302,6 +302,10 @@ def test_load_db_in_several_staging_passes(sa, oracle, monkeypatch):
     {"SPIRAL_FOLD_BLOCKS": "0"},         # fold_chain_kernel, one block per polynomial (all digits) every round
     {"SPIRAL_FOLD_BLOCKS": "1000000"},   # fold_chain_kernel, one block per (polynomial, digit) every round
     {"SPIRAL_FOLD_BLOCKS": "300"},       # mixed chunk sizes
+    {"SPIRAL_FOLD_FUSED": "1"},          # the wide rounds fused (fold_fused_kernel), the narrow ones chain + product
+    {"SPIRAL_FOLD_FUSED": "2"},          # every round fused (fold_fused_kernel), outputs as partial sums of 6 .. 48 parts
+    {"SPIRAL_FOLD_FUSED": "2", "SPIRAL_FOLD_BLOCKS": "1000000"},  # ... one digit per workgroup
+    {"SPIRAL_FOLD_FUSED": "2", "SPIRAL_FOLD_BLOCKS": "0"},        # ... all digits per workgroup
 ])
 def test_fold_chain_schedules(sa, oracle, env, monkeypatch):
     """the fold's schedule variants (read from the environment when the server is created) all give the oracle's answer"""

@@ -13,7 +13,7 @@ enum Op : int {
     FMA_F64, MUL_F64, ADD_F64, RNDNE_F64, FLOOR_F64, CVT_F64_U32, CVT_U32_F64,
     FMA_F32, PK_FMA_F32, PK_MUL_LO_U16, PK_MAD_U16, DOT4_U32_U8,
     DPP_QUAD, DPP_ROW_SHR, DPP_ROW_ROR, DPP_ROW_MIRROR, DPP_BCAST15, PERMLANE32_SWAP, PERMLANE16_SWAP, DS_BPERMUTE, DS_SWIZZLE,
-    DS_WRITE_B64, DS_READ_B64, DS_WRITE_B128, DS_READ_B128, DEP_ADD, DEP_MUL_LO, DEP_MAD_U64, DEP_SHOUP, DEP2_SHOUP, DEP4_SHOUP, N_OPS
+    DS_WRITE_B64, DS_READ_B64, DS_WRITE_B128, DS_READ_B128, DEP_ADD, DEP_MUL_LO, DEP_MAD_U64, DEP_SHOUP, DEP2_SHOUP, DEP4_SHOUP, MIX_16ADD, MIX_LDS1W1R, MIX_16ADD_LDS, MIX_VMEM1, MIX_16ADD_VMEM, N_OPS
 };
 
 template <int OP>
@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, uint32_t seed) {
     u32x4 q0 = {a0, a1, a2, a3}, q1 = {a4, a5, a6, a7};
     sh[threadIdx.x] = a0;
     __syncthreads();
+    const uint32_t* gptr = out + (threadIdx.x & 63) * 4;  // 1 KiB per wave, L1-resident
 #define ALL8(X) X(a0) X(a1) X(a2) X(a3) X(a4) X(a5) X(a6) X(a7)
 #define ALLD(X) X(d0) X(d1) X(d2) X(d3) X(d4) X(d5) X(d6) X(d7)
 #define ALLF(X) X(f0) X(f1) X(f2) X(f3) X(f4) X(f5) X(f6) X(f7)
@@ -240,6 +241,23 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, uint32_t seed) {
     : "+v"(x0), "+v"(y0), "+v"(x1), "+v"(y1), "+v"(x2), "+v"(y2), "+v"(x3), "+v"(y3) : "v"(b), "v"(c), "v"(f0), "v"(f1) : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "s20", "s21");
             X(a0, a1, a2, a3, a4, a5, a6, a7) X(a0, a1, a2, a3, a4, a5, a6, a7)
 #undef X
+        } else if constexpr (OP == MIX_16ADD || OP == MIX_16ADD_LDS || OP == MIX_LDS1W1R || OP == MIX_VMEM1 || OP == MIX_16ADD_VMEM) {
+            // do the VALU, LDS and vector-memory pipes overlap?  16 adds / one ds_write_b64 + one ds_read_b64 / one 16-byte global
+            // load, alone and together, per iteration ("cycles" printed = per 1/8 iteration)
+            if constexpr (OP == MIX_16ADD || OP == MIX_16ADD_LDS || OP == MIX_16ADD_VMEM) {
+#define X(r) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r) : "v"(b));
+                ALL8(X) ALL8(X)
+#undef X
+            }
+            if constexpr (OP == MIX_16ADD_LDS || OP == MIX_LDS1W1R) {
+                asm volatile("ds_write_b64 %0, %1" : : "v"(lds_addr), "v"(w0) : "memory");
+                asm volatile("ds_read_b64 %0, %1" : "=v"(w1) : "v"(lds_addr) : "memory");
+                if ((i & 7) == 7) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            if constexpr (OP == MIX_VMEM1 || OP == MIX_16ADD_VMEM) {
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(q1) : "v"(gptr) : "memory");
+                if ((i & 7) == 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         } else if constexpr (OP == DS_READ_B128) {
             u32x4 t0, t1;
             asm volatile("ds_read_b128 %0, %2\n ds_read_b128 %1, %2\n ds_read_b128 %0, %2\n ds_read_b128 %1, %2\n ds_read_b128 %0, %2\n ds_read_b128 %1, %2\n ds_read_b128 %0, %2\n ds_read_b128 %1, %2\n s_waitcnt lgkmcnt(0)" : "=&v"(t0), "=&v"(t1) : "v"(lds_addr16) : "memory");
@@ -276,7 +294,7 @@ void run(const char* name, uint32_t* d) {
 
 int main() {
     uint32_t* d;
-    hipMalloc(&d, 4096);
+    hipMalloc(&d, 1 << 20);
 #define R(op) run<op>(#op, d);
     R(ADD_U32) R(SUB_U32) R(ADD3_U32) R(LSHL_ADD_U32) R(AND_B32) R(LSHRREV_B32) R(ALIGNBIT_B32) R(BFE_U32) R(MIN_U32) R(CMP_CNDMASK)
     R(MUL_LO_U32) R(MUL_HI_U32) R(MAD_U64_U32_S) R(MAD_U64_U32_V) R(MUL_U32_U24) R(MUL_HI_U32_U24) R(MAD_U32_U24)
@@ -288,5 +306,7 @@ int main() {
     R(DEP_ADD) R(DEP_MUL_LO) R(DEP_MAD_U64)
     printf("Shoup butterflies, 48 instructions per iteration (cycles per INSTRUCTION = figure / 6):\n");
     R(DEP_SHOUP) R(DEP2_SHOUP) R(DEP4_SHOUP)
+    printf("pipe overlap (per 1/8 iteration; an iteration = 16 v_add and / or 1 ds_write_b64 + 1 ds_read_b64 and / or 1 global_load_dwordx4 from L1):\n");
+    R(MIX_16ADD) R(MIX_LDS1W1R) R(MIX_16ADD_LDS) R(MIX_VMEM1) R(MIX_16ADD_VMEM)
     return 0;
 }
