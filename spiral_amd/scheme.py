@@ -1,16 +1,22 @@
-"""Run one Spiral parameter set through the ./spiral command line and print the result as one JSON object.
+"""The reference's experiment driver (select_params.py) for this build: run a parameter set through ./spiral and print the
+result as one JSON object, choose a parameter set for a database with a cost model fitted on the MI355X, or fit that model.
 
-This is the measuring half of the reference's experiment driver (select_params.py:376-576): same keys, same
-derived quantities (item_sz, dbsize, tput, rate, cost), same "factor" convention (an item larger than one
-plaintext is served by `factor` database instances; the database-dependent times and the response size scale
-by it).  The searching half (the cost-model fit over all_params*.pkl) is out of scope (DESIGN.md section 1, row f):
-a parameter set is given explicitly (--params JSON) or picked from PUBLISHED, the sets the reference's
-all_parameter_choices.txt records for its paper figures.  The scheme parameters are run-time arguments of this
-build's ./spiral (environment TEXP, TEXPRIGHT, TCONV, TGSW, QPBITS, PVALUE, OUTN), where the reference
-recompiles per set (select_params.py:355-371).
+Measuring (select_params.py:376-576): same keys, same derived quantities (item_sz, dbsize, tput, rate, cost), same "factor"
+convention (an item larger than one plaintext is served by `factor` database instances; the database-dependent times and the
+response size scale by it).  The scheme parameters are run-time arguments of this build's ./spiral (environment TEXP,
+TEXPRIGHT, TCONV, TGSW, QPBITS, PVALUE, OUTN), where the reference recompiles per set (select_params.py:355-371).
+
+Selecting (select_params.py:153-198, 305, 524-540 and generate_all_schemes.py): the reference ranks a pickled table of
+noise-feasible parameter sets (git-LFS objects that are not in the repository) with stage-time regressions taken on a
+c5n.2xlarge.  Here the feasible sets are enumerated on the fly with a restatement of the reference's noise model
+(`feasible`, pinned to outputs of generate_all_schemes.py in tests/golden/scheme_model.json) and ranked with the same cost
+formula (USD per CPU-microsecond and per byte, select_params.py:119-120) over stage times predicted by a model fitted to
+measurements on the MI355X (`--fit`, coefficients in spiral_amd/cost_model_mi355x.json).
 
     python -m spiral_amd.scheme --set "20,256:spiral" --trials 3
     python -m spiral_amd.scheme --params '{"nu_1":8,"nu_2":7,"p":256,"q_prime_bits":20,"t_GSW":8,"t_conv":4,"t_exp":8,"t_exp_right":56}' --item-size 8192
+    python -m spiral_amd.scheme --select 20,256 [--variant spiral|spiralstream] [--run]
+    python -m spiral_amd.scheme --fit            (on an MI355X; rewrites the coefficient file)
 """
 import argparse
 import json
@@ -49,7 +55,7 @@ PUBLISHED = {
         "spiralstream": dict(_BASE, direct=1, nu_1=9, nu_2=5, p=16384, q_prime_bits=26, t_GSW=4, t_conv=16, t_exp=2),
         "spiralstream-pack": dict(_BASE, direct=1, n=5, nu_1=11, nu_2=3, p=65536, q_prime_bits=27, t_GSW=3, t_conv=56, t_exp=56),
     },
-    "20,100000": {  # BASELINE.json configs[3]: 2^20 x 100 KB; the two variants whose database (64 GiB, 7 instances by `factor`) fits one GPU
+    "20,100000": {  # BASELINE.json configs[3]: 2^20 x 100 KB (the table's "Streaming" section, key "20"); the two variants whose database (64 GiB, 7 instances by `factor`) fits one GPU
         "spiral": dict(_BASE, nu_1=9, nu_2=11, p=256, q_prime_bits=20, t_GSW=10, t_conv=56, t_exp=16),
         "spiralstream": dict(_BASE, direct=1, nu_1=11, nu_2=9, p=32768, q_prime_bits=27, t_GSW=4, t_conv=56, t_exp=2),
     },
@@ -89,6 +95,252 @@ GPU_EXTRAS = {
     "gpu_sweep_gbs": r"\s+Sweep kernels? alone.*\(([0-9\.]+) GB/s\)",
     "gpu_answer_us": r"\s+Whole answer, device.*:\s+([0-9\.]+)",
 }
+
+
+# ---- the reference's noise model, restated (generate_all_schemes.py:9-190, 192-289) ------------------------------------------
+REAL_Q = 66974689739603969      # generate_all_schemes.py:10
+SIGMA, P_ERR_BITS, C_BOUND = 6.4, 40.0, 5
+# plaintext moduli above 2^16 are not powers of two (generate_all_schemes.py:143-158): p -> the modulus really used
+P_MOD_TABLE = {17: 131072, 18: 262144, 19: 524288, 20: 1048576, 21: 2097152, 22: 4194304, 23: 8388592, 24: 16777184, 25: 33554332,
+               26: 67108804, 27: 134217608, 28: 268435216, 29: 536742296, 30: 1073612276}
+
+
+def real_p(p):
+    b = int(round(math.log2(p)))
+    if (1 << b) != p or b < 1 or b > 30:
+        raise KeyError(p)
+    return p if b <= 16 else P_MOD_TABLE[b]
+
+
+def noise_variance(kind, p, t_GSW, t_conv, t_exp, t_exp_right, nu_1, nu_2, n=2):
+    """variance of the response's error term: calc_fast (generate_all_schemes.py:15-81) for Spiral / SpiralStream,
+    calc_fast_highrate (:96-140) for the packing variants; `kind` in spiral, spiralstream, spiral-pack, spiralstream-pack"""
+    q, d, sigma = float(REAL_Q), POLY_LEN, SIGMA
+    z = lambda t: math.ceil(q ** (1.0 / t))
+    z_GSW, z_conv, z_exp, z_exp_right = z(t_GSW), z(t_conv), z(t_exp), z(t_exp_right)
+    stream = kind.startswith("spiralstream")
+    if not kind.endswith("-pack"):
+        m_GSW = 3 * t_GSW
+        noise_scale_GSW = 4 * (t_GSW * nu_2 + 1) ** 2
+        if stream:  # du_first_dim and kinda_direct_upload
+            sigma_hat_regev_2 = sigma ** 2
+            sigma_hat_GSW_2 = sigma ** 2
+        else:
+            sigma_hat_regev_2 = 4 ** (nu_1 + 1) * sigma ** 2 * (1 + d * t_exp * z_exp ** 2 / 3)
+            sigma_hat_GSW_2 = noise_scale_GSW * sigma ** 2 * (1 + t_exp_right * d * z_exp_right ** 2 / 3)
+        sigma_regev_2 = sigma_hat_regev_2 + d * t_conv * (z_conv ** 2) * (sigma ** 2) / 4.0
+        sigma_GSW_2 = sigma_hat_GSW_2 * d * (C_BOUND * sigma) ** 2 + t_conv * d * sigma ** 2 * z_conv ** 2 / 2
+        sigma_0_2 = 2 ** nu_1 * 2 * d * (p / 2) ** 2 * sigma_regev_2
+        return sigma_0_2 + nu_2 * d * m_GSW * z_GSW ** 2 / 2 * sigma_GSW_2
+    m_GSW = 2 * t_GSW
+    sigma_regev_2 = sigma_GSW_2 = sigma ** 2
+    if not stream:
+        noise_scale_GSW = 4 ** (math.ceil(math.log(t_GSW * nu_2, 2)) + 1)
+        sigma_regev_2 = 4 ** (nu_1 + 1) * sigma ** 2 * (1 + d * t_exp * z_exp ** 2 / 3)
+        sigma_GSW_2 = noise_scale_GSW * sigma ** 2 * (1 + t_exp_right * d * z_exp_right ** 2 / 3)
+        sigma_GSW_2 = sigma_GSW_2 * d * (C_BOUND * sigma) ** 2 + t_conv * d * sigma ** 2 * z_conv ** 2 / 2
+    sigma_0_2 = 2 ** nu_1 * 1 * d * (p / 2) ** 2 * sigma_regev_2
+    sigma_r_2 = sigma_0_2 + nu_2 * d * m_GSW * z_GSW ** 2 / 2 * sigma_GSW_2
+    return sigma_r_2 + (d * n * t_conv) * (sigma ** 2) * (z_conv ** 2) / 4
+
+
+def p_err_log2(p, q_prime, s_e, n=2):
+    """log2 of the probability that some coefficient of the response decodes wrongly (get_p_err_fast_highrate, :159-190)"""
+    pr, q, d = float(real_p(int(p))), float(REAL_Q), POLY_LEN
+    thresh = 0.25 - (1.0 / 8.0) * ((4 * pr) * (q % pr) / q)
+    assert 0 < thresh <= 0.25
+    denom = float(s_e) * (pr / q) ** 2 + ((SIGMA ** 2) * d / 4) * (pr / float(q_prime)) ** 2
+    return (math.log(2) + (-math.pi * thresh ** 2) / denom + math.log(n * n * d)) * math.log(math.e, 2)
+
+
+def feasible(kind, p, t_GSW, t_conv, t_exp, t_exp_right, nu_1, nu_2, n=2):
+    """None when the set cannot reach 2^-40 correctness, else {"q_prime_bits", "s_e"}: simul / simul_highrate
+    (generate_all_schemes.py:192-289) -- feasibility at q' = p 2^20, then the smallest q' on the reference's ladder"""
+    pack = kind.endswith("-pack")
+    kw = dict(kind=kind, p=p, t_GSW=t_GSW, t_conv=t_conv, t_exp=t_exp, t_exp_right=t_exp_right, nu_1=nu_1, nu_2=nu_2, n=n)
+    s_e = noise_variance(**kw)
+    nn = n if pack else 2
+    if p_err_log2(p, p * 2 ** 20, s_e, nn) > -P_ERR_BITS:
+        return None
+    bits, q_prime = (6, None) if pack else (8, None)
+    while bits <= 20:
+        q_prime = p * (2 ** bits) if pack else p * (2 ** bits) - p + 1
+        if p_err_log2(p, q_prime, s_e, nn) <= -P_ERR_BITS:
+            break
+        bits += 0.1
+    return {"q_prime_bits": int(math.ceil(math.log(float(q_prime), 2))), "s_e": math.log(s_e, 2)}
+
+
+# ---- stage-time model fitted on the MI355X (the analogue of select_params.py:179-187) ------------------------------------------
+MODEL_PATH = os.path.join(ROOT, "cost_model_mi355x.json")
+MIN_Q_PRIME_BITS = 14  # select_params.py:121
+FIT_GRID = [  # (nu_1, nu_2, t_GSW, t_conv, t_exp, direct): spans the published sets' ranges
+    (6, 4, 8, 4, 8, 0), (7, 5, 8, 4, 8, 0), (8, 6, 8, 4, 8, 0), (8, 7, 8, 4, 8, 0), (9, 6, 8, 4, 8, 0), (9, 7, 8, 4, 8, 0), (9, 8, 8, 4, 8, 0),
+    (9, 9, 9, 4, 8, 0), (10, 7, 8, 4, 8, 0), (10, 9, 8, 4, 8, 0), (8, 8, 4, 4, 8, 0), (8, 8, 6, 4, 8, 0), (8, 8, 10, 4, 8, 0), (8, 8, 12, 4, 8, 0),
+    (9, 5, 9, 4, 16, 0), (8, 7, 8, 4, 4, 0), (8, 7, 8, 4, 16, 0), (8, 7, 8, 4, 32, 0), (8, 7, 8, 8, 8, 0), (8, 7, 8, 16, 8, 0), (9, 10, 10, 4, 8, 0),
+    (7, 9, 8, 4, 8, 0), (10, 5, 6, 4, 8, 0), (6, 9, 8, 8, 16, 0), (9, 11, 10, 4, 8, 0),
+    (9, 6, 5, 4, 2, 1), (10, 8, 4, 32, 2, 1), (9, 5, 4, 16, 2, 1), (11, 9, 4, 56, 2, 1), (10, 10, 4, 32, 2, 1), (11, 3, 4, 56, 2, 1), (8, 6, 5, 4, 2, 1),
+    (10, 6, 6, 8, 2, 1), (11, 7, 4, 16, 2, 1), (9, 9, 8, 4, 2, 1),
+]
+
+
+def _ceil_log2(x):
+    r = 0
+    while (1 << r) < x:
+        r += 1
+    return r
+
+
+def model_features(nu_1, nu_2, t_GSW, t_conv, t_exp, t_exp_right=56, direct=0):
+    """what the stage times are regressed on: counts of limb-pair transforms, of products, of launches and of database bytes,
+    derived from the parameters exactly as the server schedules them (host_common.h run_expand, server.cpp)"""
+    dim0, num_per, ell = 1 << nu_1, 1 << nu_2, t_GSW
+    f = {"db_words": dim0 * num_per * 4 * POLY_LEN, "lift_polys": num_per * 6}
+    if direct:
+        f.update(exp_rounds=0, exp_transforms=0, exp_macs=0)
+    else:
+        g = _ceil_log2(dim0 + ell * nu_2)
+        stop = _ceil_log2(ell * nu_2) if nu_2 and ell * nu_2 <= dim0 else 0
+        tr = mac = 0
+        for r in range(g):
+            even = 1 << r
+            odd = 0 if (stop and r > stop) else (min(1 << r, ell * nu_2 + 1) if (stop and r == stop) else (1 << r))
+            tr += even * (1 + t_exp) + odd * (1 + t_exp_right)
+            mac += even * t_exp + odd * t_exp_right
+        f.update(exp_rounds=g, exp_transforms=tr, exp_macs=mac)
+    f["conv_transforms"] = (dim0 + 2 * nu_2 * ell) * (1 + t_conv)
+    f["conv_macs"] = dim0 * 6 * t_conv + nu_2 * ell * (6 * t_conv + 6 * t_conv)
+    f["fold_rounds"] = nu_2
+    f["fold_transforms"] = (num_per - 1) * 2 * 6 * (ell + 1) if nu_2 else 0   # 2 np' cts x 6 polys x (1 lift + ell digits), summed over the rounds
+    f["fold_macs"] = (num_per - 1) * 6 * 2 * 3 * ell
+    return f
+
+
+# stage -> the features it is regressed on (plus a constant); times in microseconds
+MODEL_TERMS = {
+    "exp_us": ["exp_rounds", "exp_transforms", "exp_macs"],
+    "conv_us": ["conv_transforms", "conv_macs"],
+    "fdim_us": ["db_words", "lift_polys"],
+    "fold_us": ["fold_rounds", "fold_transforms", "fold_macs"],
+}
+
+
+def load_model(path=None):
+    return json.load(open(path or MODEL_PATH))
+
+
+def predict_times(model, params):
+    f = model_features(params["nu_1"], params["nu_2"], params["t_GSW"], params["t_conv"], params["t_exp"], params.get("t_exp_right", 56), params.get("direct", 0))
+    out = {}
+    for stage, terms in MODEL_TERMS.items():
+        c = model["coefficients"][stage]
+        out[stage] = max(0.0, c["const"] * (0 if (stage == "exp_us" and params.get("direct")) else 1) + sum(c[t] * f[t] for t in terms))
+    return out
+
+
+def predicted_cost(model, params, item_size):
+    """select_params.py:153-215 with the MI355X stage times: (cost in USD, total_us, response bytes, factor)"""
+    n = 2
+    factor = max(1, math.ceil(item_size / (n * n * POLY_LEN * math.log2(real_p(params["p"])) / 8)))
+    t = predict_times(model, params)
+    total_us = t["exp_us"] + t["conv_us"] + factor * (t["fdim_us"] + t["fold_us"])
+    qpb = max(params["q_prime_bits"], MIN_Q_PRIME_BITS)
+    total_bytes = factor * ((2 * 2 * 2048 * math.ceil(math.log2(4 * params["p"])) + 2 * 2048 * qpb) / 8)
+    return USD_PER_US * total_us + USD_PER_BYTE * total_bytes, total_us, total_bytes, factor
+
+
+def enumerate_sets(variant, log_n, item_size):
+    """noise-feasible parameter sets whose database holds 2^log_n items of item_size bytes: the reference's search space
+    (generate_all_schemes.py get_regular_choices / get_streaming_choices) filtered by select_params.py pred (:305-330), with
+    nu_1 + nu_2 kept within 1 of the smallest that fits (the cost grows with both)"""
+    stream = variant == "spiralstream"
+    target = (1 << log_n) * item_size
+    out = []
+    for pb in range(2, (20 if stream else 15) + 1):
+        p = 1 << pb
+        base_item = 4 * POLY_LEN * math.log2(real_p(p)) / 8
+        factor = math.ceil(item_size / base_item)
+        need = _ceil_log2(math.ceil(target / (factor * base_item)))
+        if stream:
+            need = max(need, log_n) if item_size == 1 else need
+        for total_nu in (max(need, 10 if not stream else 4), max(need, 10 if not stream else 4) + 1):
+            for nu_1 in range(2, (13 if stream else 10) + 1):
+                nu_2 = total_nu - nu_1
+                if nu_2 < 2 or nu_2 > 13:
+                    continue
+                for t_GSW in range(2, 29):
+                    for t_conv in (2, 4, 8, 16, 32, 56):
+                        for t_exp in ((2,) if stream else (2, 4, 8, 16, 32, 56)):
+                            r = feasible(variant, p, t_GSW, t_conv, t_exp, 56, nu_1, nu_2)
+                            if r is None:
+                                continue
+                            if not stream and _ceil_log2((1 << nu_1) + t_GSW * nu_2) > 11:
+                                continue  # the query must fit one polynomial
+                            prm = dict(nu_1=nu_1, nu_2=nu_2, p=p, q_prime_bits=max(r["q_prime_bits"], MIN_Q_PRIME_BITS), t_GSW=t_GSW, t_conv=t_conv, t_exp=t_exp,
+                                       t_exp_right=56, s_e=r["s_e"])
+                            if stream:
+                                prm["direct"] = 1
+                            out.append(prm)
+    return out
+
+
+def select(variant, log_n, item_size, model=None, top=5, optimize_for="cost", usd_per_us=None):
+    """the best feasible sets under the MI355X model, best first: [(cost, total_us, bytes, factor, params)].  optimize_for:
+    "cost" (USD per query, select_params.py:198-205; usd_per_us overrides the reference's price of a CPU-microsecond, which
+    undervalues a GPU-microsecond by two orders of magnitude), "tput" (server time) or "rate" (response size), the reference's
+    --optimize-for shortcuts (select_params.py:268-276)"""
+    model = model or load_model()
+    ranked = []
+    for prm in enumerate_sets(variant, log_n, item_size):
+        try:
+            cost, total_us, nbytes, factor = predicted_cost(model, prm, item_size)
+        except KeyError:
+            continue
+        if usd_per_us is not None:
+            cost = usd_per_us * total_us + USD_PER_BYTE * nbytes
+        key = {"cost": cost, "tput": total_us, "rate": nbytes}[optimize_for]
+        ranked.append((key, (cost, total_us, nbytes, factor, prm)))
+    ranked.sort(key=lambda x: x[0])
+    return [r[1] for r in ranked[:top]]
+
+
+def fit_model(out_path=None, reps=12):
+    """measure the stage times of FIT_GRID on this GPU (resident server, arbitrary valid database words, synthetic keys and
+    query: the times do not depend on the values) and regress them on model_features: writes the coefficient file"""
+    import numpy as np
+
+    import spiral_amd as sa
+
+    rows = []
+    rng = np.random.default_rng(1)
+    mk = lambda shape: np.stack([rng.integers(0, m, size=shape + (sa.N,), dtype=np.uint64) for m in (sa.P, sa.B)], axis=-2)
+    for nu_1, nu_2, t_GSW, t_conv, t_exp, direct in FIT_GRID:
+        pg = sa.make_params(nu_1, nu_2, t_gsw=t_GSW, t_conv=t_conv, t_exp=t_exp, t_exp_right=56, qprime_bits=20, p_db=256, direct_upload=direct)
+        shp = sa.get_shape(pg)
+        srv = sa.Server(pg)
+        srv.fill_db_random(3)
+        srv.set_pub_params(mk((max(shp.n_left, 1), 2, t_exp)), mk((max(shp.n_right, 1), 2, 56)), mk((3, 2 * t_conv)), mk((3, 2 * t_conv)))
+        srv.set_query(mk((shp.n_query_cts, 2)))
+        us = [srv.answer_resident() for _ in range(reps)][2:]
+        med = {k: float(np.median([u[k] for u in us])) for k in us[0]}
+        srv.close()
+        rows.append({"params": dict(nu_1=nu_1, nu_2=nu_2, t_GSW=t_GSW, t_conv=t_conv, t_exp=t_exp, direct=direct),
+                     "measured": {"exp_us": med["expansion_us"], "conv_us": med["conversion_us"], "fdim_us": med["first_dim_us"], "fold_us": med["folding_us"] + med["response_us"]},
+                     "features": model_features(nu_1, nu_2, t_GSW, t_conv, t_exp, 56, direct)})
+    coef, err = {}, {}
+    for stage, terms in MODEL_TERMS.items():
+        use = [r for r in rows if not (stage == "exp_us" and r["params"]["direct"])]
+        A = np.array([[1.0] + [r["features"][t] for t in terms] for r in use])
+        y = np.array([r["measured"][stage] for r in use])
+        w = 1.0 / np.maximum(y, 20.0)  # relative error matters: a 300 us stage and a 10 ms stage both count
+        x, *_ = np.linalg.lstsq(A * w[:, None], y * w, rcond=None)
+        coef[stage] = dict(zip(["const"] + terms, [float(v) for v in x]))
+        pred = A @ x
+        err[stage] = {"median_rel_err": float(np.median(np.abs(pred - y) / np.maximum(y, 1))), "max_rel_err": float(np.max(np.abs(pred - y) / np.maximum(y, 1)))}
+    model = {"device": "MI355X (gfx950), one GPU, eager stage launches timed with HIP events (Server.answer_resident)",
+             "units": "microseconds; features: spiral_amd.scheme.model_features", "coefficients": coef, "fit_error": err, "grid": rows}
+    json.dump(model, open(out_path or MODEL_PATH, "w"), indent=1)
+    return model
 
 
 def is_high_rate(params):
@@ -169,6 +421,13 @@ def main(argv=None):
     g.add_argument("--set", help='published set "<workload>:<variant>", e.g. "20,256:spiral" or "wiki:spiralstream-pack"')
     g.add_argument("--params", help="JSON object with nu_1 nu_2 p q_prime_bits t_GSW t_conv t_exp t_exp_right [n] [direct]")
     g.add_argument("--list", action="store_true", help="print the published sets and exit")
+    g.add_argument("--select", metavar="LOGN,ITEMSIZE", help="choose the cheapest noise-feasible parameter set for 2^LOGN items of ITEMSIZE bytes under the MI355X cost model")
+    g.add_argument("--fit", action="store_true", help="measure the fitting grid on this GPU and rewrite the cost-model coefficients")
+    ap.add_argument("--variant", default="spiral", choices=["spiral", "spiralstream"], help="--select: query compression (spiral) or direct upload (spiralstream)")
+    ap.add_argument("--run", action="store_true", help="--select: also run the chosen set through ./spiral and report the measured times")
+    ap.add_argument("--top", type=int, default=5, help="--select: how many of the cheapest sets to list")
+    ap.add_argument("--optimize-for", default="cost", choices=["cost", "tput", "rate"], help="--select: USD per query (default), server time, or response size")
+    ap.add_argument("--usd-per-us", type=float, help="--select: price of a server microsecond (default: the reference's CPU figure, 5.4e-12)")
     ap.add_argument("--item-size", type=int, help="bytes per item (default: the workload's, or one plaintext)")
     ap.add_argument("--trials", type=int, default=1)
     ap.add_argument("--random-data", action="store_true", help="pseudo-random database words, no correctness check (the reference's default)")
@@ -177,6 +436,32 @@ def main(argv=None):
     a = ap.parse_args(argv)
     if a.list:
         print(json.dumps(PUBLISHED, indent=1))
+        return 0
+    if a.fit:
+        m = fit_model()
+        print(json.dumps({"coefficients": m["coefficients"], "fit_error": m["fit_error"], "points": len(m["grid"]), "written": MODEL_PATH}))
+        return 0
+    if a.select:
+        log_n, item_size = (int(x) for x in a.select.split(","))
+        model = load_model()
+        ranked = select(a.variant, log_n, item_size, model, a.top, a.optimize_for, a.usd_per_us)
+        if not ranked:
+            sys.exit("no feasible parameter set")
+        out = {"workload": {"log_n": log_n, "item_size": item_size, "variant": a.variant, "optimize_for": a.optimize_for}, "model": os.path.basename(MODEL_PATH),
+               "candidates": [{"params": prm, "predicted_us": predict_times(model, prm), "predicted_total_us": tot, "resp_bytes": nb, "factor": fac, "cost_usd": cost}
+                              for cost, tot, nb, fac, prm in ranked]}
+        work = f"{log_n},{item_size}"
+        if work in PUBLISHED and a.variant in PUBLISHED[work]:  # what the reference's CPU model chose for the same workload, under this model
+            pub = dict(PUBLISHED[work][a.variant])
+            c = predicted_cost(model, pub, item_size)
+            out["published_choice"] = {"params": pub, "predicted_total_us": c[1], "cost_usd": c[0]}
+        if a.run:
+            if not os.path.exists(BIN):
+                sys.exit("spiral_amd/spiral is not built")
+            best = {k: v for k, v in ranked[0][4].items() if k != "s_e"}
+            runs = [run_once(best, ranked[0][3], not a.random_data, a.seed) for _ in range(max(1, a.trials))]
+            out["measured"] = summarize(runs, best, item_size, ranked[0][3])
+        print(json.dumps(out))
         return 0
     if a.set:
         work, _, variant = a.set.partition(":")
