@@ -57,6 +57,8 @@ struct FwdParams {
     uint32_t bits;      // digit width
     uint32_t ell;       // LD_SDIGIT: digits per value (t_GSW)
     uint32_t tinv;      // automorphism gather x -> x^t folded into the load: t^-1 mod 2N, 0 = none
+    uint32_t lazy_out;  // ST_PK: 1 = leave the outputs in [0, 2m) instead of [0, m): allowed when the only readers are u64
+                        // multiply-accumulate kernels summing fewer than 128 products (digit operands); LD_EXPAND always does
     uint32_t fold_np;   // LD_SDIGIT: num_per' (destination is the fold operand layout)
     // LD_PDIGIT: map selector; fold_np = np' and num_per (ct stride of a trial in the raw buffer) for PM_FOLD / PM_PACK
     uint32_t pmode, pk_num_per;
@@ -116,6 +118,7 @@ struct FoldChainParams {
     uint32_t ell, bits, fold_np;
     uint32_t pre_reduce;  // 1: fields are lazy sums (< 2^32), reduce mod m first
     uint32_t dpb;         // digits per block, 1 .. ell
+    uint32_t lazy_out;    // 1: digit transforms left in [0, 2m) (the product kernel sums 6 * ell < 128 terms of < 2^57)
     uint32_t src_parts, src_part_stride;  // > 1: a source polynomial is the sum of that many partial sums (a fused round's output), stride in polynomials
     // SpiralPack fold (foldCiphertextsDim1): sources are [trial][2*np][2] 2 x 1 ciphertexts with a trial stride of src_stride
     // ciphertexts, unsigned digits, operand layout as LD_PDIGIT / PM_FOLD

@@ -271,7 +271,11 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
             DIGIT_WIDTH_DISPATCH(p.bits, body);
     }
 
-    ntt_forward_block(lo, hi, sh, t.fwd, tid);
+    ntt_forward_block<false>(lo, hi, sh, t.fwd, tid);
+    // the expansion's digit transforms feed only expand_mac_round_* (at most 56 + 56 products per accumulator): left in [0, 2m)
+    bool lazy = LOAD == LD_EXPAND;
+    if constexpr (STORE == ST_PK && LOAD != LD_EXPAND) lazy = p.lazy_out != 0;
+    if (!lazy) canonicalize8(lo, hi);
 
 #ifdef NTT_ABLATE_STORE
     if (lo[0] != 0x12345u) return;
@@ -481,7 +485,8 @@ __global__ __launch_bounds__(256) void fold_chain_kernel(Tables t, FoldChainPara
         };
         DIGIT_WIDTH_DISPATCH(p.bits, digits);
         if (k > k0) __syncthreads();  // the previous transform's last LDS reads
-        ntt_forward_block(lo, hi, sh, t.fwd, tid);
+        ntt_forward_block<false>(lo, hi, sh, t.fwd, tid);
+        if (!p.lazy_out) canonicalize8(lo, hi);
         const size_t di = p.pack ? (size_t)(((pt * p.fold_np + pi) * 2u + phh) * (2u * p.ell) + 2u * k + prow)
                                  : (size_t)(((i * 2u + hi_half) * m2 + row + 3u * k) * 2u + c);
         uint64_t x[8];

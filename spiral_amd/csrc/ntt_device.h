@@ -16,6 +16,17 @@
 #ifndef TWI
 #define TWI(i) (i)
 #endif
+// The twiddle rows are fetched through a buffer descriptor (32-bit byte offsets against a wave-uniform base) rather than
+// 64-bit flat addresses: the 20 per-thread row loads of a transform then need one shift each instead of a 64-bit add.
+struct TwTable {
+    __amdgpu_buffer_rsrc_t rs;
+    __device__ __forceinline__ explicit TwTable(const uint4* tw) : rs(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(tw), 0, 2048 * 16, 0x00020000)) {}
+    __device__ __forceinline__ uint4 operator[](uint32_t i) const {
+        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, i * 16u, 0, 0);
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+};
 #ifdef NTT_ABLATE_BARRIER
 #define NTT_SYNC() ((void)0)
 #else
@@ -75,7 +86,8 @@ __device__ __forceinline__ void gs2(uint32_t* lo, uint32_t* hi, int a, int b, ui
 
 // three forward stages on 8 register-resident coefficients whose indices differ in the 3 bits the
 // stages consume: distance 4, then 2, then 1 in register numbering
-__device__ __forceinline__ void ct_radix8(uint32_t* lo, uint32_t* hi, const uint4* tw, uint32_t b0, uint32_t b1, uint32_t b2) {
+template <class TW>
+__device__ __forceinline__ void ct_radix8(uint32_t* lo, uint32_t* hi, const TW& tw, uint32_t b0, uint32_t b1, uint32_t b2) {
     uint4 t0 = tw[TWI(b0)];
 #pragma unroll
     for (int k = 0; k < 4; k++) ct2(lo, hi, k, k + 4, t0);
@@ -87,7 +99,8 @@ __device__ __forceinline__ void ct_radix8(uint32_t* lo, uint32_t* hi, const uint
 #pragma unroll
     for (int q = 0; q < 4; q++) ct2(lo, hi, 2 * q, 2 * q + 1, tw[TWI(b2 + q)]);
 }
-__device__ __forceinline__ void ct_radix4x2(uint32_t* lo, uint32_t* hi, const uint4* tw, uint32_t b1, uint32_t b2) {
+template <class TW>
+__device__ __forceinline__ void ct_radix4x2(uint32_t* lo, uint32_t* hi, const TW& tw, uint32_t b1, uint32_t b2) {
     uint4 t1a = tw[TWI(b1)], t1b = tw[TWI(b1 + 1)];
     ct2(lo, hi, 0, 2, t1a);
     ct2(lo, hi, 1, 3, t1a);
@@ -97,7 +110,8 @@ __device__ __forceinline__ void ct_radix4x2(uint32_t* lo, uint32_t* hi, const ui
     for (int q = 0; q < 4; q++) ct2(lo, hi, 2 * q, 2 * q + 1, tw[TWI(b2 + q)]);
 }
 // inverse order: distance 1, 2, 4
-__device__ __forceinline__ void gs_radix8(uint32_t* lo, uint32_t* hi, const uint4* tw, uint32_t b0, uint32_t b1, uint32_t b2) {
+template <class TW>
+__device__ __forceinline__ void gs_radix8(uint32_t* lo, uint32_t* hi, const TW& tw, uint32_t b0, uint32_t b1, uint32_t b2) {
 #pragma unroll
     for (int q = 0; q < 4; q++) gs2(lo, hi, 2 * q, 2 * q + 1, tw[TWI(b2 + q)]);
     uint4 t1a = tw[TWI(b1)], t1b = tw[TWI(b1 + 1)];
@@ -109,7 +123,8 @@ __device__ __forceinline__ void gs_radix8(uint32_t* lo, uint32_t* hi, const uint
 #pragma unroll
     for (int k = 0; k < 4; k++) gs2(lo, hi, k, k + 4, t0);
 }
-__device__ __forceinline__ void gs_radix4x2(uint32_t* lo, uint32_t* hi, const uint4* tw, uint32_t b1, uint32_t b2) {
+template <class TW>
+__device__ __forceinline__ void gs_radix4x2(uint32_t* lo, uint32_t* hi, const TW& tw, uint32_t b1, uint32_t b2) {
 #pragma unroll
     for (int q = 0; q < 4; q++) gs2(lo, hi, 2 * q, 2 * q + 1, tw[TWI(b2 + q)]);
     uint4 t1a = tw[TWI(b1)], t1b = tw[TWI(b1 + 1)];
@@ -124,7 +139,8 @@ __device__ __forceinline__ void gs_radix4x2(uint32_t* lo, uint32_t* hi, const ui
 struct Tw7 {
     uint4 t[7];
 };
-__device__ __forceinline__ Tw7 tw_load8(const uint4* tw, uint32_t b0, uint32_t b1, uint32_t b2) {
+template <class TW>
+__device__ __forceinline__ Tw7 tw_load8(const TW& tw, uint32_t b0, uint32_t b1, uint32_t b2) {
     Tw7 r;
     r.t[0] = tw[TWI(b0)];
     r.t[1] = tw[TWI(b1)];
@@ -133,7 +149,8 @@ __device__ __forceinline__ Tw7 tw_load8(const uint4* tw, uint32_t b0, uint32_t b
     for (int q = 0; q < 4; q++) r.t[3 + q] = tw[TWI(b2 + q)];
     return r;
 }
-__device__ __forceinline__ Tw7 tw_load4x2(const uint4* tw, uint32_t b1, uint32_t b2) {
+template <class TW>
+__device__ __forceinline__ Tw7 tw_load4x2(const TW& tw, uint32_t b1, uint32_t b2) {
     Tw7 r;
     r.t[0] = make_uint4(0, 0, 0, 0);
     r.t[1] = tw[TWI(b1)];
@@ -250,57 +267,54 @@ __device__ __forceinline__ void pk_pack8(const uint32_t* lo, const uint32_t* hi,
 }
 
 // Forward transform of the 2048 coefficients held as (lo,hi)[k] <-> index ix_a(tid,k), values < 2m.
-// On return (lo,hi)[k] <-> slot ix_d(tid,k) = 8*tid + k, canonical in [0, m).
-// Bounds: < 2m in; +6m per pass: < 14m after passes A and B -> reduced to < 2m; < 12m after C and D.
+// On return (lo,hi)[k] <-> slot ix_d(tid,k) = 8*tid + k, canonical in [0, m) -- or, with CANONICAL = false, only reduced
+// to [0, 2m): what a transform of gadget digits may leave when its only readers are the u64 multiply-accumulate kernels
+// (a product of a canonical residue with a value < 2m is < 2^57; up to 127 of them fit the accumulator).
+// Bounds: < 2m in, +2m per stage: < 14m after passes A and B (6 stages).  Pass C's first stage multiplies registers 4..7
+// (any u32 is a valid Shoup operand and the product is < 2m) and only adds to registers 0..3, so only those four are
+// reduced (to < 2m) after the exchange; from there +2m per stage again: < 12m after the remaining 5 stages.
+// Pass A's twiddles (rows 1..7) are wave-uniform and come through the scalar cache; the per-thread rows of the other
+// passes are fetched through a buffer descriptor, one pass ahead of their use.
+// [0, 2m) -> [0, m) for a thread's 8 x 2 values
+__device__ __forceinline__ void canonicalize8(uint32_t* lo, uint32_t* hi) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        lo[k] = csub_min(lo[k], kP);
+        hi[k] = csub_min(hi[k], kB);
+    }
+}
+template <bool CANONICAL = true>
 __device__ __forceinline__ void ntt_forward_block(uint32_t* lo, uint32_t* hi, uint64_t* sh, const uint4* tw, uint32_t tid) {
-#ifndef NTT_NO_PREFETCH_TW  // twiddles of the next pass are requested before the current pass's arithmetic (-3..4 % on the NTT-bound stages)
-    Tw7 wb = tw_load8(tw, 8 + (tid >> 5), 16 + 2 * (tid >> 5), 32 + 4 * (tid >> 5));
+    const TwTable tb(tw);
+    Tw7 wb = tw_load8(tb, 8 + (tid >> 5), 16 + 2 * (tid >> 5), 32 + 4 * (tid >> 5));
     ct_radix8(lo, hi, tw, 1, 2, 4);
     lds_put<ix_a>(sh, tid, lo, hi);
     NTT_SYNC();
     lds_get<ix_b>(sh, tid, lo, hi);
-    Tw7 wc = tw_load8(tw, 64 + (tid >> 2), 128 + 2 * (tid >> 2), 256 + 4 * (tid >> 2));
+    Tw7 wc = tw_load8(tb, 64 + (tid >> 2), 128 + 2 * (tid >> 2), 256 + 4 * (tid >> 2));
     ct_radix8_pre(lo, hi, wb);
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        lo[k] = lazy_reduce(lo[k], kP);
-        hi[k] = lazy_reduce(hi[k], kB);
-    }
     lds_put<ix_b>(sh, tid, lo, hi);
     NTT_SYNC();
     lds_get<ix_c>(sh, tid, lo, hi);
-    Tw7 wd = tw_load4x2(tw, 512 + 2 * tid, 1024 + 4 * tid);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        lo[k] = lazy_reduce(lo[k], kP);
+        hi[k] = lazy_reduce(hi[k], kB);
+    }
+    Tw7 wd = tw_load4x2(tb, 512 + 2 * tid, 1024 + 4 * tid);
     ct_radix8_pre(lo, hi, wc);
     lds_put<ix_c>(sh, tid, lo, hi);
     NTT_SYNC();
     lds_get<ix_d>(sh, tid, lo, hi);
     ct_radix4x2_pre(lo, hi, wd);
-#else
-    ct_radix8(lo, hi, tw, 1, 2, 4);
-    lds_put<ix_a>(sh, tid, lo, hi);
-    NTT_SYNC();
-    lds_get<ix_b>(sh, tid, lo, hi);
-    uint32_t g = tid >> 5;
-    ct_radix8(lo, hi, tw, 8 + g, 16 + 2 * g, 32 + 4 * g);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         lo[k] = lazy_reduce(lo[k], kP);
         hi[k] = lazy_reduce(hi[k], kB);
-    }
-    lds_put<ix_b>(sh, tid, lo, hi);
-    NTT_SYNC();
-    lds_get<ix_c>(sh, tid, lo, hi);
-    g = tid >> 2;
-    ct_radix8(lo, hi, tw, 64 + g, 128 + 2 * g, 256 + 4 * g);
-    lds_put<ix_c>(sh, tid, lo, hi);
-    NTT_SYNC();
-    lds_get<ix_d>(sh, tid, lo, hi);
-    ct_radix4x2(lo, hi, tw, 512 + 2 * tid, 1024 + 4 * tid);
-#endif
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        lo[k] = csub_min(lazy_reduce(lo[k], kP), kP);
-        hi[k] = csub_min(lazy_reduce(hi[k], kB), kB);
+        if constexpr (CANONICAL) {
+            lo[k] = csub_min(lo[k], kP);
+            hi[k] = csub_min(hi[k], kB);
+        }
     }
 }
 
@@ -308,14 +322,15 @@ __device__ __forceinline__ void ntt_forward_block(uint32_t* lo, uint32_t* hi, ui
 // out (lo,hi)[k] <-> coefficient ix_a(tid,k) = tid + 256k, canonical in [0, m).
 // Bounds: sum side < 2m + 11 * m/2 = 7.5m, product side < 2m: every t = u + 8m - v is in (0, 15.5m).
 __device__ __forceinline__ void ntt_inverse_block(uint32_t* lo, uint32_t* hi, uint64_t* sh, const uint4* tw, uint32_t tid) {
-#ifndef NTT_NO_PREFETCH_TW  // as in the forward transform: the next pass's twiddles are in flight during the current pass
-    Tw7 wd = tw_load4x2(tw, 512 + 2 * tid, 1024 + 4 * tid);
-    Tw7 wc = tw_load8(tw, 64 + (tid >> 2), 128 + 2 * (tid >> 2), 256 + 4 * (tid >> 2));
+    // as in the forward transform: the next pass's twiddles are in flight during the current pass
+    const TwTable tb(tw);
+    Tw7 wd = tw_load4x2(tb, 512 + 2 * tid, 1024 + 4 * tid);
+    Tw7 wc = tw_load8(tb, 64 + (tid >> 2), 128 + 2 * (tid >> 2), 256 + 4 * (tid >> 2));
     gs_radix4x2_pre(lo, hi, wd);
     lds_put<ix_d>(sh, tid, lo, hi);
     __syncthreads();
     lds_get<ix_c>(sh, tid, lo, hi);
-    Tw7 wb = tw_load8(tw, 8 + (tid >> 5), 16 + 2 * (tid >> 5), 32 + 4 * (tid >> 5));
+    Tw7 wb = tw_load8(tb, 8 + (tid >> 5), 16 + 2 * (tid >> 5), 32 + 4 * (tid >> 5));
     gs_radix8_pre(lo, hi, wc);
     lds_put<ix_c>(sh, tid, lo, hi);
     __syncthreads();
@@ -326,28 +341,6 @@ __device__ __forceinline__ void ntt_inverse_block(uint32_t* lo, uint32_t* hi, ui
     __syncthreads();
     lds_get<ix_a>(sh, tid, lo, hi);
     gs_radix8_pre(lo, hi, wa);
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        lo[k] = csub_min(lazy_reduce(lo[k], kP), kP);
-        hi[k] = csub_min(lazy_reduce(hi[k], kB), kB);
-    }
-    return;
-#endif
-    gs_radix4x2(lo, hi, tw, 512 + 2 * tid, 1024 + 4 * tid);
-    lds_put<ix_d>(sh, tid, lo, hi);
-    __syncthreads();
-    lds_get<ix_c>(sh, tid, lo, hi);
-    uint32_t g = tid >> 2;
-    gs_radix8(lo, hi, tw, 64 + g, 128 + 2 * g, 256 + 4 * g);
-    lds_put<ix_c>(sh, tid, lo, hi);
-    __syncthreads();
-    lds_get<ix_b>(sh, tid, lo, hi);
-    g = tid >> 5;
-    gs_radix8(lo, hi, tw, 8 + g, 16 + 2 * g, 32 + 4 * g);
-    lds_put<ix_b>(sh, tid, lo, hi);
-    __syncthreads();
-    lds_get<ix_a>(sh, tid, lo, hi);
-    gs_radix8(lo, hi, tw, 1, 2, 4);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         lo[k] = csub_min(lazy_reduce(lo[k], kP), kP);
