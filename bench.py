@@ -141,6 +141,8 @@ def main():
                     "more to the contention, 349 -> 422 us, than the 30 us of conversion it hides); 0: everything in order on one stream")
     ap.add_argument("--event-every", type=int, default=4, help="bracket the stages with HIP events on every n-th timed step only (1 = every step)")
     ap.add_argument("--root-fold", action="store_true", help="N > 1: plain reduce to rank 0, which lifts and folds alone")
+    ap.add_argument("--replicated-expansion", action="store_true", help="N > 1: every rank runs the whole query expansion (default: each rank expands its own "
+                    "first-dimension subtree and every N-th GSW bit, one all-gather of the GSW bits)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the one-GPU self-test)")
     ap.add_argument("--shared-device", action="store_true", help="self-test: all ranks use device 0")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the reduce even with one rank (self-test)")
@@ -207,6 +209,13 @@ def main():
         sharded_fold = True
     else:
         sharded_fold = False
+    # sharded expansion: the expansion is database-independent, so N ranks would each repeat all of it; instead a rank expands the
+    # subtree above its own j-block and every N-th GSW bit, and the GSW bits are all-gathered
+    shard_expand = use_dist and not args.replicated_expansion and sdist.expand_shard_ok(shp, pg, world)
+    if shard_expand:
+        srv.set_expand_shard(rank, world)
+        bits = torch.zeros(srv.gsw_bits_words(), dtype=torch.int64, device=dev)
+        bits_all = torch.zeros(world * bits.numel(), dtype=torch.int64, device=dev)
     srv.use_graphs(not args.no_graphs)  # expand+convert and lift+fold+finish replay as two hipGraphs
     srv.set_overlap(bool(args.overlap))
 
@@ -225,10 +234,20 @@ def main():
             return
         if e:
             e[0].record(stream)
-            srv.run_pre()
+            if shard_expand:
+                srv.run_expand_pack(bits.data_ptr())
+                sdist.all_gather_gsw_bits(bits_all, bits)
+                srv.gsw_bits_unpack(bits_all.data_ptr())
+                srv.convert()
+            else:
+                srv.run_pre()
             e[1].record(stream)
             srv.first_dim()
             e[2].record(stream)
+        elif shard_expand:
+            srv.run_expand_pack(bits.data_ptr())       # this rank's share of the expansion, one graph
+            sdist.all_gather_gsw_bits(bits_all, bits)  # every rank needs every GSW bit
+            srv.run_unpack_convert_sweep(bits_all.data_ptr())
         else:
             srv.run_pre_sweep()  # one graph for everything before the collective
         if sharded_fold:
@@ -295,7 +314,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": label + ", explicit DB generated on device, sharded by first-dimension index",
                    "db_bytes_ntt_form": int(shp.dim0) * int(shp.num_per) * 4 * sa.N * 8, "schedule": "GSW conversion overlapped with the sweep (side stream)" if args.overlap else "in order, one stream",
-                   "parallelism": (f"j-shard x{world}, reduce-scatter + distributed fold + all-gather" if sharded_fold else f"j-shard x{world} + 1 reduce")},
+                   "parallelism": (f"j-shard x{world}, reduce-scatter + distributed fold + all-gather" if sharded_fold else f"j-shard x{world} + 1 reduce")
+                                  + (", sharded expansion + all-gather of the GSW bits" if shard_expand else "")},
         "queries_per_s": round(1e3 / ms_per_step, 2),
         "stages_us": {k: round(v, 1) for k, v in stages.items()},
         "reference_buckets_us_eager": ({k: round(v, 1) for k, v in detail.items() if k != "scaltomat_us"} if detail else None),

@@ -200,6 +200,20 @@ void *spiral_gpu_server_acc(spiral_gpu_server *s, size_t *bytes);
 int spiral_gpu_server_set_fold_ranks(spiral_gpu_server *s, uint32_t n_ranks);
 int spiral_gpu_server_fold_local(spiral_gpu_server *s, const void *acc_chunk, void *out_ct);
 int spiral_gpu_server_fold_root(spiral_gpu_server *s, const void *gathered_cts);
+/* Sharded expansion over G = 2^k ranks (the query expansion is database-independent, so a G-GPU answer would otherwise repeat all
+ * of it on every GPU).  set_expand_shard(rank, G): expand() then computes only what this rank needs of expandImproved's tree
+ * (src/spiral.cpp:1664-1743): the first-dimension ciphertexts of its own j-range [rank dim0/G, (rank+1) dim0/G) -- the server
+ * must have been created on exactly that range -- and every G-th GSW-bit ciphertext (i = rank mod G).  All ranks need all GSW
+ * bits (regevToGSW, :2315-2331), so they are exchanged: gsw_bits_pack writes this rank's block (gsw_bits_words() uint64 words,
+ * device pointer), ONE all-gather of the blocks in rank order, gsw_bits_unpack stores the gathered blocks; then convert() as
+ * usual.  run_expand_pack / run_unpack_convert_sweep are those steps as launch groups (hipGraphs with use_graphs on) either
+ * side of the all-gather.  Results are identical to the unsharded expansion.  Needs query compression with stopround > 0. */
+int spiral_gpu_server_set_expand_shard(spiral_gpu_server *s, uint32_t rank, uint32_t n_ranks);
+size_t spiral_gpu_server_gsw_bits_words(spiral_gpu_server *s);
+int spiral_gpu_server_gsw_bits_pack(spiral_gpu_server *s, void *block_out);
+int spiral_gpu_server_gsw_bits_unpack(spiral_gpu_server *s, const void *gathered);
+int spiral_gpu_server_run_expand_pack(spiral_gpu_server *s, void *bits_out);
+int spiral_gpu_server_run_unpack_convert_sweep(spiral_gpu_server *s, const void *gathered);
 /* make the sweep write into caller-owned device memory (e.g. a torch tensor) */
 int spiral_gpu_server_set_acc(spiral_gpu_server *s, void *device_ptr);
 

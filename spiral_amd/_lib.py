@@ -106,6 +106,12 @@ PROTOTYPES = {
     "spiral_gpu_server_set_fold_ranks": (C.c_int, [C.c_void_p, C.c_uint32]),
     "spiral_gpu_server_fold_local": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "spiral_gpu_server_fold_root": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "spiral_gpu_server_set_expand_shard": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "spiral_gpu_server_gsw_bits_words": (C.c_size_t, [C.c_void_p]),
+    "spiral_gpu_server_gsw_bits_pack": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "spiral_gpu_server_gsw_bits_unpack": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "spiral_gpu_server_run_expand_pack": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "spiral_gpu_server_run_unpack_convert_sweep": (C.c_int, [C.c_void_p, C.c_void_p]),
     "spiral_gpu_server_acc": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "spiral_gpu_server_set_acc": (C.c_int, [C.c_void_p, C.c_void_p]),
     "spiral_gpu_server_answer": (C.c_int, [C.c_void_p, U64P, U64P, U64P, C.POINTER(C.c_double)]),

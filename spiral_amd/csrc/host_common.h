@@ -133,11 +133,22 @@ inline size_t expand_g_polys(uint32_t g, uint32_t t_exp, uint32_t t_exp_right) {
     return half * ((size_t)t_exp + 1 + t_exp_right + 1);
 }
 
+// What one rank of a G = 2^g_log rank answer expands (all zero: everything).  The expanded ciphertexts end up at cv[2 j]
+// (first-dimension index j) and cv[2 i + 1] (GSW bit i) (reorderFromStopround, src/spiral.cpp:2027-2036), and slot index
+// bit r is decided in round r.  A rank needs the first-dimension ciphertexts of its own j in [rank J, (rank + 1) J),
+// J = 2^j_log: in round r <= j_log those still descend from every even ciphertext of the round, afterwards only from the
+// J whose higher slot bits spell the low bits of `rank`.  Of the GSW bits -- all ranks need all of them, for the folding
+// keys -- each rank expands those with i = rank mod G from round g_log on, and the ranks exchange them (one all-gather).
+struct ExpandShard {
+    uint32_t rank, g_log, j_log;
+};
+
 // src/spiral.cpp:1664-1743.  cv: 2^g cts (2 PK polys each).
 inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_t t_exp, const uint64_t* w_left, uint32_t t_exp_right,
                 const uint64_t* w_right, uint32_t max_bits_right, uint32_t stopround, const ExpandWork& wk, hipStream_t st,
                 const uint64_t* query = nullptr,  // query: the packed query ciphertext when cv[0] does not hold it yet
-                uint32_t r_begin = 0, uint32_t r_end = 0xffffffffu) {  // rounds [r_begin, min(r_end, g))
+                uint32_t r_begin = 0, uint32_t r_end = 0xffffffffu,  // rounds [r_begin, min(r_end, g))
+                const ExpandShard& shard = ExpandShard{}) {
     // active odd-index ciphertexts of round r (:1701-1702); the even ones are all 2^r
     auto odd_count = [&](uint32_t r) {
         const uint32_t num_in = 1u << r;
@@ -148,7 +159,20 @@ inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_
     for (uint32_t r = r_begin; r < std::min(r_end, g); r++) {
         const uint32_t num_in = 1u << r;
         const uint32_t t = (kN >> r) + 1;
-        const uint32_t cnt_even = num_in, cnt_odd = odd_count(r);
+        uint32_t cnt_even = num_in, cnt_odd = odd_count(r);
+        ExpandActive act{};
+        if (shard.g_log) {
+            if (r > shard.j_log) {  // 2^(r - j_log) blocks of J even ciphertexts: this rank's is the one its low bits name
+                cnt_even = 1u << shard.j_log;
+                act.e_off = (shard.rank & ((1u << (r - shard.j_log)) - 1u)) << shard.j_log;
+            }
+            if (r >= shard.g_log) {  // every G-th odd ciphertext, starting at `rank`
+                const uint32_t G = 1u << shard.g_log;
+                cnt_odd = cnt_odd > shard.rank ? (cnt_odd - shard.rank + G - 1u) / G : 0u;
+                act.o_stride_m1 = G - 1u;
+                act.o_off = shard.rank;
+            }
+        }
         // 1) INTT + CRT of row 0 and the automorphed row 1 (a slot permutation) of every active ct, both parities;
         //    cts with i >= num_in are neg1 * cv[i - num_in] (:1709): created inside this kernel in round 0, by the
         //    previous round's MAC afterwards
@@ -161,6 +185,7 @@ inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_
         ip.neg1s = tb.neg1s + (size_t)r * kN;
         ip.num_in = num_in;
         ip.cnt_e = cnt_even;
+        ip.act = act;
         ip.auto_t = t;
         ip.create_here = r == 0;
         ip.query = query;
@@ -184,6 +209,7 @@ inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_
         mp.a1 = wk.raw;
         mp.cnt_e = cnt_even;
         mp.cnt_o = cnt_odd;
+        mp.act = act;
         mp.t_e = t_exp;
         mp.t_o = t_exp_right;
         if (r + 1 < g) {

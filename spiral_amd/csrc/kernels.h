@@ -81,6 +81,18 @@ struct FwdParams {
 };
 void launch_ntt_forward(const DeviceTables& t, const FwdParams& p, uint32_t load, uint32_t store, uint32_t nblocks, hipStream_t s);
 
+// Which ciphertexts of an expansion round a launch works on (src/spiral.cpp:1700-1702 enumerates i < 2^(r+1), odd i only up to
+// `stopround`).  Active ciphertext a < cnt_e is the even one i = 2 (a + e_off); the others are odd, i = 2 ((a - cnt_e) *
+// (o_stride_m1 + 1) + o_off) + 1.  All zero = every ciphertext of the round (one GPU).  A rank of a G-GPU answer expands only
+// what it needs (server.cpp expand shard): the even subtree above its own first-dimension range (a contiguous block of a),
+// and of the odd ciphertexts -- the GSW bits -- every G-th.
+struct ExpandActive {
+    uint32_t e_off, o_stride_m1, o_off;
+    __host__ __device__ uint32_t index(uint32_t a, uint32_t cnt_e) const {
+        return a < cnt_e ? 2u * (a + e_off) : 2u * ((a - cnt_e) * (o_stride_m1 + 1u) + o_off) + 1u;
+    }
+};
+
 // ---- inverse NTT ---------------------------------------------------------------------------------
 enum InvStore : uint32_t {
     IST_CRT = 0,    // CRT-lifted raw coefficient in [0, Q)   (from_ntt, src/poly.cpp:357)
@@ -103,6 +115,7 @@ struct InvParams {
     const uint64_t* neg1;
     const uint64_t* neg1s;  // Shoup companions of neg1
     uint32_t num_in, cnt_e;
+    ExpandActive act;
     uint32_t auto_t;  // the round's automorphism x -> x^t
     uint32_t create_here;  // 1: cts with i >= num_in do not exist yet (round 0); 0: the previous round's MAC wrote them
     const uint64_t* query;  // create_here only, optional: cv[0] is read from here (and written to cv) instead of from cv
@@ -182,8 +195,10 @@ struct ExpandMacParams {
     const uint64_t* g;
     const uint64_t* a1;
     uint32_t cnt_e, cnt_o, t_e, t_o;
+    ExpandActive act;
     // next round's new ciphertexts cv[i + next_num_in] = neg1 * cv[i] (src/spiral.cpp:1709), written while the updated cv[i]
-    // is in registers: every even i, and odd active ct a' when a' + next_num_in/2 < next_cnt_o.  neg1n == null: none.
+    // is in registers: every even i, and odd i when (i - 1)/2 + next_num_in/2 < next_cnt_o (the whole round's count of odd
+    // ciphertexts, not a shard's).  neg1n == null: none.
     const uint64_t* neg1n;
     const uint64_t* neg1ns;  // Shoup companions
     uint32_t next_num_in, next_cnt_o;
@@ -236,6 +251,10 @@ void launch_fill_db_random(uint64_t* db_dev, uint32_t num_per, uint32_t dim0_sha
 void launch_db_read_item(const uint64_t* db_dev, uint64_t* out_ref, uint32_t num_per, uint32_t dim0_shard, uint32_t j_local, uint32_t ii, hipStream_t s);
 void launch_db_read_slots(const uint64_t* db_dev, uint64_t* out, uint32_t num_per, uint32_t dim0_shard, uint32_t z0, uint32_t nz, hipStream_t s);
 void launch_fill_db1_random(uint64_t* db_dev, uint32_t num_per, uint32_t dim0, uint64_t seed, hipStream_t s);
+// the GSW-bit ciphertexts (odd slots 2 i + 1 of cv, i < n_bits) a rank of a G-rank answer expanded itself (i = a G + rank) <->
+// its block of the all-gather buffer [rank][a < n_max][2 polynomials]; pack: cv -> this rank's block, unpack: all blocks -> cv
+void launch_gsw_bits_pack(const uint64_t* cv, uint64_t* block, uint32_t rank, uint32_t n_ranks, uint32_t n_bits, hipStream_t s);
+void launch_gsw_bits_unpack(uint64_t* cv, const uint64_t* gathered, uint32_t n_ranks, uint32_t n_bits, hipStream_t s);
 
 // ---- SpiralPack (pack.hip; reference src/testing.cpp) -----------------------------------------------------------
 // device DB layout, 1 x 1 plaintexts.  Packed (dim0 % 16 == 0; as the base path's, common.h): a word is two 28-bit

@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void ntt_inverse_kernel(Tables t, InvParams p)
     uint32_t lo[8], hi[8];
     if constexpr (EXPAND) {
         const uint32_t a = b >> 1, row = b & 1u;
-        const uint32_t i = a < p.cnt_e ? 2u * a : 2u * (a - p.cnt_e) + 1u;
+        const uint32_t i = p.act.index(a, p.cnt_e);
 #ifdef EXP_ABL_NO_ROW1
         if (row == 1) return;
 #endif

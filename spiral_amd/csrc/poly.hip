@@ -193,13 +193,12 @@ __global__ __launch_bounds__(kTpb) void expand_mac_round_kernel(ExpandMacParams 
     const uint32_t zz = threadIdx.x & 63u, kg = threadIdx.x >> 6, z = blockIdx.x * 64u + zz, a = blockIdx.y;
     const bool odd = a >= p.cnt_e;
     const uint32_t tdim = odd ? p.t_o : p.t_e;
-    const uint32_t i = odd ? 2u * (a - p.cnt_e) + 1u : 2u * a;
+    const uint32_t i = p.act.index(a, p.cnt_e);
     const size_t gbase = odd ? (size_t)p.cnt_e * p.t_e + (size_t)(a - p.cnt_e) * p.t_o : (size_t)a * p.t_e;
     const uint64_t* w = (odd ? p.w_o : p.w_e) + z;
     const uint64_t* gp = p.g + gbase * kN + z;
     // next round's neg1 words are cold: request them before the MAC loop
-    const uint32_t ao = a - p.cnt_e;
-    const bool make_next = kg == 0 && p.neg1n != nullptr && (!odd || ao + (p.next_num_in >> 1) < p.next_cnt_o);
+    const bool make_next = kg == 0 && p.neg1n != nullptr && (!odd || (i >> 1) + (p.next_num_in >> 1) < p.next_cnt_o);
     uint64_t nw = 0, nws = 0;
     if (make_next) {
         nw = p.neg1n[z];
@@ -250,12 +249,11 @@ __global__ __launch_bounds__(kTpb) void expand_mac_round_wide_kernel(ExpandMacPa
     const uint32_t zz = threadIdx.x & 63u, kg = threadIdx.x >> 6, z = (blockIdx.x * 64u + zz) * 2u, a = blockIdx.y;
     const bool odd = a >= p.cnt_e;
     const uint32_t tdim = odd ? p.t_o : p.t_e;
-    const uint32_t i = odd ? 2u * (a - p.cnt_e) + 1u : 2u * a;
+    const uint32_t i = p.act.index(a, p.cnt_e);
     const size_t gbase = odd ? (size_t)p.cnt_e * p.t_e + (size_t)(a - p.cnt_e) * p.t_o : (size_t)a * p.t_e;
     const uint64_t* w = (odd ? p.w_o : p.w_e) + z;
     const uint64_t* gp = p.g + gbase * kN + z;
-    const uint32_t ao = a - p.cnt_e;
-    const bool make_next = kg == 0 && p.neg1n != nullptr && (!odd || ao + (p.next_num_in >> 1) < p.next_cnt_o);
+    const bool make_next = kg == 0 && p.neg1n != nullptr && (!odd || (i >> 1) + (p.next_num_in >> 1) < p.next_cnt_o);
     u64x2_t nw = {0, 0}, nws = {0, 0};
     if (make_next) {
         nw = *reinterpret_cast<const u64x2_t*>(p.neg1n + z);
@@ -485,6 +483,27 @@ __global__ __launch_bounds__(kTpb) void fold_key_from_reoriented_kernel(const ui
 }
 void launch_fold_key_from_reoriented(const uint64_t* q_re, const uint64_t* qneg_re, uint64_t* key, uint32_t m2, hipStream_t s) {
     hipLaunchKernelGGL(fold_key_from_reoriented_kernel, dim3(kBpp, 3 * m2), dim3(kTpb), 0, s, q_re, qneg_re, key, m2);
+}
+
+// ---- exchange of the GSW-bit ciphertexts of a sharded expansion (kernels.h) -------------------------------------------------
+__global__ __launch_bounds__(kTpb) void gsw_bits_copy_kernel(uint64_t* cv, uint64_t* buf, uint32_t rank, uint32_t n_ranks, uint32_t n_bits, uint32_t n_max, int unpack) {
+    const uint32_t z = blockIdx.x * kTpb + threadIdx.x, row = blockIdx.y & 1u, slot = blockIdx.y >> 1;  // slot = r * n_max + a (unpack) or a (pack)
+    const uint32_t r = unpack ? slot / n_max : rank, a = unpack ? slot - r * n_max : slot, i = a * n_ranks + r;
+    if (i >= n_bits) return;
+    uint64_t* c = cv + ((size_t)(2u * i + 1u) * 2u + row) * kN + z;
+    uint64_t* b = buf + ((size_t)slot * 2u + row) * kN + z;
+    if (unpack)
+        *c = *b;
+    else
+        *b = *c;
+}
+void launch_gsw_bits_pack(const uint64_t* cv, uint64_t* block, uint32_t rank, uint32_t n_ranks, uint32_t n_bits, hipStream_t s) {
+    const uint32_t n_max = (n_bits + n_ranks - 1) / n_ranks;
+    if (n_max) hipLaunchKernelGGL(gsw_bits_copy_kernel, dim3(kBpp, 2 * n_max), dim3(kTpb), 0, s, const_cast<uint64_t*>(cv), block, rank, n_ranks, n_bits, n_max, 0);
+}
+void launch_gsw_bits_unpack(uint64_t* cv, const uint64_t* gathered, uint32_t n_ranks, uint32_t n_bits, hipStream_t s) {
+    const uint32_t n_max = (n_bits + n_ranks - 1) / n_ranks;
+    if (n_max) hipLaunchKernelGGL(gsw_bits_copy_kernel, dim3(kBpp, 2 * n_max * n_ranks), dim3(kTpb), 0, s, cv, const_cast<uint64_t*>(gathered), 0u, n_ranks, n_bits, n_max, 1);
 }
 
 }  // namespace spiral

@@ -40,7 +40,7 @@ struct spiral_gpu_server {
     // reduce_first; instantiated lazily, invalidated when a captured pointer or flag changes
     bool use_graphs = false;
     // [3] = Regev->GSW conversion on the side stream, [4] = whole query, [5] = fold_local, [6] = fold_root, [7] = run_pre + sweep
-    hipGraphExec_t graph[8] = {};
+    hipGraphExec_t graph[10] = {};  // [8] = sharded expansion + pack, [9] = unpack + convert + sweep
     const void *cap_chunk = nullptr, *cap_gathered = nullptr;
     void* cap_ct = nullptr;  // the caller's buffers captured into graphs 5 and 6
     // overlap mode: run_pre forks the Regev->GSW conversion (needed only by the folding) onto side_stream so that it
@@ -54,6 +54,9 @@ struct spiral_gpu_server {
     bool fold_chain = true;
     uint32_t fold_blocks = 768;
     uint32_t fold_g_log = 0;  // distributed fold over 2^fold_g_log ranks: the sweep groups its output by ii mod G
+    ExpandShard ex_shard{};   // sharded expansion (set_expand_shard): what this rank expands itself
+    const void* cap_bits_out = nullptr;  // the caller's exchange buffers captured into graphs 8 and 9
+    const void* cap_bits_in = nullptr;
 };
 
 namespace {
@@ -783,7 +786,7 @@ int spiral_gpu_server_expand(spiral_gpu_server* S) {
     }
     ExpandWork wk{S->ex_raw.p, S->ex_g.p};
     run_expand(S->tb, S->cv.p, S->s.g, p.t_exp, S->w_left.p, p.t_exp_right, S->w_right.p, S->s.ell * p.nu2, S->s.stopround, wk, S->stream,
-               S->s.g ? S->query.p : nullptr);
+               S->s.g ? S->query.p : nullptr, 0, 0xffffffffu, S->ex_shard);
     if (S->s.g == 0) HIP_OK(hipMemcpyAsync(S->cv.p, S->query.p, 2 * kPolyBytes, hipMemcpyDeviceToDevice, S->stream));
     return 0;
 }
@@ -1015,6 +1018,46 @@ int spiral_gpu_server_set_fold_ranks(spiral_gpu_server* S, uint32_t n_ranks) {
     return 0;
 }
 
+// Sharded expansion for one rank of an n_ranks-GPU answer.  After it, expand() leaves this rank with
+// the first-dimension ciphertexts of its own j-range (which must be the contiguous block `rank` of n_ranks equal ones) and
+// with the GSW bits i = rank mod n_ranks; gsw_bits_pack / one all-gather / gsw_bits_unpack give every rank all of them
+// before convert().  Needs the reordered layout (stopround > 0, src/spiral.cpp:2027-2036) and query compression.
+int spiral_gpu_server_set_expand_shard(spiral_gpu_server* S, uint32_t rank, uint32_t n_ranks) {
+    if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
+    srv_drop_graphs(S);
+    if (n_ranks <= 1) {
+        S->ex_shard = ExpandShard{};
+        return 0;
+    }
+    if ((n_ranks & (n_ranks - 1)) || n_ranks > S->s.dim0 || rank >= n_ranks) return fail("expansion shard %u of %u: the rank count must be a power of two <= dim0", rank, n_ranks);
+    if (S->p.direct_upload || S->s.stopround == 0) return fail("sharded expansion needs query compression with stopround > 0");
+    const uint32_t per = S->s.dim0 / n_ranks;
+    if (S->j0 != rank * per || S->j1 != (rank + 1) * per) return fail("sharded expansion: this server must hold first-dimension block %u of %u, it holds [%u, %u)", rank, n_ranks, S->j0, S->j1);
+    S->ex_shard = ExpandShard{rank, ceil_log2(n_ranks), S->p.nu1 - ceil_log2(n_ranks)};
+    return 0;
+}
+
+size_t spiral_gpu_server_gsw_bits_words(spiral_gpu_server* S) {
+    if (!S) return 0;
+    const uint32_t G = 1u << S->ex_shard.g_log, n_bits = S->s.ell * S->p.nu2;
+    return (size_t)((n_bits + G - 1) / G) * 2 * kN;
+}
+
+int spiral_gpu_server_gsw_bits_pack(spiral_gpu_server* S, void* block_out) {
+    if (!S || !block_out) return fail("null argument");
+    HIP_OK(hipSetDevice(S->device));
+    launch_gsw_bits_pack(S->cv.p, (uint64_t*)block_out, S->ex_shard.rank, 1u << S->ex_shard.g_log, S->s.ell * S->p.nu2, S->stream);
+    return 0;
+}
+
+int spiral_gpu_server_gsw_bits_unpack(spiral_gpu_server* S, const void* gathered) {
+    if (!S || !gathered) return fail("null argument");
+    HIP_OK(hipSetDevice(S->device));
+    launch_gsw_bits_unpack(S->cv.p, (const uint64_t*)gathered, 1u << S->ex_shard.g_log, S->s.ell * S->p.nu2, S->stream);
+    return 0;
+}
+
 int spiral_gpu_server_finish(spiral_gpu_server* S) {
     if (!S) return fail("null server");
     HIP_OK(hipSetDevice(S->device));
@@ -1160,6 +1203,39 @@ int spiral_gpu_server_run_pre_sweep(spiral_gpu_server* S) {
     }
     return run_group(S, 7, S->stream, [&]() {
         if (expand_convert(S)) return -1;
+        return spiral_gpu_server_first_dim(S);
+    });
+}
+
+// the two halves of everything before the accumulator reduce when the expansion is sharded: run_expand_pack = expand + pack of
+// this rank's GSW bits into bits_out; [all-gather]; run_unpack_convert_sweep = unpack of the gathered blocks + convert + sweep
+int spiral_gpu_server_run_expand_pack(spiral_gpu_server* S, void* bits_out) {
+    if (!S || !bits_out) return fail("null argument");
+    HIP_OK(hipSetDevice(S->device));
+    if (!S->have_query || !S->have_pp) return fail("query and public parameters must be set first");
+    if (S->graph[8] && S->cap_bits_out != bits_out) {
+        (void)hipGraphExecDestroy(S->graph[8]);
+        S->graph[8] = nullptr;
+    }
+    S->cap_bits_out = bits_out;
+    return run_group(S, 8, S->stream, [&]() {
+        if (spiral_gpu_server_expand(S)) return -1;
+        return spiral_gpu_server_gsw_bits_pack(S, bits_out);
+    });
+}
+
+int spiral_gpu_server_run_unpack_convert_sweep(spiral_gpu_server* S, const void* gathered) {
+    if (!S || !gathered) return fail("null argument");
+    HIP_OK(hipSetDevice(S->device));
+    if (!S->have_db) return fail("no database loaded");
+    if (S->graph[9] && S->cap_bits_in != gathered) {
+        (void)hipGraphExecDestroy(S->graph[9]);
+        S->graph[9] = nullptr;
+    }
+    S->cap_bits_in = gathered;
+    return run_group(S, 9, S->stream, [&]() {
+        if (spiral_gpu_server_gsw_bits_unpack(S, gathered)) return -1;
+        if (spiral_gpu_server_convert(S)) return -1;
         return spiral_gpu_server_first_dim(S);
     });
 }

@@ -58,3 +58,16 @@ def all_gather_cts(gathered, ct, group=None):
 def fold_ranks(world: int, num_per: int) -> int:
     """ranks taking part in the distributed fold: all of them when they divide num_per, else 1 (root folds alone)"""
     return world if world >= 1 and (world & (world - 1)) == 0 and world <= num_per else 1
+
+
+def all_gather_gsw_bits(gathered, mine, group=None):
+    """sharded expansion: collect the ranks' blocks of GSW-bit ciphertexts in rank order (1.8 MiB in all at config 2)"""
+    import torch.distributed as dist
+
+    dist.all_gather_into_tensor(gathered, mine, group=group)
+    return gathered
+
+
+def expand_shard_ok(shape, params, world: int) -> bool:
+    """can the expansion be sharded over `world` ranks: query compression with the reordered layout, power-of-two ranks"""
+    return world >= 1 and (world & (world - 1)) == 0 and not params.direct_upload and shape.stopround > 0 and world <= shape.dim0

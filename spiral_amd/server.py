@@ -133,6 +133,27 @@ class Server:
         """last log2(G) folding rounds + response switch on the G gathered cts (rank order)"""
         check(lib().spiral_gpu_server_fold_root(self.h, C.c_void_p(gathered_ptr)))
 
+    def set_expand_shard(self, rank: int, n_ranks: int):
+        """expand only what rank `rank` of an n_ranks-GPU answer needs (own first-dimension block, every n_ranks-th GSW bit)"""
+        check(lib().spiral_gpu_server_set_expand_shard(self.h, rank, n_ranks))
+
+    def gsw_bits_words(self) -> int:
+        return int(lib().spiral_gpu_server_gsw_bits_words(self.h))
+
+    def gsw_bits_pack(self, block_ptr: int):
+        check(lib().spiral_gpu_server_gsw_bits_pack(self.h, C.c_void_p(block_ptr)))
+
+    def gsw_bits_unpack(self, gathered_ptr: int):
+        check(lib().spiral_gpu_server_gsw_bits_unpack(self.h, C.c_void_p(gathered_ptr)))
+
+    def run_expand_pack(self, block_ptr: int):
+        """sharded expansion + pack of this rank's GSW bits (one hipGraph replay when graphs are on)"""
+        check(lib().spiral_gpu_server_run_expand_pack(self.h, C.c_void_p(block_ptr)))
+
+    def run_unpack_convert_sweep(self, gathered_ptr: int):
+        """unpack of the all-gathered GSW bits + convert + first_dim (one hipGraph replay when graphs are on)"""
+        check(lib().spiral_gpu_server_run_unpack_convert_sweep(self.h, C.c_void_p(gathered_ptr)))
+
     def acc(self):
         nbytes = C.c_size_t()
         ptr = lib().spiral_gpu_server_acc(self.h, C.byref(nbytes))

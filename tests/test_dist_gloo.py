@@ -154,3 +154,95 @@ def test_shard_range_partition():
         sdist.shard_range(0, 3, 256)
     with pytest.raises(ValueError):
         sdist.shard_range(0, 32, 256)  # beyond the carry-safe bound of the packed sum
+
+
+def _expand_shard_with_oracle(O, po, s, cv, wl, wr, rank, G):
+    """expandImproved (src/spiral.cpp:1664-1743) restricted to what rank `rank` of G needs -- the even subtree above its own
+    first-dimension block and every G-th odd (GSW bit) ciphertext -- with the oracle's primitives as the kernels: the
+    schedule of spiral_amd/csrc/host_common.h run_expand (ExpandShard), restated"""
+    k, j_log = int(np.log2(G)), po.nu1 - int(np.log2(G))
+    wl = wl.reshape(s.n_left, 2, po.t_exp, 2, O.N)
+    wr = wr.reshape(s.n_right, 2, po.t_exp_right, 2, O.N)
+    max_bits = s.ell * po.nu2
+    for r in range(s.g):
+        num_in, t = 1 << r, (O.N >> r) + 1
+        raw = np.zeros((1, O.N), dtype=np.uint64)
+        raw[0, O.N - num_in] = 1
+        neg1 = O.to_ntt(O.invert(raw))[0]
+        odd_total = 0 if r > s.stopround else (min(num_in, max_bits + 1) if r == s.stopround else num_in)
+        if r > j_log:
+            off = (rank & ((1 << (r - j_log)) - 1)) << j_log
+            even = [2 * (a + off) for a in range(1 << j_log)]
+        else:
+            even = [2 * a for a in range(num_in)]
+        odd = [2 * a + 1 for a in range(odd_total) if r < k or a % G == rank]
+        active = even + odd
+        for i in active:  # the ciphertexts this round creates (:1709), wherever this rank still holds the parent
+            if i >= num_in:
+                cv[i] = O.mul_by_const(neg1, cv[i - num_in])
+        for i in active:
+            gdim, W = (po.t_exp_right, wr[r]) if i & 1 else (po.t_exp, wl[r])
+            ca = O.automorph(O.from_ntt(cv[i]), t)
+            g_ntt = O.to_ntt(O.gadget_invert(ca[:1].reshape(1, 1, O.N), gdim, 1).reshape(gdim, O.N), reduce=False).reshape(gdim, 1, 2, O.N)
+            upd = O.multiply(np.ascontiguousarray(W), g_ntt)
+            upd[1] = O.add(upd[1], O.to_ntt(ca[1:2]))
+            cv[i] = O.add(cv[i], upd[:, 0])
+    return cv
+
+
+def _worker_sharded_expansion(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+
+    from oracle import pyoracle as O
+    from spiral_amd import dist as sdist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    kw = dict(t_gsw=4)
+    po = O.make_params(3, 2, **kw)
+    s = O.shape_of(po)
+    assert s.stopround > 0 and sdist.expand_shard_ok(s, po, world)
+    cl = O.Client(po, seed=5)
+    wl, wr, w, v = cl.pub_params()
+    qy = cl.query(13)
+    cv = np.zeros((1 << s.g, 2, 2, O.N), dtype=np.uint64)
+    cv[0] = qy.reshape(2, 2, O.N)
+    cv = _expand_shard_with_oracle(O, po, s, cv, wl, wr, rank, world)
+    n_bits = s.ell * po.nu2
+    n_max = (n_bits + world - 1) // world
+    mine = np.zeros((n_max, 2, 2, O.N), dtype=np.uint64)  # gsw_bits_pack: bit i = a * world + rank
+    for a in range(n_max):
+        if a * world + rank < n_bits:
+            mine[a] = cv[2 * (a * world + rank) + 1]
+    gathered = torch.zeros(world * mine.size, dtype=torch.int64)
+    sdist.all_gather_gsw_bits(gathered, torch.from_numpy(mine.view(np.int64).reshape(-1).copy()))
+    blocks = gathered.numpy().view(np.uint64).reshape(world, n_max, 2, 2, O.N)
+    for r in range(world):  # gsw_bits_unpack
+        for a in range(n_max):
+            if a * world + r < n_bits:
+                cv[2 * (a * world + r) + 1] = blocks[r, a]
+    want = O.stage_expand(po, qy, wl, wr)  # [first-dimension cts | GSW bits], reordered
+    j0, j1 = sdist.shard_range(rank, world, s.dim0)
+    ok = all((cv[2 * j] == want[j]).all() for j in range(j0, j1)) and all((cv[2 * i + 1] == want[s.dim0 + i]).all() for i in range(n_bits))
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_expansion_equals_full_expansion():
+    """each rank expands its own subtree + every second GSW bit, one all-gather of the bits: every rank ends up with exactly
+    the ciphertexts of the full expansion it needs (its own first-dimension block, all GSW bits)"""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sharded_expansion, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == {0: True, 1: True}

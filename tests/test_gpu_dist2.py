@@ -21,7 +21,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, root_fold, q):
+def _worker(rank, world, port, root_fold, shard_expand, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
@@ -55,6 +55,10 @@ def _worker(rank, world, port, root_fold, q):
     chunk = torch.zeros(words // G, dtype=torch.int64, device=dev)
     ct = torch.zeros(6 * sa.N, dtype=torch.int64, device=dev)
     gathered = torch.zeros(G * 6 * sa.N, dtype=torch.int64, device=dev)
+    if shard_expand:  # each rank expands its own subtree and every world-th GSW bit; the bits are all-gathered
+        srv.set_expand_shard(rank, world)
+        bits = torch.zeros(srv.gsw_bits_words(), dtype=torch.int64, device=dev)
+        bits_all = torch.zeros(world * bits.numel(), dtype=torch.int64, device=dev)
     srv.use_graphs(True)
     ok = True
     db = O.gen_db(po, 5) if rank == 0 else None
@@ -62,7 +66,12 @@ def _worker(rank, world, port, root_fold, q):
         for idx in (9, 200, 255, 9):
             qy = cl.query(idx)
             srv.set_query(qy)
-            srv.run_pre_sweep()
+            if shard_expand:
+                srv.run_expand_pack(bits.data_ptr())
+                sdist.all_gather_gsw_bits(bits_all, bits)
+                srv.run_unpack_convert_sweep(bits_all.data_ptr())
+            else:
+                srv.run_pre_sweep()
             if root_fold:
                 sdist.reduce_accumulators(acc, dst=0)
                 if rank == 0:
@@ -85,14 +94,14 @@ def _worker(rank, world, port, root_fold, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("root_fold", [False, True])
-def test_two_processes_one_gpu(root_fold):
+@pytest.mark.parametrize("root_fold,shard_expand", [(False, False), (True, False), (False, True), (True, True)])
+def test_two_processes_one_gpu(root_fold, shard_expand):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, root_fold, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, root_fold, shard_expand, q)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -115,7 +124,7 @@ def test_bench_two_rank_flow_on_one_gpu():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["value"] > 0 and out["scaling"] == "strong"
     assert out["roofline"]["bound"] == "hbm" and out["roofline"]["achieved"] > 0
-    assert "reduce-scatter" in out["config"]["parallelism"]
+    assert "reduce-scatter" in out["config"]["parallelism"] and "sharded expansion" in out["config"]["parallelism"]
 
 
 @pytest.mark.parametrize("extra", [[], ["--root-fold"]])

@@ -525,3 +525,63 @@ def test_raw_ingest_matches_load_db(sa, oracle, nu1, nu2, p_db, bits, monkeypatc
             srv.load_db_items(O.pack_items(bad, bits), bits)
     srv.close()
     half.close()
+
+
+@pytest.mark.parametrize("nu1,nu2,kw,G,graphs", [(4, 4, dict(t_gsw=4), 2, False), (4, 4, dict(t_gsw=4), 4, True), (4, 4, dict(t_gsw=4), 8, False),
+                                                  (6, 2, {}, 4, False), (5, 3, dict(t_gsw=8), 8, True), (8, 2, dict(t_gsw=4), 16, False)])
+def test_sharded_expansion_emulated_on_one_gpu(sa, oracle, nu1, nu2, kw, G, graphs):
+    """every rank expands only the subtree above its own first-dimension block and every G-th GSW bit, the blocks of GSW bits
+    are all-gathered (torch.cat stands in for the collective), and from there the answer runs as in the unsharded N-GPU flow:
+    ScalToMat outputs of each rank's block, the GSW matrices on every rank and the final answer must equal the oracle's"""
+    import torch
+    from spiral_amd import server as SV
+
+    O = oracle
+    po, pg = O.make_params(nu1, nu2, **kw), sa.make_params(nu1, nu2, **kw)
+    s = O.shape_of(po)
+    assert s.stopround > 0
+    cl = O.Client(po, seed=41)
+    wl, wr, w, v = cl.pub_params()
+    db = O.gen_db(po, 19)
+    dev = torch.device("cuda", 0)
+    words = s.num_per * 6 * N
+    per = s.dim0 // G
+    srvs, accs, blocks = [], [], []
+    for g in range(G):
+        srv = sa.Server(pg, 0, g * per, (g + 1) * per)
+        srv.gen_db(19)
+        srv.set_pub_params(wl, wr, w, v)
+        srv.set_expand_shard(g, G)
+        srv.keep_cts(True)
+        accs.append(torch.zeros(words, dtype=torch.int64, device=dev))
+        srv.set_acc(accs[g].data_ptr())
+        blocks.append(torch.zeros(srv.gsw_bits_words(), dtype=torch.int64, device=dev))
+        srv.use_graphs(graphs)
+        srvs.append(srv)
+    gathered = torch.zeros(G * blocks[0].numel(), dtype=torch.int64, device=dev)
+    total = s.dim0 * s.num_per
+    for idx in ((total - 1, 5, total // 2) if graphs else (total // 3,)):
+        q = cl.query(idx)
+        cts, gsw = O.stage_convert(po, O.stage_expand(po, q, wl, wr), w, v)
+        for g in range(G):
+            srvs[g].set_query(q)
+            srvs[g].run_expand_pack(blocks[g].data_ptr())
+            srvs[g].sync()
+        gathered.copy_(torch.cat(blocks))  # the all-gather
+        torch.cuda.synchronize()
+        for g in range(G):
+            srvs[g].run_unpack_convert_sweep(gathered.data_ptr())
+            srvs[g].sync()
+            assert_eq(srvs[g].read(SV.BUF_CTS), cts[g * per:(g + 1) * per], f"rank {g}: scalToMat outputs of its own block")
+            assert_eq(srvs[g].read(SV.BUF_GSW), gsw, f"rank {g}: regevToGSW outputs")
+        srvs[0].set_acc(0)  # root folds alone from the summed accumulators
+        tot = torch.stack(accs).sum(0)
+        torch.cuda.synchronize()
+        srvs[0].set_acc(tot.data_ptr())
+        srvs[0].run_post(reduce_first=True)
+        srvs[0].sync()
+        assert_eq(srvs[0].read(SV.BUF_FINAL), O.answer(po, q, wl, wr, w, v, db), f"answer with sharded expansion, G={G} idx={idx}")
+        assert_eq(cl.decode(srvs[0].read(SV.BUF_RESPONSE)), O.db_item(po, 19, idx), "decoded plaintext")
+        srvs[0].set_acc(accs[0].data_ptr())
+    for srv in srvs:
+        srv.close()
