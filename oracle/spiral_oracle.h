@@ -15,6 +15,11 @@
  *   (3) the end-to-end "Is correct?" check (src/spiral.cpp:1412-1494): a query generated and decoded
  *       by the oracle's restated client must decrypt to the database item.
  *
+ * (Round 2 added data pins for the parameter-selection side only -- tests/golden/scheme_model.json: the published
+ * parameter table and 600 outputs of the reference's generate_all_schemes.py -- which pin spiral_amd/scheme.py, not this
+ * file.)  The `native` Makefile target builds the same sources with -march=native -fopenmp for the full-size parity tests
+ * and bench.py's all-cores baseline; orc_set_threads() enables the `omp parallel for`s, results are identical.
+ *
  * Layouts are the reference's: NTT-form polynomial = [2 limbs][2048] u64 residues (limb 0 mod p,
  * limb 1 mod b); raw polynomial = [2048] u64 in [0,Q]; matrices row-major (include/poly.h:24-64).
  */
