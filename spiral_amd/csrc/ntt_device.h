@@ -72,7 +72,11 @@ __device__ __forceinline__ void gs_bfly(uint32_t& u, uint32_t& v, uint32_t w, ui
     const uint32_t t = u + 8 * m - v;
     const uint32_t s = u + v;
     u = (s + ((s & 1u) ? m : 0u)) >> 1;
+#ifdef NTT_ABLATE_ALU
+    v = t ^ w;
+#else
     v = shoup(t, w, ws, m);
+#endif
 }
 
 __device__ __forceinline__ void ct2(uint32_t* lo, uint32_t* hi, int a, int b, uint4 tw) {
@@ -200,7 +204,10 @@ __device__ __forceinline__ void gs_radix4x2_pre(uint32_t* lo, uint32_t* hi, cons
 // ---- LDS tile -----------------------------------------------------------------------------------
 // 2048 packed coefficients; +4 words of padding per 32 keeps the stride-32 and stride-8 access
 // patterns of passes C and D off a single bank
-constexpr uint32_t kLdsWords = kN + (kN >> 5) * 4;
+#ifndef NTT_LDS_EXTRA_WORDS  // tuning only: extra LDS per workgroup, to limit the workgroups resident on a CU
+#define NTT_LDS_EXTRA_WORDS 0
+#endif
+constexpr uint32_t kLdsWords = kN + (kN >> 5) * 4 + NTT_LDS_EXTRA_WORDS;
 __device__ __forceinline__ uint32_t lds_ix(uint32_t i) { return i + ((i >> 5) << 2); }
 
 // coefficient index held in register k by thread `tid` in each pass
