@@ -127,12 +127,58 @@ WORKLOADS = {
 }
 
 
+def bench_pack(args):
+    """--workload pack: BASELINE.json configs[4], SpiralPack 2^18 x 30 KB (all_parameter_choices.txt "(18, 30000)"/spiral-pack:
+    nu1=10, nu2=8, n=4, p=256, q'=2^20, t_GSW=8, t_conv=4, t_exp=16) -- 16 trial databases of 4 GiB, one GPU.  A step is one
+    whole answer (expansion, conversion, 16 first-dimension sweeps, folding, packing, modulus switch), timed on the host
+    around PackServer.answer (query upload and response download included: 64 KiB + 160 KiB against 11 ms)."""
+    import numpy as np
+    import torch
+
+    import spiral_amd as sa
+
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
+        raise SystemExit("--workload pack runs on one GPU")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    out_n = 4
+    pg = sa.make_params(10, 8, t_gsw=8, t_conv=4, t_exp=16, t_exp_right=56, qprime_bits=20, p_db=256)
+    shp = sa.get_pack_shape(pg, out_n)
+    srv = sa.PackServer(pg, out_n)
+    srv.gen_db(2024)
+    rng = np.random.default_rng(1)
+    srv.set_pub_params(synth_residues(rng, np, (shp.n_left, 2, pg.t_exp)), synth_residues(rng, np, (shp.n_right, 2, pg.t_exp_right)),
+                       synth_residues(rng, np, (2, 2 * pg.t_conv)), synth_residues(rng, np, (out_n, out_n + 1, pg.t_conv)))
+    q = synth_residues(rng, np, (shp.n_query_cts, 2))
+    for _ in range(args.warmup):
+        srv.answer(q, want_packed=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    us = [srv.answer(q, want_packed=False)[2] for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    sweep_ms = sum(u["sweep_kernels_us"] for u in us) / len(us) / 1e3
+    nbytes = shp.trials * srv.sweep_bytes()
+    achieved = nbytes / (sweep_ms * 1e-3) / 1e9
+    out = {"metric": "server ms/query + DB GB/s vs HBM roofline (pack)", "value": round(ms, 4), "unit": "ms/query", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(ms, 4), "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
+           "dtype": "u32 residues, 32x32->64-bit integer MAC (two 28-bit CRT primes)", "data": "synthetic",
+           "config": {"workload": "configs[4]: SpiralPack 2^18 x 30KB (nu1=10, nu2=8, n=4, p=256, t_GSW=8, t_conv=4, t_exp=16, q'=2^20), 16 explicit trial databases generated on device",
+                      "db_bytes_ntt_form": int(shp.trials) * int(shp.dim0) * int(shp.num_per) * sa.N * 8},
+           "stages_us": {k: round(sum(u[k] for u in us) / len(us), 1) for k in us[0]},
+           "roofline": {"bound": "hbm", "kernel": "sweep1_kernel (16 trials)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                        "traffic": None, "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_ms": round(sweep_ms, 4)}}
+    srv.close()
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS), help="config2 = BASELINE.json configs[1], the one the metric is quoted on")
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS) + ["pack"], help="config2 = BASELINE.json configs[1], the one the metric is quoted on; "
+                    "config3 / stream / pack = configs[2] / [3] / [4]")
     ap.add_argument("--nu1", type=int, default=None, help="override the workload's first-dimension size (tuning)")
     ap.add_argument("--nu2", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -141,12 +187,17 @@ def main():
                     "more to the contention, 349 -> 422 us, than the 30 us of conversion it hides); 0: everything in order on one stream")
     ap.add_argument("--event-every", type=int, default=4, help="bracket the stages with HIP events on every n-th timed step only (1 = every step)")
     ap.add_argument("--root-fold", action="store_true", help="N > 1: plain reduce to rank 0, which lifts and folds alone")
+    ap.add_argument("--comm-overlap", action="store_true", help="N > 1 with the sharded expansion: overlap the all-gather of the GSW bits with ScalToMat + sweep and the "
+                    "Regev->GSW conversion with the reduce-scatter (async collectives; one more graph launch and two more stream joins per query: "
+                    "+20..50 us at world size 1, where there is nothing to hide, so it is opt-in until measured on N > 1)")
     ap.add_argument("--replicated-expansion", action="store_true", help="N > 1: every rank runs the whole query expansion (default: each rank expands its own "
                     "first-dimension subtree and every N-th GSW bit, one all-gather of the GSW bits)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the one-GPU self-test)")
     ap.add_argument("--shared-device", action="store_true", help="self-test: all ranks use device 0")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the reduce even with one rank (self-test)")
     args = ap.parse_args()
+    if args.workload == "pack":
+        return bench_pack(args)
 
     import numpy as np
     import torch
@@ -216,6 +267,7 @@ def main():
         srv.set_expand_shard(rank, world)
         bits = torch.zeros(srv.gsw_bits_words(), dtype=torch.int64, device=dev)
         bits_all = torch.zeros(world * bits.numel(), dtype=torch.int64, device=dev)
+    overlap_comm = shard_expand and sharded_fold and args.comm_overlap
     srv.use_graphs(not args.no_graphs)  # expand+convert and lift+fold+finish replay as two hipGraphs
     srv.set_overlap(bool(args.overlap))
 
@@ -244,6 +296,21 @@ def main():
             e[1].record(stream)
             srv.first_dim()
             e[2].record(stream)
+        elif shard_expand and overlap_comm:
+            # the GSW bits only feed the folding keys: their all-gather runs under ScalToMat + sweep, and the Regev->GSW conversion
+            # that consumes them under the reduce-scatter of the accumulators
+            srv.run_expand_pack(bits.data_ptr())
+            w_bits = sdist.all_gather_gsw_bits(bits_all, bits, async_op=True)
+            srv.run_scal2mat_sweep()
+            w_acc = sdist.reduce_scatter_accumulators(chunk, acc, async_op=True)
+            w_bits.wait()
+            srv.run_unpack_gsw(bits_all.data_ptr())
+            if w_acc is not None: w_acc.wait()
+            srv.fold_local(chunk.data_ptr(), ct.data_ptr())
+            sdist.all_gather_cts(gathered, ct)
+            if rank == 0:
+                srv.fold_root(gathered.data_ptr())
+            return
         elif shard_expand:
             srv.run_expand_pack(bits.data_ptr())       # this rank's share of the expansion, one graph
             sdist.all_gather_gsw_bits(bits_all, bits)  # every rank needs every GSW bit
@@ -315,7 +382,8 @@ def main():
         "config": {"workload": label + ", explicit DB generated on device, sharded by first-dimension index",
                    "db_bytes_ntt_form": int(shp.dim0) * int(shp.num_per) * 4 * sa.N * 8, "schedule": "GSW conversion overlapped with the sweep (side stream)" if args.overlap else "in order, one stream",
                    "parallelism": (f"j-shard x{world}, reduce-scatter + distributed fold + all-gather" if sharded_fold else f"j-shard x{world} + 1 reduce")
-                                  + (", sharded expansion + all-gather of the GSW bits" if shard_expand else "")},
+                                  + (", sharded expansion + all-gather of the GSW bits" if shard_expand else "")
+                                  + (" (overlapped with ScalToMat + sweep)" if overlap_comm else "")},
         "queries_per_s": round(1e3 / ms_per_step, 2),
         "stages_us": {k: round(v, 1) for k, v in stages.items()},
         "reference_buckets_us_eager": ({k: round(v, 1) for k, v in detail.items() if k != "scaltomat_us"} if detail else None),

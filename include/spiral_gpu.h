@@ -214,6 +214,10 @@ int spiral_gpu_server_gsw_bits_pack(spiral_gpu_server *s, void *block_out);
 int spiral_gpu_server_gsw_bits_unpack(spiral_gpu_server *s, const void *gathered);
 int spiral_gpu_server_run_expand_pack(spiral_gpu_server *s, void *bits_out);
 int spiral_gpu_server_run_unpack_convert_sweep(spiral_gpu_server *s, const void *gathered);
+/* the same work split so that the all-gather can overlap the database-dependent part: run_scal2mat_sweep (ScalToMat + sweep:
+ * needs no GSW bit) while the all-gather is in flight, run_unpack_gsw (unpack + regevToGSW + fold keys) once it has landed */
+int spiral_gpu_server_run_scal2mat_sweep(spiral_gpu_server *s);
+int spiral_gpu_server_run_unpack_gsw(spiral_gpu_server *s, const void *gathered);
 /* make the sweep write into caller-owned device memory (e.g. a torch tensor) */
 int spiral_gpu_server_set_acc(spiral_gpu_server *s, void *device_ptr);
 

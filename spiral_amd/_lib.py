@@ -112,6 +112,8 @@ PROTOTYPES = {
     "spiral_gpu_server_gsw_bits_unpack": (C.c_int, [C.c_void_p, C.c_void_p]),
     "spiral_gpu_server_run_expand_pack": (C.c_int, [C.c_void_p, C.c_void_p]),
     "spiral_gpu_server_run_unpack_convert_sweep": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "spiral_gpu_server_run_scal2mat_sweep": (C.c_int, [C.c_void_p]),
+    "spiral_gpu_server_run_unpack_gsw": (C.c_int, [C.c_void_p, C.c_void_p]),
     "spiral_gpu_server_acc": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "spiral_gpu_server_set_acc": (C.c_int, [C.c_void_p, C.c_void_p]),
     "spiral_gpu_server_answer": (C.c_int, [C.c_void_p, U64P, U64P, U64P, C.POINTER(C.c_double)]),

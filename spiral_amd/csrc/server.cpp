@@ -40,7 +40,7 @@ struct spiral_gpu_server {
     // reduce_first; instantiated lazily, invalidated when a captured pointer or flag changes
     bool use_graphs = false;
     // [3] = Regev->GSW conversion on the side stream, [4] = whole query, [5] = fold_local, [6] = fold_root, [7] = run_pre + sweep
-    hipGraphExec_t graph[10] = {};  // [8] = sharded expansion + pack, [9] = unpack + convert + sweep
+    hipGraphExec_t graph[12] = {};  // [8] = sharded expansion + pack, [9] = unpack + convert + sweep, [10] = ScalToMat + sweep, [11] = unpack + Regev->GSW
     const void *cap_chunk = nullptr, *cap_gathered = nullptr;
     void* cap_ct = nullptr;  // the caller's buffers captured into graphs 5 and 6
     // overlap mode: run_pre forks the Regev->GSW conversion (needed only by the folding) onto side_stream so that it
@@ -1228,15 +1228,47 @@ int spiral_gpu_server_run_unpack_convert_sweep(spiral_gpu_server* S, const void*
     if (!S || !gathered) return fail("null argument");
     HIP_OK(hipSetDevice(S->device));
     if (!S->have_db) return fail("no database loaded");
-    if (S->graph[9] && S->cap_bits_in != gathered) {
-        (void)hipGraphExecDestroy(S->graph[9]);
-        S->graph[9] = nullptr;
-    }
+    if (S->cap_bits_in != gathered)
+        for (int g : {9, 11})
+            if (S->graph[g]) {
+                (void)hipGraphExecDestroy(S->graph[g]);
+                S->graph[g] = nullptr;
+            }
     S->cap_bits_in = gathered;
     return run_group(S, 9, S->stream, [&]() {
         if (spiral_gpu_server_gsw_bits_unpack(S, gathered)) return -1;
         if (spiral_gpu_server_convert(S)) return -1;
         return spiral_gpu_server_first_dim(S);
+    });
+}
+
+// The same split so that the all-gather of the GSW bits can run UNDER the database-dependent work: the sweep needs only the
+// ScalToMat outputs (this rank's own first-dimension ciphertexts), the GSW bits only feed the folding keys.
+// run_scal2mat_sweep = ScalToMat + sweep (after run_expand_pack, while the all-gather is in flight);
+// run_unpack_gsw = unpack of the gathered blocks + Regev->GSW conversion (after the all-gather, e.g. under the reduce-scatter).
+int spiral_gpu_server_run_scal2mat_sweep(spiral_gpu_server* S) {
+    if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
+    if (!S->have_db) return fail("no database loaded");
+    return run_group(S, 10, S->stream, [&]() {
+        if (convert_scal2mat(S, S->stream)) return -1;
+        return spiral_gpu_server_first_dim(S);
+    });
+}
+
+int spiral_gpu_server_run_unpack_gsw(spiral_gpu_server* S, const void* gathered) {
+    if (!S || !gathered) return fail("null argument");
+    HIP_OK(hipSetDevice(S->device));
+    if (S->cap_bits_in != gathered)
+        for (int g : {9, 11})
+            if (S->graph[g]) {
+                (void)hipGraphExecDestroy(S->graph[g]);
+                S->graph[g] = nullptr;
+            }
+    S->cap_bits_in = gathered;
+    return run_group(S, 11, S->stream, [&]() {
+        if (spiral_gpu_server_gsw_bits_unpack(S, gathered)) return -1;
+        return convert_gsw(S, S->stream);
     });
 }
 

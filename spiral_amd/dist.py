@@ -31,7 +31,7 @@ def reduce_accumulators(acc, dst: int = 0, group=None):
     return acc
 
 
-def reduce_scatter_accumulators(chunk, acc, group=None):
+def reduce_scatter_accumulators(chunk, acc, group=None, async_op=False):
     """one collective: every rank receives the element-wise sum of its contiguous chunk of the ranks' accumulator
     buffers (the sweep wrote them grouped by ii mod world, Server.set_fold_ranks).  RCCL has a native reduce-scatter;
     gloo (CPU tests) does not, there the same result is an all-reduce followed by a slice."""
@@ -42,9 +42,9 @@ def reduce_scatter_accumulators(chunk, acc, group=None):
         dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group)
         n = chunk.numel()
         chunk.copy_(tmp[dist.get_rank(group) * n:(dist.get_rank(group) + 1) * n])
-    else:
-        dist.reduce_scatter_tensor(chunk, acc, op=dist.ReduceOp.SUM, group=group)
-    return chunk
+        return None if async_op else chunk
+    work = dist.reduce_scatter_tensor(chunk, acc, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return work if async_op else chunk
 
 
 def all_gather_cts(gathered, ct, group=None):
@@ -60,12 +60,14 @@ def fold_ranks(world: int, num_per: int) -> int:
     return world if world >= 1 and (world & (world - 1)) == 0 and world <= num_per else 1
 
 
-def all_gather_gsw_bits(gathered, mine, group=None):
-    """sharded expansion: collect the ranks' blocks of GSW-bit ciphertexts in rank order (1.8 MiB in all at config 2)"""
+def all_gather_gsw_bits(gathered, mine, group=None, async_op=False):
+    """sharded expansion: collect the ranks' blocks of GSW-bit ciphertexts in rank order (1.8 MiB in all at config 2).
+    async_op: returns the Work handle; the collective then runs on the backend's own stream (ordered after what the
+    current stream has enqueued so far) and work.wait() makes the current stream wait for it"""
     import torch.distributed as dist
 
-    dist.all_gather_into_tensor(gathered, mine, group=group)
-    return gathered
+    work = dist.all_gather_into_tensor(gathered, mine, group=group, async_op=async_op)
+    return work if async_op else gathered
 
 
 def expand_shard_ok(shape, params, world: int) -> bool:

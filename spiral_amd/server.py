@@ -154,6 +154,14 @@ class Server:
         """unpack of the all-gathered GSW bits + convert + first_dim (one hipGraph replay when graphs are on)"""
         check(lib().spiral_gpu_server_run_unpack_convert_sweep(self.h, C.c_void_p(gathered_ptr)))
 
+    def run_scal2mat_sweep(self):
+        """ScalToMat + first_dim: the database-dependent part needs no GSW bit, so it can run under their all-gather"""
+        check(lib().spiral_gpu_server_run_scal2mat_sweep(self.h))
+
+    def run_unpack_gsw(self, gathered_ptr: int):
+        """unpack of the all-gathered GSW bits + Regev->GSW conversion (fold keys)"""
+        check(lib().spiral_gpu_server_run_unpack_gsw(self.h, C.c_void_p(gathered_ptr)))
+
     def acc(self):
         nbytes = C.c_size_t()
         ptr = lib().spiral_gpu_server_acc(self.h, C.byref(nbytes))

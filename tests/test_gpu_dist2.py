@@ -21,7 +21,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, root_fold, shard_expand, q):
+def _worker(rank, world, port, root_fold, shard_expand, overlap, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
@@ -66,7 +66,16 @@ def _worker(rank, world, port, root_fold, shard_expand, q):
         for idx in (9, 200, 255, 9):
             qy = cl.query(idx)
             srv.set_query(qy)
-            if shard_expand:
+            if shard_expand and overlap:  # bench.py's overlapped order: the all-gather under ScalToMat + sweep
+                srv.run_expand_pack(bits.data_ptr())
+                w_bits = sdist.all_gather_gsw_bits(bits_all, bits, async_op=True)
+                srv.run_scal2mat_sweep()
+                w_acc = sdist.reduce_scatter_accumulators(chunk, acc, async_op=True)
+                w_bits.wait()
+                srv.run_unpack_gsw(bits_all.data_ptr())
+                if w_acc is not None:
+                    w_acc.wait()
+            elif shard_expand:
                 srv.run_expand_pack(bits.data_ptr())
                 sdist.all_gather_gsw_bits(bits_all, bits)
                 srv.run_unpack_convert_sweep(bits_all.data_ptr())
@@ -77,7 +86,8 @@ def _worker(rank, world, port, root_fold, shard_expand, q):
                 if rank == 0:
                     srv.run_post(reduce_first=True)
             else:
-                sdist.reduce_scatter_accumulators(chunk, acc)
+                if not (shard_expand and overlap):
+                    sdist.reduce_scatter_accumulators(chunk, acc)
                 srv.fold_local(chunk.data_ptr(), ct.data_ptr())
                 sdist.all_gather_cts(gathered, ct)
                 if rank == 0:
@@ -94,14 +104,14 @@ def _worker(rank, world, port, root_fold, shard_expand, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("root_fold,shard_expand", [(False, False), (True, False), (False, True), (True, True)])
-def test_two_processes_one_gpu(root_fold, shard_expand):
+@pytest.mark.parametrize("root_fold,shard_expand,overlap", [(False, False, False), (True, False, False), (False, True, False), (True, True, False), (False, True, True)])
+def test_two_processes_one_gpu(root_fold, shard_expand, overlap):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, root_fold, shard_expand, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, root_fold, shard_expand, overlap, q)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
