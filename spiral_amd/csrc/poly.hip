@@ -312,6 +312,93 @@ __global__ __launch_bounds__(kTpb) void expand_mac_round_wide_kernel(ExpandMacPa
         }
     }
 }
+// The widest rounds: CT ciphertexts of one parity per workgroup, so that a W word is fetched once for CT digit streams (the
+// single-ciphertext kernels above read 2 W words per digit word: two thirds of their L2 traffic).  Same split over 4
+// k-groups; wave c finishes ciphertext c from the other waves' partial sums (LDS [k-group][ct][word][lane]: conflict-free).
+template <int CT>
+__global__ __launch_bounds__(kTpb) void expand_mac_round_batch_kernel(ExpandMacParams p) {
+    __shared__ uint64_t sh[4][CT][8][64];
+    const uint32_t zz = threadIdx.x & 63u, kg = threadIdx.x >> 6, z = (blockIdx.x * 64u + zz) * 2u;
+    const uint32_t groups_e = (p.cnt_e + CT - 1) / CT;
+    const bool odd = blockIdx.y >= groups_e;
+    const uint32_t a0 = odd ? p.cnt_e + (blockIdx.y - groups_e) * CT : blockIdx.y * CT;
+    const uint32_t n = min((uint32_t)CT, (odd ? p.cnt_e + p.cnt_o : p.cnt_e) - a0);
+    const uint32_t tdim = odd ? p.t_o : p.t_e;
+    const size_t gbase = odd ? (size_t)p.cnt_e * p.t_e + (size_t)(a0 - p.cnt_e) * p.t_o : (size_t)a0 * p.t_e;
+    const uint64_t* w = (odd ? p.w_o : p.w_e) + z;
+    const uint64_t* gp = p.g + gbase * kN + z;
+    Acc2 acc[CT][2][2];  // [ciphertext][output row][slot of the pair]
+#pragma unroll 2
+    for (uint32_t k = kg; k < tdim; k += 4) {
+        const u64x2_t w0 = *reinterpret_cast<const u64x2_t*>(w + (size_t)k * kN), w1 = *reinterpret_cast<const u64x2_t*>(w + (size_t)(tdim + k) * kN);
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+            const uint32_t cc = min((uint32_t)c, n - 1u);  // a short last group re-reads its last ciphertext; the result is not stored
+            const u64x2_t gv = __builtin_nontemporal_load(reinterpret_cast<const u64x2_t*>(gp + ((size_t)cc * tdim + k) * kN));
+            acc[c][0][0].mac(w0.x, gv.x);
+            acc[c][0][1].mac(w0.y, gv.y);
+            acc[c][1][0].mac(w1.x, gv.x);
+            acc[c][1][1].mac(w1.y, gv.y);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CT; c++)
+        if ((uint32_t)(c & 3) != kg) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    sh[kg][c][4 * r + 2 * h + 0][zz] = acc[c][r][h].lo;
+                    sh[kg][c][4 * r + 2 * h + 1][zz] = acc[c][r][h].hi;
+                }
+        }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CT; c++) {
+        if ((uint32_t)(c & 3) != kg || (uint32_t)c >= n) continue;
+        const uint32_t a = a0 + c, i = p.act.index(a, p.cnt_e);
+        const bool make_next = p.neg1n != nullptr && (!odd || (i >> 1) + (p.next_num_in >> 1) < p.next_cnt_o);
+        uint64_t* cp = p.cv + (size_t)i * 2 * kN + z;
+        const u64x2_t old0 = *reinterpret_cast<const u64x2_t*>(cp), old1 = *reinterpret_cast<const u64x2_t*>(cp + kN);
+        const u64x2_t a1v = *reinterpret_cast<const u64x2_t*>(p.a1 + ((size_t)a * 2u + 1u) * kN + z);
+        u64x2_t nw = {0, 0}, nws = {0, 0};
+        if (make_next) {
+            nw = *reinterpret_cast<const u64x2_t*>(p.neg1n + z);
+            nws = *reinterpret_cast<const u64x2_t*>(p.neg1ns + z);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)  // <= 56 terms of < 2^56 in total: no overflow
+            if ((uint32_t)q != kg) {
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        acc[c][r][h].lo += sh[q][c][4 * r + 2 * h + 0][zz];
+                        acc[c][r][h].hi += sh[q][c][4 * r + 2 * h + 1][zz];
+                    }
+            }
+        uint64_t c0[2], c1[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            c0[h] = add_pk(h ? old0.y : old0.x, acc[c][0][h].reduced());
+            c1[h] = add_pk(add_pk(h ? old1.y : old1.x, acc[c][1][h].reduced()), h ? a1v.y : a1v.x);
+        }
+        *reinterpret_cast<u64x2_t*>(cp) = u64x2_t{c0[0], c0[1]};
+        *reinterpret_cast<u64x2_t*>(cp + kN) = u64x2_t{c1[0], c1[1]};
+        if (make_next) {
+            uint64_t* nx = p.cv + (size_t)(i + p.next_num_in) * 2 * kN + z;
+            uint64_t n0[2], n1[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint64_t ww = h ? nw.y : nw.x, ws = h ? nws.y : nws.x;
+                n0[h] = pack(csub(shoup32(lo32(c0[h]), lo32(ww), lo32(ws), kP), kP), csub(shoup32(hi32(c0[h]), hi32(ww), hi32(ws), kB), kB));
+                n1[h] = pack(csub(shoup32(lo32(c1[h]), lo32(ww), lo32(ws), kP), kP), csub(shoup32(hi32(c1[h]), hi32(ww), hi32(ws), kB), kB));
+            }
+            *reinterpret_cast<u64x2_t*>(nx) = u64x2_t{n0[0], n0[1]};
+            *reinterpret_cast<u64x2_t*>(nx + kN) = u64x2_t{n1[0], n1[1]};
+        }
+    }
+}
 void launch_expand_mac_round(const ExpandMacParams& p, hipStream_t s) {
     const uint32_t cnt = p.cnt_e + p.cnt_o;
     if (cnt == 0) return;
@@ -319,7 +406,19 @@ void launch_expand_mac_round(const ExpandMacParams& p, hipStream_t s) {
         const char* e = getenv("SPIRAL_MAC_WIDE_MIN");  // tuning only
         return e ? (uint32_t)strtoul(e, nullptr, 10) : 64u;
     }();
-    if (cnt >= wide_min)
+    static const uint32_t ct2_min = [] {
+        const char* e = getenv("SPIRAL_MAC_CT2_MIN");  // tuning only
+        return e ? (uint32_t)strtoul(e, nullptr, 10) : 64u;
+    }();
+    static const uint32_t ct4_min = [] {
+        const char* e = getenv("SPIRAL_MAC_CT4_MIN");  // tuning only
+        return e ? (uint32_t)strtoul(e, nullptr, 10) : 128u;
+    }();
+    if (cnt >= ct4_min)
+        hipLaunchKernelGGL(expand_mac_round_batch_kernel<4>, dim3(kN / 128, (p.cnt_e + 3) / 4 + (p.cnt_o + 3) / 4), dim3(kTpb), 0, s, p);
+    else if (cnt >= ct2_min)
+        hipLaunchKernelGGL(expand_mac_round_batch_kernel<2>, dim3(kN / 128, (p.cnt_e + 1) / 2 + (p.cnt_o + 1) / 2), dim3(kTpb), 0, s, p);
+    else if (cnt >= wide_min)
         hipLaunchKernelGGL(expand_mac_round_wide_kernel, dim3(kN / 128, cnt), dim3(kTpb), 0, s, p);
     else
         hipLaunchKernelGGL(expand_mac_round_kernel, dim3(kN / 64, cnt), dim3(kTpb), 0, s, p);
