@@ -187,6 +187,7 @@ def main():
                     "more to the contention, 349 -> 422 us, than the 30 us of conversion it hides); 0: everything in order on one stream")
     ap.add_argument("--event-every", type=int, default=4, help="bracket the stages with HIP events on every n-th timed step only (1 = every step)")
     ap.add_argument("--root-fold", action="store_true", help="N > 1: plain reduce to rank 0, which lifts and folds alone")
+    ap.add_argument("--lanes", type=int, default=3, help="N = 1: queries in flight in the extra throughput leg (`pipelined` in the JSON line; 1 = skip it)")
     ap.add_argument("--comm-overlap", action="store_true", help="N > 1 with the sharded expansion: overlap the all-gather of the GSW bits with ScalToMat + sweep and the "
                     "Regev->GSW conversion with the reduce-scatter (async collectives; one more graph launch and two more stream joins per query: "
                     "+20..50 us at world size 1, where there is nothing to hide, so it is opt-in until measured on N > 1)")
@@ -244,9 +245,11 @@ def main():
     srv.set_stream(stream.cuda_stream)
     srv.gen_db(1234)  # explicit database generated on the device, this rank's j-shard
     rng = np.random.default_rng(1)  # same synthetic inputs on every rank
-    srv.set_pub_params(synth_residues(rng, np, (max(shp.n_left, 1), 2, pg.t_exp)), synth_residues(rng, np, (max(shp.n_right, 1), 2, pg.t_exp_right)),
-                       synth_residues(rng, np, (3, 2 * pg.t_conv)), synth_residues(rng, np, (3, 2 * pg.t_conv)))
-    srv.set_query(synth_residues(rng, np, (shp.n_query_cts, 2)))
+    pub = (synth_residues(rng, np, (max(shp.n_left, 1), 2, pg.t_exp)), synth_residues(rng, np, (max(shp.n_right, 1), 2, pg.t_exp_right)),
+           synth_residues(rng, np, (3, 2 * pg.t_conv)), synth_residues(rng, np, (3, 2 * pg.t_conv)))
+    srv.set_pub_params(*pub)
+    query = synth_residues(rng, np, (shp.n_query_cts, 2))
+    srv.set_query(query)
     acc = torch.zeros(shp.num_per * 6 * sa.N, dtype=torch.int64, device=dev)
     srv.set_acc(acc.data_ptr())
     # distributed fold (reduce-scatter variant): the ranks' accumulators are reduce-scattered by ciphertext,
@@ -351,6 +354,33 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+        # throughput leg (outside the timed region, reported beside `value`, never as it): `lanes` queries in flight on one database
+        # image, one server handle and one stream per lane, each replaying the whole-query graph
+        pipelined = None
+        if whole and args.lanes > 1:
+            lanes = [(srv, stream)]
+            for _ in range(args.lanes - 1):
+                lane, lane_stream = sa.Server(pg, local_rank, j0, j1), torch.cuda.Stream(device=dev)
+                lane.set_stream(lane_stream.cuda_stream)
+                lane.share_db(srv)
+                lane.set_pub_params(*pub)
+                lane.set_query(query)
+                lane.use_graphs(True)
+                lanes.append((lane, lane_stream))
+            for lane, _ in lanes:
+                lane.run_query()  # graph capture, untimed
+            torch.cuda.synchronize()
+            n_q = max(args.steps, 100) // args.lanes * args.lanes
+            t1 = time.perf_counter()
+            for k in range(n_q):
+                lanes[k % args.lanes][0].run_query()
+            torch.cuda.synchronize()
+            dt_p = time.perf_counter() - t1
+            pipelined = {"lanes": args.lanes, "queries": n_q, "queries_per_s": round(n_q / dt_p, 1), "ms_per_query_amortised": round(dt_p * 1e3 / n_q, 4),
+                         "note": "throughput with several queries in flight (one handle + stream per lane sharing the database image, share_db); "
+                                 "each query's own latency is `value` or longer"}
+            for lane, _ in lanes[1:]:
+                lane.close()
         # untimed: the reference's stage buckets (src/spiral.cpp:246-257) from one eager pass with HIP events
         detail = None
         if world == 1:
@@ -409,6 +439,7 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         if roofline_ntt: out["roofline_ntt"] = roofline_ntt
+        if pipelined: out["pipelined"] = pipelined
         if world == 1 and not args.no_cpu_baseline and args.workload == "config2":  # (the larger workloads' 32 / 64 GiB host databases are not built for a baseline)
             out["cpu_baseline"] = cpu_baseline(params_kw, np, args.workload)
         import ctypes

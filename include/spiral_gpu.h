@@ -156,6 +156,10 @@ int spiral_gpu_server_read_db_item(spiral_gpu_server *s, uint64_t item, uint64_t
 int spiral_gpu_server_read_db_slots(spiral_gpu_server *s, uint32_t z_begin, uint32_t nz, uint64_t *out);
 /* --random-data analogue: arbitrary valid NTT-form words, timing only */
 int spiral_gpu_server_fill_db_random(spiral_gpu_server *s, uint64_t seed);
+/* a second in-flight query on one database: `s` releases its own image and sweeps `owner`'s (same parameters, shard and device;
+ * the owner outlives `s` and does not reload while `s` answers; loads through `s` fail).  One handle per query lane, each on
+ * its own stream: the latency-bound expansion / folding of one query runs under the HBM-bound sweep of another. */
+int spiral_gpu_server_share_db(spiral_gpu_server *s, spiral_gpu_server *owner);
 
 /* public parameters (NTT form): W_exp_left g x (n0 x t_exp), W_exp_right n_right x (n0 x t_exp_right),
  * W n1 x (n0*t_conv), V n1 x (2*t_conv)   (src/spiral.cpp:2091-2092, 2216-2227, 2279-2296) */

@@ -85,6 +85,7 @@ PROTOTYPES = {
     "spiral_gpu_server_load_db": (C.c_int, [C.c_void_p, U64P]),
     "spiral_gpu_server_gen_db": (C.c_int, [C.c_void_p, C.c_uint64]),
     "spiral_gpu_server_fill_db_random": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "spiral_gpu_server_share_db": (C.c_int, [C.c_void_p, C.c_void_p]),
     "spiral_gpu_server_load_db_items": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]),
     "spiral_gpu_server_read_db_item": (C.c_int, [C.c_void_p, C.c_uint64, U64P]),
     "spiral_gpu_server_read_db_slots": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, U64P]),

@@ -20,6 +20,7 @@ struct spiral_gpu_server {
     hipStream_t own_stream = nullptr, stream = nullptr;
     DeviceTables tb;
     bool keep_cts = false, have_db = false, have_pp = false, have_query = false;
+    bool db_shared = false;  // db.p is another server's image (share_db): never written, never freed here
     // expanded-ciphertext positions inside cv: first-dim j at j*pos_stride + pos_first, rest i at i*pos_stride + pos_rest
     uint32_t pos_stride = 1, pos_first = 0, pos_rest = 0, n_cv = 0;
 
@@ -125,6 +126,7 @@ void srv_free(spiral_gpu_server* S) {
     DevBuf* all[] = {&S->db, &S->w_left, &S->w_right, &S->w, &S->v, &S->query, &S->cv, &S->ex_raw, &S->ex_g, &S->cv_raw,
                      &S->cv_g, &S->gsw, &S->key, &S->cts_keep, &S->qs, &S->acc_own, &S->raw, &S->fold_d, &S->fold_c, &S->fold_p[0], &S->fold_p[1],
                      &S->resp, &S->stage};
+    if (S->db_shared) S->db.p = nullptr;
     for (DevBuf* b : all) b->release();
     for (auto& e : S->ev)
         if (e) (void)hipEventDestroy(e);
@@ -633,6 +635,7 @@ int spiral_gpu_server_use_graphs(spiral_gpu_server* S, int on) {
 
 int spiral_gpu_server_load_db(spiral_gpu_server* S, const uint64_t* database) {
     if (!S || !database) return fail("null argument");
+    if (S->db_shared) return fail("this server sweeps another server's database image (share_db): load it through the owner");
     HIP_OK(hipSetDevice(S->device));
     // stage the reference-layout database one z-slab group at a time and re-lay the shard
     const size_t per_z_ref = (size_t)S->s.num_per * 2 * S->s.dim0 * 2;
@@ -661,6 +664,7 @@ int spiral_gpu_server_load_db(spiral_gpu_server* S, const uint64_t* database) {
 
 int spiral_gpu_server_gen_db(spiral_gpu_server* S, uint64_t seed) {
     if (!S) return fail("null server");
+    if (S->db_shared) return fail("this server sweeps another server's database image (share_db): load it through the owner");
     HIP_OK(hipSetDevice(S->device));
     FwdParams fp{};
     fp.dst = S->db.p;
@@ -684,6 +688,7 @@ int spiral_gpu_server_gen_db(spiral_gpu_server* S, uint64_t seed) {
 
 int spiral_gpu_server_load_db_items(spiral_gpu_server* S, const void* items, uint32_t coeff_bits, uint64_t first_item, uint64_t n_items) {
     if (!S) return fail("null server");
+    if (S->db_shared) return fail("this server sweeps another server's database image (share_db): load it through the owner");
     HIP_OK(hipSetDevice(S->device));
     const uint64_t total = (uint64_t)S->s.dim0 * S->s.num_per;
     if (first_item > total || n_items > total - first_item) return fail("items [%llu, +%llu) outside the database of %llu", (unsigned long long)first_item,
@@ -747,9 +752,31 @@ int spiral_gpu_server_read_db_slots(spiral_gpu_server* S, uint32_t z_begin, uint
 
 int spiral_gpu_server_fill_db_random(spiral_gpu_server* S, uint64_t seed) {
     if (!S) return fail("null server");
+    if (S->db_shared) return fail("this server sweeps another server's database image (share_db): load it through the owner");
     HIP_OK(hipSetDevice(S->device));
     launch_fill_db_random(S->db.p, S->s.num_per, S->dim0_shard, seed, S->stream);
     HIP_OK(hipStreamSynchronize(S->stream));
+    S->have_db = true;
+    return 0;
+}
+
+// A second in-flight query on the same database: `S` gives up its own image and sweeps `owner`'s (the image is read-only on
+// the answer path).  Same parameters, shard and device; `owner` must stay alive and must not reload its database while `S`
+// answers.  With one handle per query lane, each on its own stream, the latency-bound expansion / fold of one query runs
+// under the HBM-bound sweep of the other.
+int spiral_gpu_server_share_db(spiral_gpu_server* S, spiral_gpu_server* owner) {
+    if (!S || !owner || S == owner) return fail("share_db needs two different servers");
+    if (owner->db_shared) return fail("the owner does not own its database image");
+    if (S->device != owner->device || S->j0 != owner->j0 || S->dim0_shard != owner->dim0_shard || S->p.nu1 != owner->p.nu1 || S->p.nu2 != owner->p.nu2 ||
+        S->s.num_per != owner->s.num_per)
+        return fail("share_db: the servers differ in device, shard or database geometry");
+    if (!owner->have_db) return fail("the owner has no database loaded");
+    HIP_OK(hipSetDevice(S->device));
+    HIP_OK(hipStreamSynchronize(S->stream));
+    if (!S->db_shared) S->db.release();
+    S->db.p = owner->db.p;
+    S->db.words = owner->db.words;
+    S->db_shared = true;
     S->have_db = true;
     return 0;
 }

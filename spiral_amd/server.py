@@ -71,6 +71,11 @@ class Server:
     def fill_db_random(self, seed: int):
         check(lib().spiral_gpu_server_fill_db_random(self.h, seed))
 
+    def share_db(self, owner: "Server"):
+        """sweep `owner`'s database image instead of an own copy (a second query lane on one database)"""
+        check(lib().spiral_gpu_server_share_db(self.h, owner.h))
+        self._db_owner = owner  # keeps the owner alive
+
     def set_pub_params(self, w_left, w_right, w, v):
         check(lib().spiral_gpu_server_set_pub_params(self.h, _p(w_left), _p(w_right), _p(w), _p(v)))
 

@@ -371,6 +371,49 @@ def test_graph_replay_matches_eager(sa, oracle, graphs, overlap):
     srv.close()
 
 
+def test_two_query_lanes_share_one_database(sa, oracle):
+    """share_db: a second server handle sweeps the first one's database image; queries of two clients in flight on two streams,
+    interleaved, every answer bit-exact; loading through the lane is refused"""
+    import torch
+
+    O = oracle
+    from spiral_amd import server as SV
+
+    kw = dict(t_gsw=4)
+    po, pg = O.make_params(5, 3, **kw), sa.make_params(5, 3, **kw)
+    db = O.gen_db(po, 31)
+    owner, lane = sa.Server(pg), sa.Server(pg)
+    owner.gen_db(31)
+    lane.share_db(owner)
+    with pytest.raises(RuntimeError):
+        lane.gen_db(5)
+    with pytest.raises(RuntimeError):
+        lane.fill_db_random(5)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    clients = [O.Client(po, seed=5), O.Client(po, seed=6)]
+    pps = [cl.pub_params() for cl in clients]  # (fresh randomness per call: generated once)
+    for s, st, pp in zip((owner, lane), streams, pps):
+        s.set_stream(st.cuda_stream)
+        s.set_pub_params(*pp)
+        s.use_graphs(True)
+    for rnd, (i0, i1) in enumerate([(0, 255), (17, 17), (200, 3), (128, 64)]):
+        qs = [clients[0].query(i0), clients[1].query(i1)]
+        owner.set_query(qs[0])
+        lane.set_query(qs[1])
+        for _ in range(3):  # several replays in flight on both streams before anything is read
+            owner.run_query()
+            lane.run_query()
+        owner.sync()
+        lane.sync()
+        for s, cl, pp, q, idx in zip((owner, lane), clients, pps, qs, (i0, i1)):
+            assert_eq(s.read(SV.BUF_FINAL), O.answer(po, q, *pp, db), f"lane answer round {rnd} idx={idx}")
+            assert_eq(cl.decode(s.read(SV.BUF_RESPONSE)), O.db_item(po, 31, idx), "decoded plaintext")
+    lane.close()
+    fin, resp, _ = owner.answer(clients[0].query(9))  # the owner is unaffected by the lane's release
+    assert_eq(clients[0].decode(resp), O.db_item(po, 31, 9), "owner after the lane closed")
+    owner.close()
+
+
 def test_sharded_first_dim_sums_to_unsharded(sa, oracle):
     """two j-shards on one device: summing their accumulators (what the RCCL reduce does) == one server"""
     O = oracle
