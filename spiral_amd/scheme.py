@@ -15,7 +15,7 @@ measurements on the MI355X (`--fit`, coefficients in spiral_amd/cost_model_mi355
 
     python -m spiral_amd.scheme --set "20,256:spiral" --trials 3
     python -m spiral_amd.scheme --params '{"nu_1":8,"nu_2":7,"p":256,"q_prime_bits":20,"t_GSW":8,"t_conv":4,"t_exp":8,"t_exp_right":56}' --item-size 8192
-    python -m spiral_amd.scheme --select 20,256 [--variant spiral|spiralstream] [--run]
+    python -m spiral_amd.scheme --select 20,256 [--variant spiral|spiralstream|spiral-pack|spiralstream-pack] [--run]
     python -m spiral_amd.scheme --fit            (on an MI355X; rewrites the coefficient file)
 """
 import argparse
@@ -225,11 +225,65 @@ MODEL_TERMS = {
 }
 
 
+# SpiralPack / SpiralStreamPack: the same regression on what pack_server.cpp schedules; (nu_1, nu_2, t_GSW, t_conv, t_exp, n, direct).
+# The database is n^2 trial images of 2^(nu_1+nu_2) single polynomials (7 bytes per word on the device): the grid stays under 100 GiB.
+PACK_FIT_GRID = [
+    (9, 6, 8, 4, 8, 2, 0), (9, 6, 8, 4, 8, 4, 0), (10, 8, 8, 4, 16, 4, 0), (10, 4, 6, 32, 8, 8, 0), (10, 8, 8, 4, 16, 2, 0), (8, 6, 8, 4, 8, 2, 0), (9, 7, 8, 4, 8, 2, 0),
+    (9, 5, 6, 8, 8, 4, 0), (10, 6, 8, 4, 8, 4, 0), (9, 8, 10, 4, 16, 2, 0), (8, 7, 4, 16, 4, 4, 0), (9, 4, 8, 4, 32, 8, 0), (10, 5, 5, 4, 8, 12, 0), (9, 6, 12, 4, 8, 2, 0),
+    (7, 7, 8, 8, 8, 4, 0), (10, 7, 9, 4, 8, 2, 0), (9, 9, 8, 4, 8, 2, 0), (8, 8, 6, 4, 16, 4, 0),
+    (10, 3, 2, 56, 56, 4, 1), (11, 6, 3, 56, 56, 4, 1), (11, 3, 3, 56, 56, 5, 1), (12, 6, 3, 56, 56, 5, 1), (11, 3, 3, 56, 56, 12, 1), (10, 5, 4, 56, 56, 6, 1),
+    (11, 5, 2, 56, 56, 8, 1), (9, 6, 5, 56, 56, 4, 1), (12, 4, 3, 56, 56, 7, 1), (10, 7, 3, 56, 56, 4, 1), (11, 7, 4, 56, 56, 4, 1), (9, 9, 6, 56, 56, 4, 1),
+    (13, 3, 3, 56, 56, 5, 1), (12, 2, 3, 56, 56, 5, 1), (13, 2, 4, 56, 56, 4, 1), (12, 3, 2, 56, 56, 9, 1), (13, 4, 3, 56, 56, 4, 1), (10, 2, 8, 4, 8, 4, 0), (10, 3, 6, 8, 16, 8, 0),
+    (8, 2, 6, 4, 8, 12, 0), (8, 4, 16, 4, 56, 12, 0), (9, 3, 8, 4, 16, 12, 0), (9, 5, 8, 8, 8, 8, 0), (8, 5, 10, 4, 32, 8, 0), (9, 4, 12, 16, 4, 12, 0), (7, 6, 14, 4, 16, 8, 0),
+]
+
+
+def pack_model_features(nu_1, nu_2, t_GSW, t_conv, t_exp, n, t_exp_right=56, direct=0):
+    """counts behind the stage times of the packing variants, as pack_server.cpp schedules them (n^2 trials batched)"""
+    dim0, num_per, ell, trials = 1 << nu_1, 1 << nu_2, t_GSW, n * n
+    f = {"db_words": trials * dim0 * num_per * POLY_LEN, "acc_polys": trials * num_per * 2, "trials": trials,
+         "query_words": trials * dim0 * 2 * POLY_LEN}  # the first-dimension query records, streamed once per trial
+    if direct:
+        f.update(exp_rounds=0, exp_transforms=0, exp_macs=0, conv_transforms=0, conv_macs=0)
+    else:
+        base = model_features(nu_1, nu_2, t_GSW, t_conv, t_exp, t_exp_right, 0)
+        f.update(exp_rounds=base["exp_rounds"], exp_transforms=base["exp_transforms"], exp_macs=base["exp_macs"])
+        f["conv_transforms"] = 2 * nu_2 * ell * (1 + t_conv)  # regevToSimpleGsw: both rows of every GSW-bit ciphertext
+        f["conv_macs"] = nu_2 * ell * 2 * 2 * t_conv
+    f["key_polys"] = nu_2 * 2 * 4 * ell  # fold keys assembled from the (uploaded or converted) GSW ciphertexts
+    f["fold_rounds"] = nu_2
+    f["fold_transforms"] = trials * (4 * (num_per - 1) * (1 + ell) + 2)  # 2 np cts x 2 polys x (1 lift + ell digits) per round, + the last lift
+    f["fold_macs"] = trials * (num_per - 1) * 2 * 4 * ell
+    f["pack_transforms"] = trials * (1 + t_conv) + n * (n + 1)  # digits of every trial's row 0, the lift of the packed ct
+    f["pack_macs"] = n * (n + 1) * n * t_conv
+    return f
+
+
+PACK_MODEL_TERMS = {
+    "exp_us": ["exp_rounds", "exp_transforms", "exp_macs"],
+    "conv_us": ["conv_transforms", "conv_macs", "key_polys"],
+    "fdim_us": ["db_words", "query_words", "acc_polys", "trials"],
+    "fold_us": ["fold_rounds", "fold_transforms", "fold_macs"],
+    "pack_us": ["pack_transforms", "pack_macs"],
+}
+
+
+def is_pack(params):
+    return "n" in params
+
+
 def load_model(path=None):
     return json.load(open(path or MODEL_PATH))
 
 
 def predict_times(model, params):
+    if is_pack(params):
+        f = pack_model_features(params["nu_1"], params["nu_2"], params["t_GSW"], params["t_conv"], params["t_exp"], params["n"], params.get("t_exp_right", 56), params.get("direct", 0))
+        out = {}
+        for stage, terms in PACK_MODEL_TERMS.items():
+            c = model["pack"]["coefficients"][stage]
+            out[stage] = max(0.0, c["const"] * (0 if (stage == "exp_us" and params.get("direct")) else 1) + sum(c[t] * f[t] for t in terms))
+        return out
     f = model_features(params["nu_1"], params["nu_2"], params["t_GSW"], params["t_conv"], params["t_exp"], params.get("t_exp_right", 56), params.get("direct", 0))
     out = {}
     for stage, terms in MODEL_TERMS.items():
@@ -240,19 +294,36 @@ def predict_times(model, params):
 
 def predicted_cost(model, params, item_size):
     """select_params.py:153-215 with the MI355X stage times: (cost in USD, total_us, response bytes, factor)"""
-    n = 2
+    n = params.get("n", 2)
     factor = max(1, math.ceil(item_size / (n * n * POLY_LEN * math.log2(real_p(params["p"])) / 8)))
     t = predict_times(model, params)
-    total_us = t["exp_us"] + t["conv_us"] + factor * (t["fdim_us"] + t["fold_us"])
     qpb = max(params["q_prime_bits"], MIN_Q_PRIME_BITS)
-    total_bytes = factor * ((2 * 2 * 2048 * math.ceil(math.log2(4 * params["p"])) + 2 * 2048 * qpb) / 8)
+    if is_pack(params):  # calc_cost_highrate (select_params.py:217-266): n^2 trials per instance (inside the fitted stage times), one packed response
+        total_us = t["exp_us"] + t["conv_us"] + factor * (t["fdim_us"] + t["fold_us"] + t["pack_us"])
+        total_bytes = factor * ((n * n * 2048 * math.ceil(math.log2(4 * params["p"])) + n * 2048 * qpb) / 8)
+    else:
+        total_us = t["exp_us"] + t["conv_us"] + factor * (t["fdim_us"] + t["fold_us"])
+        total_bytes = factor * ((2 * 2 * 2048 * math.ceil(math.log2(4 * params["p"])) + 2 * 2048 * qpb) / 8)
     return USD_PER_US * total_us + USD_PER_BYTE * total_bytes, total_us, total_bytes, factor
+
+
+DEVICE_DB_BUDGET = 256 << 30  # bytes of one MI355X's 288 GB left to the database image(s) of a candidate
+
+
+def device_db_bytes(params, item_size):
+    """what the candidate's database occupies on the device: `factor` instances (select_params.py:297) of 4 polynomials per item
+    (n^2 trial images of one polynomial for the packing variants), 7 bytes per word"""
+    n = params.get("n", 2)
+    factor = max(1, math.ceil(item_size / (n * n * POLY_LEN * math.log2(real_p(params["p"])) / 8)))
+    return factor * (n * n if is_pack(params) else 4) * (1 << (params["nu_1"] + params["nu_2"])) * POLY_LEN * 7
 
 
 def enumerate_sets(variant, log_n, item_size):
     """noise-feasible parameter sets whose database holds 2^log_n items of item_size bytes: the reference's search space
     (generate_all_schemes.py get_regular_choices / get_streaming_choices) filtered by select_params.py pred (:305-330), with
     nu_1 + nu_2 kept within 1 of the smallest that fits (the cost grows with both)"""
+    if variant.endswith("-pack"):
+        return enumerate_pack_sets(variant, log_n, item_size)
     stream = variant == "spiralstream"
     target = (1 << log_n) * item_size
     out = []
@@ -284,15 +355,51 @@ def enumerate_sets(variant, log_n, item_size):
     return out
 
 
-def select(variant, log_n, item_size, model=None, top=5, optimize_for="cost", usd_per_us=None):
+def enumerate_pack_sets(variant, log_n, item_size):
+    """the same for the packing variants: get_highrate_choices / get_highrate_streaming_choices (generate_all_schemes.py:
+    371-421) -- n in 2, 4, 8, 12 with every t_exp, t_conv (SpiralPack); n in 4..12, p from 2^10, t_GSW <= 10, t_exp = t_conv = 56
+    (SpiralStreamPack) -- filtered by select_params.py pred (:305-336)"""
+    stream = variant == "spiralstream-pack"
+    target = (1 << log_n) * item_size
+    out = []
+    for n in (range(4, 13) if stream else (2, 4, 8, 12)):
+        for pb in (range(10, 31) if stream else range(2, 21)):
+            p = 1 << pb
+            base_item = n * n * POLY_LEN * math.log2(real_p(p)) / 8
+            factor = math.ceil(item_size / base_item)
+            need = max(_ceil_log2(math.ceil(target / (factor * base_item))), 10 if not stream else 4)
+            for total_nu in (need, need + 1):
+                for nu_1 in range(2, (13 if stream else 10) + 1):
+                    nu_2 = total_nu - nu_1
+                    if nu_2 < 2 or nu_2 > 13:
+                        continue
+                    for t_GSW in range(2, (10 if stream else 16) + 1):
+                        if not stream and _ceil_log2((1 << nu_1) + t_GSW * nu_2) > 11:
+                            continue  # the query must fit one polynomial
+                        for t_conv in ((56,) if stream else (2, 4, 8, 16, 32, 56)):
+                            for t_exp in ((56,) if stream else (2, 4, 8, 16, 32, 56)):
+                                r = feasible(variant, p, t_GSW, t_conv, t_exp, 56, nu_1, nu_2, n)
+                                if r is None:
+                                    continue
+                                prm = dict(n=n, nu_1=nu_1, nu_2=nu_2, p=p, q_prime_bits=max(r["q_prime_bits"], MIN_Q_PRIME_BITS), t_GSW=t_GSW, t_conv=t_conv,
+                                           t_exp=t_exp, t_exp_right=56, s_e=r["s_e"])
+                                if stream:
+                                    prm["direct"] = 1
+                                out.append(prm)
+    return out
+
+
+def select(variant, log_n, item_size, model=None, top=5, optimize_for="cost", usd_per_us=None, max_db_bytes=None):
     """the best feasible sets under the MI355X model, best first: [(cost, total_us, bytes, factor, params)].  optimize_for:
     "cost" (USD per query, select_params.py:198-205; usd_per_us overrides the reference's price of a CPU-microsecond, which
     undervalues a GPU-microsecond by two orders of magnitude), "tput" (server time) or "rate" (response size), the reference's
-    --optimize-for shortcuts (select_params.py:268-276)"""
+    --optimize-for shortcuts (select_params.py:268-276); max_db_bytes drops candidates whose device database is larger"""
     model = model or load_model()
     ranked = []
     for prm in enumerate_sets(variant, log_n, item_size):
         try:
+            if max_db_bytes is not None and device_db_bytes(prm, item_size) > max_db_bytes:
+                continue  # --one-gpu: the candidate's database image(s) must be resident on one device
             cost, total_us, nbytes, factor = predicted_cost(model, prm, item_size)
         except KeyError:
             continue
@@ -339,8 +446,58 @@ def fit_model(out_path=None, reps=12):
         err[stage] = {"median_rel_err": float(np.median(np.abs(pred - y) / np.maximum(y, 1))), "max_rel_err": float(np.max(np.abs(pred - y) / np.maximum(y, 1)))}
     model = {"device": "MI355X (gfx950), one GPU, eager stage launches timed with HIP events (Server.answer_resident)",
              "units": "microseconds; features: spiral_amd.scheme.model_features", "coefficients": coef, "fit_error": err, "grid": rows}
+    if os.path.exists(out_path or MODEL_PATH):  # the packing variants' section is fitted separately (fit_pack_model)
+        old = json.load(open(out_path or MODEL_PATH))
+        if "pack" in old:
+            model["pack"] = old["pack"]
     json.dump(model, open(out_path or MODEL_PATH, "w"), indent=1)
     return model
+
+
+def _regress(rows, terms_by_stage, np, skip=lambda stage, r: False):
+    coef, err = {}, {}
+    for stage, terms in terms_by_stage.items():
+        use = [r for r in rows if not skip(stage, r)]
+        A = np.array([[1.0] + [r["features"][t] for t in terms] for r in use])
+        y = np.array([r["measured"][stage] for r in use])
+        w = 1.0 / np.maximum(y, 20.0)
+        x, *_ = np.linalg.lstsq(A * w[:, None], y * w, rcond=None)
+        coef[stage] = dict(zip(["const"] + terms, [float(v) for v in x]))
+        pred = A @ x
+        err[stage] = {"median_rel_err": float(np.median(np.abs(pred - y) / np.maximum(y, 1))), "max_rel_err": float(np.max(np.abs(pred - y) / np.maximum(y, 1)))}
+    return coef, err
+
+
+def fit_pack_model(out_path=None, reps=6):
+    """the packing variants' section of the coefficient file: PACK_FIT_GRID through PackServer.answer (its stage buckets are HIP
+    events between the stages of one answer), regressed on pack_model_features"""
+    import numpy as np
+
+    import spiral_amd as sa
+
+    rows = []
+    rng = np.random.default_rng(2)
+    mk = lambda shape: np.stack([rng.integers(0, m, size=shape + (sa.N,), dtype=np.uint64) for m in (sa.P, sa.B)], axis=-2)
+    for nu_1, nu_2, t_GSW, t_conv, t_exp, n, direct in PACK_FIT_GRID:
+        pg = sa.make_params(nu_1, nu_2, t_gsw=t_GSW, t_conv=t_conv, t_exp=t_exp, t_exp_right=56, qprime_bits=20, p_db=256, direct_upload=direct)
+        shp = sa.get_pack_shape(pg, n)
+        srv = sa.PackServer(pg, n)
+        srv.fill_db_random(3)
+        srv.set_pub_params(mk((max(shp.n_left, 1), 2, t_exp)), mk((max(shp.n_right, 1), 2, 56)), mk((2, 2 * t_conv)), mk((n, n + 1, t_conv)))
+        q = mk((shp.n_query_cts, 2))
+        us = [srv.answer(q, want_packed=False)[2] for _ in range(reps)][2:]
+        med = {k: float(np.median([u[k] for u in us])) for k in us[0]}
+        srv.close()
+        rows.append({"params": dict(nu_1=nu_1, nu_2=nu_2, t_GSW=t_GSW, t_conv=t_conv, t_exp=t_exp, n=n, direct=direct),
+                     "measured": {"exp_us": med["expansion_us"], "conv_us": med["conversion_us"], "fdim_us": med["first_dim_us"], "fold_us": med["folding_us"],
+                                  "pack_us": med["packing_us"], "total_us": med["total_us"]},
+                     "features": pack_model_features(nu_1, nu_2, t_GSW, t_conv, t_exp, n, 56, direct)})
+    coef, err = _regress(rows, PACK_MODEL_TERMS, np, skip=lambda stage, r: stage in ("exp_us",) and r["params"]["direct"])
+    path = out_path or MODEL_PATH
+    model = json.load(open(path)) if os.path.exists(path) else {}
+    model["pack"] = {"units": "microseconds per answer (all n^2 trials); features: spiral_amd.scheme.pack_model_features", "coefficients": coef, "fit_error": err, "grid": rows}
+    json.dump(model, open(path, "w"), indent=1)
+    return model["pack"]
 
 
 def is_high_rate(params):
@@ -423,10 +580,13 @@ def main(argv=None):
     g.add_argument("--list", action="store_true", help="print the published sets and exit")
     g.add_argument("--select", metavar="LOGN,ITEMSIZE", help="choose the cheapest noise-feasible parameter set for 2^LOGN items of ITEMSIZE bytes under the MI355X cost model")
     g.add_argument("--fit", action="store_true", help="measure the fitting grid on this GPU and rewrite the cost-model coefficients")
-    ap.add_argument("--variant", default="spiral", choices=["spiral", "spiralstream"], help="--select: query compression (spiral) or direct upload (spiralstream)")
+    g.add_argument("--fit-pack", action="store_true", help="the same for the packing variants' section of the coefficient file")
+    ap.add_argument("--variant", default="spiral", choices=["spiral", "spiralstream", "spiral-pack", "spiralstream-pack"],
+                    help="--select: query compression (spiral) or direct upload (spiralstream), each with or without response packing")
     ap.add_argument("--run", action="store_true", help="--select: also run the chosen set through ./spiral and report the measured times")
     ap.add_argument("--top", type=int, default=5, help="--select: how many of the cheapest sets to list")
     ap.add_argument("--optimize-for", default="cost", choices=["cost", "tput", "rate"], help="--select: USD per query (default), server time, or response size")
+    ap.add_argument("--one-gpu", action="store_true", help="--select: only sets whose database image(s) fit one MI355X (256 GiB of its 288 GB)")
     ap.add_argument("--usd-per-us", type=float, help="--select: price of a server microsecond (default: the reference's CPU figure, 5.4e-12)")
     ap.add_argument("--item-size", type=int, help="bytes per item (default: the workload's, or one plaintext)")
     ap.add_argument("--trials", type=int, default=1)
@@ -441,14 +601,19 @@ def main(argv=None):
         m = fit_model()
         print(json.dumps({"coefficients": m["coefficients"], "fit_error": m["fit_error"], "points": len(m["grid"]), "written": MODEL_PATH}))
         return 0
+    if a.fit_pack:
+        m = fit_pack_model()
+        print(json.dumps({"coefficients": m["coefficients"], "fit_error": m["fit_error"], "points": len(m["grid"]), "written": MODEL_PATH}))
+        return 0
     if a.select:
         log_n, item_size = (int(x) for x in a.select.split(","))
         model = load_model()
-        ranked = select(a.variant, log_n, item_size, model, a.top, a.optimize_for, a.usd_per_us)
+        ranked = select(a.variant, log_n, item_size, model, a.top, a.optimize_for, a.usd_per_us, DEVICE_DB_BUDGET if a.one_gpu else None)
         if not ranked:
             sys.exit("no feasible parameter set")
         out = {"workload": {"log_n": log_n, "item_size": item_size, "variant": a.variant, "optimize_for": a.optimize_for}, "model": os.path.basename(MODEL_PATH),
-               "candidates": [{"params": prm, "predicted_us": predict_times(model, prm), "predicted_total_us": tot, "resp_bytes": nb, "factor": fac, "cost_usd": cost}
+               "candidates": [{"params": prm, "predicted_us": predict_times(model, prm), "predicted_total_us": tot, "resp_bytes": nb, "factor": fac, "cost_usd": cost,
+                               "device_db_bytes": device_db_bytes(prm, item_size), "gpus_for_db": math.ceil(device_db_bytes(prm, item_size) / DEVICE_DB_BUDGET)}
                               for cost, tot, nb, fac, prm in ranked]}
         work = f"{log_n},{item_size}"
         if work in PUBLISHED and a.variant in PUBLISHED[work]:  # what the reference's CPU model chose for the same workload, under this model
