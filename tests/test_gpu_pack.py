@@ -105,6 +105,44 @@ def test_pack_server_matches_oracle(sa, oracle, nu1, nu2, out_n, kw):
     srv2.close()
 
 
+def _random_pack_sets(count, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < count:
+        nu1, nu2, out_n = int(rng.integers(2, 6)), int(rng.integers(0, 5)), int(rng.choice([2, 3, 4, 5, 7, 8, 12]))
+        kw = dict(t_gsw=int(rng.integers(2, 11)), t_conv=int(rng.choice([2, 3, 4, 8, 16, 56])), t_exp=int(rng.choice([2, 4, 5, 8, 16, 56])),
+                  qprime_bits=int(rng.integers(14, 37)), p_db=int(rng.choice([2, 256, 4096, 65536, 1 << 19])), direct_upload=int(rng.integers(0, 2)))
+        if out_n * out_n * (1 << (nu1 + nu2)) > 16384:  # the oracle builds out_n^2 trial databases
+            continue
+        if nu2 < 1 or (not kw["direct_upload"] and kw["t_gsw"] * nu2 > (1 << nu1)):  # the packing path needs a fold and a stop round (src/testing.cpp:957-965)
+            continue
+        out.append((nu1, nu2, out_n, kw))
+    return out
+
+
+@pytest.mark.parametrize("nu1,nu2,out_n,kw", _random_pack_sets(12, 7), ids=[f"set{i}" for i in range(12)])
+def test_random_pack_sets_bit_exact(sa, oracle, nu1, nu2, out_n, kw):
+    """a seeded draw of SpiralPack / SpiralStreamPack parameter sets (odd gadget dimensions and output sizes, every q' width):
+    packed ciphertext and switched response == the oracle's, word for word"""
+    O = oracle
+    po, pg = O.make_params(nu1, nu2, **kw), sa.make_params(nu1, nu2, **kw)
+    s = O.pack_shape_of(po, out_n)
+    db = O.pack_gen_db(po, out_n, 5)
+    cl = O.PackClient(po, out_n, seed=nu1 + 10 * nu2)
+    wl, wr, v, vw = cl.pub_params()
+    srv = sa.PackServer(pg, out_n)
+    srv.gen_db(5)
+    srv.set_pub_params(wl, wr, v, vw)
+    total = s.dim0 * s.num_per
+    for idx in (0, total - 1):
+        q = cl.query(idx)
+        resp, packed, _ = srv.answer(q)
+        exp_resp, exp_packed = O.pack_answer(po, out_n, q, wl, wr, v, vw, db)
+        assert_eq(packed, exp_packed, f"packed ciphertext idx={idx} params {nu1},{nu2},{out_n},{kw}")
+        assert_eq(resp, exp_resp, "response")
+    srv.close()
+
+
 def test_pack_raw_ingest(sa, oracle):
     """raw ingest of the trial databases (1 x 1 plaintexts, src/testing.cpp:845-869 + convertDb :316-340 on the device):
     same answers as the device-generated and as the uploaded database"""

@@ -371,6 +371,53 @@ def test_graph_replay_matches_eager(sa, oracle, graphs, overlap):
     srv.close()
 
 
+def _random_parameter_sets(count, seed):
+    """valid parameter sets the fixed cases do not visit: odd gadget dimensions, every q' width, tiny and large plaintext moduli, both
+    query forms, expansions with and without a stop round"""
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < count:
+        nu1, nu2 = int(rng.integers(1, 7)), int(rng.integers(0, 5))
+        kw = dict(t_gsw=int(rng.integers(2, 13)), t_conv=int(rng.choice([1, 2, 3, 4, 7, 8, 16, 28, 56])), t_exp=int(rng.choice([2, 3, 4, 5, 8, 16, 28, 56])),
+                  t_exp_right=int(rng.choice([4, 8, 28, 56])), qprime_bits=int(rng.integers(14, 37)), p_db=int(rng.choice([2, 4, 256, 4096, 65536, 1 << 20])),
+                  direct_upload=int(rng.integers(0, 2)))
+        if not kw["direct_upload"] and (1 << nu1) + kw["t_gsw"] * nu2 > 2048:
+            continue
+        out.append((nu1, nu2, kw))
+    return out
+
+
+@pytest.mark.parametrize("nu1,nu2,kw", _random_parameter_sets(16, 2024), ids=[f"set{i}" for i in range(16)])
+def test_random_parameter_sets_bit_exact(sa, oracle, nu1, nu2, kw):
+    """a seeded draw of parameter sets: the folded ciphertext of the eager stages and of the whole-query graph == the oracle's, word for
+    word (whether such a set decodes is the noise model's business, not the server's)"""
+    O = oracle
+    from spiral_amd import server as SV
+
+    po, pg = O.make_params(nu1, nu2, **kw), sa.make_params(nu1, nu2, **kw)
+    cl = O.Client(po, seed=nu1 * 31 + nu2)
+    wl, wr, w, v = cl.pub_params()
+    seed = 77 + nu1
+    db = O.gen_db(po, seed)
+    srv = sa.Server(pg)
+    srv.gen_db(seed)
+    srv.set_pub_params(wl, wr, w, v)
+    total = 1 << (nu1 + nu2)
+    for k, idx in enumerate((0, total - 1, total // 3)):
+        q = cl.query(idx)
+        want = O.answer(po, q, wl, wr, w, v, db)
+        if k == 0:
+            fin, resp, _ = srv.answer(q)
+        else:
+            srv.use_graphs(True)
+            srv.set_query(q)
+            srv.run_query()
+            srv.sync()
+            fin = srv.read(SV.BUF_FINAL)
+        assert_eq(fin, want, f"final ciphertext, idx={idx}, params {nu1},{nu2},{kw}")
+    srv.close()
+
+
 def test_two_query_lanes_share_one_database(sa, oracle):
     """share_db: a second server handle sweeps the first one's database image; queries of two clients in flight on two streams,
     interleaved, every answer bit-exact; loading through the lane is refused"""
