@@ -94,6 +94,16 @@ int spiral_gpu_gadget_invert(uint64_t *out, const uint64_t *in, size_t mx, size_
 /* getRescaled, src/poly.cpp:593 : element-wise rescale(a % Q, inp_mod, out_mod) */
 int spiral_gpu_get_rescaled(uint64_t *out, const uint64_t *in, size_t n, uint64_t inp_mod, uint64_t out_mod);
 
+/* Wire form of a switched response [(out_n+1)][out_n][N] (base Spiral: out_n = 2): one little-endian bit stream written the way
+ * write_arbitrary_bits does (src/core.cpp:32-52) along modswitch's walk over rows, columns and coefficients (src/spiral.cpp:
+ * 40-76), at the two widths the summary's "Response size" assumes (src/spiral.cpp:231-233): row 0 -- the q' row -- at qprime_bits
+ * per coefficient, the other rows at ceil(log2(4 p_db)) bits.  20 480 bytes instead of 98 304 at config 2.
+ * spiral_gpu_response_wire_bytes: its size (0 for unsupported parameters); ..._server_read_response_wire: packs the last
+ * answer's response on the device and downloads it; spiral_gpu_response_from_wire: the client's half (load_modswitched_into_ct,
+ * src/client.cpp:90-110), plain host code. */
+size_t spiral_gpu_response_wire_bytes(const spiral_gpu_params *p, uint32_t out_n);
+int spiral_gpu_response_from_wire(const spiral_gpu_params *p, uint32_t out_n, const void *wire, uint64_t *response);
+
 /* ------------------------------------------------------------------------------------------------
  * L5 seams: the server hot-path functions (host buffers, reference layouts)
  * ------------------------------------------------------------------------------------------------ */
@@ -249,6 +259,7 @@ int spiral_gpu_server_keep_cts(spiral_gpu_server *s, int on);
 size_t spiral_gpu_server_buffer_words(spiral_gpu_server *s, int which);
 int spiral_gpu_server_read(spiral_gpu_server *s, int which, uint64_t *out);
 /* overwrite the lifted ciphertexts (raw [num_per][n1][n2][N]) -- lets a test drive fold() alone */
+int spiral_gpu_server_read_response_wire(spiral_gpu_server *s, void *out, size_t capacity);
 int spiral_gpu_server_write_raw(spiral_gpu_server *s, const uint64_t *raw_cts);
 
 /* measurement helper: average duration (ms) of the sweep kernel alone over `iters` launches, timed
@@ -304,6 +315,7 @@ int spiral_gpu_pack_server_answer(spiral_gpu_pack_server *s, const uint64_t *que
                                   double stage_us[8]);
 /* the first-dimension accumulators of one trial of the last answer (fastMultiplyQueryByDatabaseDim1's output, :1050):
  * num_per ciphertexts base_dim x 1, NTT form (tests) */
+int spiral_gpu_pack_server_read_response_wire(spiral_gpu_pack_server *s, void *out, size_t capacity);
 int spiral_gpu_pack_server_read_acc(spiral_gpu_pack_server *s, uint32_t trial, uint64_t *out);
 uint64_t spiral_gpu_pack_server_sweep_bytes(spiral_gpu_pack_server *s); /* algorithmic bytes of ONE trial's sweep */
 

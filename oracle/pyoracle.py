@@ -74,6 +74,8 @@ def lib():
         for name in ("orc_words_w_left", "orc_words_w_right", "orc_words_w", "orc_words_v", "orc_words_query"):
             getattr(_lib, name).restype = C.c_size_t
             getattr(_lib, name).argtypes = [C.POINTER(Params)]
+        _lib.orc_response_wire_bytes.restype = C.c_size_t
+        _lib.orc_response_wire_bytes.argtypes = [C.POINTER(Params), C.c_uint32]
         _lib.orc_rescale.restype = C.c_uint64
         _lib.orc_rescale.argtypes = [C.c_uint64] * 3
         _lib.orc_crt_compose.restype = C.c_uint64
@@ -204,6 +206,28 @@ def build_gadget(rows, cols):
 
 def rescale(a, inp_mod, out_mod):
     return lib().orc_rescale(int(a), int(inp_mod), int(out_mod))
+
+
+def response_wire_bytes(p, out_n=2):
+    return int(lib().orc_response_wire_bytes(C.byref(p), out_n))
+
+
+def response_to_wire(p, resp, out_n=2) -> np.ndarray:
+    """switched response [(out_n+1)][out_n][N] -> its wire bytes (modswitch's walk + write_arbitrary_bits at the two widths)"""
+    resp = np.ascontiguousarray(resp, dtype=np.uint64)
+    n = response_wire_bytes(p, out_n)
+    buf = u64(n // 8 + 1)
+    lib().orc_response_to_wire(C.byref(p), C.c_uint32(out_n), _p(resp), _p(buf))
+    return buf.view(np.uint8)[:n].copy()
+
+
+def response_from_wire(p, wire, out_n=2) -> np.ndarray:
+    n = response_wire_bytes(p, out_n)
+    buf = u64(n // 8 + 1)
+    buf.view(np.uint8)[:n] = np.ascontiguousarray(wire, dtype=np.uint8)[:n]
+    out = u64(out_n + 1, out_n, N)
+    lib().orc_response_from_wire(C.byref(p), C.c_uint32(out_n), _p(buf), _p(out))
+    return out
 
 
 # ---- L5 ----

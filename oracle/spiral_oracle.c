@@ -272,6 +272,62 @@ void orc_invert(uint64_t *out, const uint64_t *in, size_t npolys) { /* src/poly.
     for (size_t i = 0; i < npolys * N; i++) out[i] = Q - in[i];
 }
 
+/* src/core.cpp:20-30 */
+uint64_t orc_read_arbitrary_bits(const uint64_t *p, size_t bit_offs, size_t num_bits) {
+    size_t word_off = bit_offs / 64, within = bit_offs % 64;
+    if (within + num_bits <= 64) return (p[word_off] >> within) & ((1ULL << num_bits) - 1);
+    unsigned __int128 val = (unsigned __int128)p[word_off] | ((unsigned __int128)p[word_off + 1] << 64);
+    return (uint64_t)(val >> within) & ((1ULL << num_bits) - 1);
+}
+/* src/core.cpp:32-52 */
+void orc_write_arbitrary_bits(uint64_t *p, uint64_t val, size_t bit_offs, size_t num_bits) {
+    size_t word_off = bit_offs / 64, within = bit_offs % 64;
+    val &= (1ULL << num_bits) - 1;
+    if (within + num_bits <= 64) {
+        p[word_off] &= ~(((1ULL << num_bits) - 1) << within);
+        p[word_off] |= val << within;
+    } else {
+        unsigned __int128 cur = (unsigned __int128)p[word_off] | ((unsigned __int128)p[word_off + 1] << 64);
+        cur &= ~((unsigned __int128)((1ULL << num_bits) - 1) << within);
+        cur |= (unsigned __int128)val << within;
+        p[word_off] = (uint64_t)cur;
+        p[word_off + 1] = (uint64_t)(cur >> 64);
+    }
+}
+static uint32_t wire_bits_rest(const orc_params *p) { /* bits that hold a value below 4 p_db (pt_mod + 2 for a power of two, spiral.cpp:232) */
+    uint32_t b = 0;
+    while ((1ULL << b) < 4 * p->p_db) b++;
+    return b;
+}
+size_t orc_response_wire_bytes(const orc_params *p, uint32_t out_n) {
+    return ((size_t)out_n * N * p->qprime_bits + (size_t)out_n * out_n * N * wire_bits_rest(p)) / 8;
+}
+/* the walk of modswitch, src/spiral.cpp:40-76, over an already switched response */
+void orc_response_to_wire(const orc_params *p, uint32_t out_n, const uint64_t *resp, uint64_t *wire) {
+    size_t rs = out_n + 1, cs = out_n, bit_offs = 0;
+    memset(wire, 0, orc_response_wire_bytes(p, out_n) + 8);
+    for (size_t r = 0; r < rs; r++) {
+        size_t width = r == 0 ? p->qprime_bits : wire_bits_rest(p);
+        for (size_t c = 0; c < cs; c++)
+            for (size_t m = 0; m < N; m++) {
+                orc_write_arbitrary_bits(wire, resp[(r * cs + c) * N + m], bit_offs, width);
+                bit_offs += width;
+            }
+    }
+}
+/* load_modswitched_into_ct, src/client.cpp:90-110 */
+void orc_response_from_wire(const orc_params *p, uint32_t out_n, const uint64_t *wire, uint64_t *resp) {
+    size_t rs = out_n + 1, cs = out_n, bit_offs = 0;
+    for (size_t r = 0; r < rs; r++) {
+        size_t width = r == 0 ? p->qprime_bits : wire_bits_rest(p);
+        for (size_t c = 0; c < cs; c++)
+            for (size_t m = 0; m < N; m++) {
+                resp[(r * cs + c) * N + m] = orc_read_arbitrary_bits(wire, bit_offs, width);
+                bit_offs += width;
+            }
+    }
+}
+
 /* src/poly.cpp:578-591 */
 uint64_t orc_rescale(uint64_t a, uint64_t inp_mod, uint64_t out_mod) {
     int64_t v = (int64_t)(a % inp_mod);

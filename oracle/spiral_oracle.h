@@ -80,6 +80,16 @@ void orc_mul_by_const(uint64_t *out, const uint64_t *single, const uint64_t *a,
 void orc_automorph(uint64_t *out, const uint64_t *in, size_t npolys, uint64_t t); /* poly.cpp:240 */
 void orc_invert(uint64_t *out, const uint64_t *in, size_t npolys);            /* poly.cpp:269 */
 uint64_t orc_rescale(uint64_t a, uint64_t inp_mod, uint64_t out_mod);         /* poly.cpp:578 */
+/* bit-granular little-endian field access, core.cpp:20-52 (num_bits < 64; buffers carry one spare word at the end) */
+uint64_t orc_read_arbitrary_bits(const uint64_t *p, size_t bit_offs, size_t num_bits);
+void orc_write_arbitrary_bits(uint64_t *p, uint64_t val, size_t bit_offs, size_t num_bits);
+/* wire form of a switched response [(out_n+1)][out_n][N] (base Spiral: out_n = 2): the walk of modswitch (spiral.cpp:40-76:
+ * rows, columns, coefficients, one contiguous bit stream written with write_arbitrary_bits) at the two widths the summary's
+ * "Response size" assumes (spiral.cpp:231-233): row 0 -- the q' row -- at qprime_bits per coefficient, the other rows at
+ * ceil(log2(4 p_db)).  orc_response_wire_bytes = that size; the buffer handed to to_wire / from_wire holds 8 more bytes. */
+size_t orc_response_wire_bytes(const orc_params *p, uint32_t out_n);
+void orc_response_to_wire(const orc_params *p, uint32_t out_n, const uint64_t *resp, uint64_t *wire);
+void orc_response_from_wire(const orc_params *p, uint32_t out_n, const uint64_t *wire, uint64_t *resp);
 uint64_t orc_crt_compose(uint64_t x, uint64_t y);                             /* poly.cpp:344 */
 
 /* ---- L3: gadget (src/util.cpp:89-144, include/util.h:34) ---- */

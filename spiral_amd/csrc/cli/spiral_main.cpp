@@ -72,7 +72,11 @@ static int run_high_rate(spiral_gpu_params p, uint32_t out_n, uint64_t idx_targe
     double us[8];
     GPU_OK(spiral_gpu_pack_server_answer(srv, query.data(), resp.data(), nullptr, us));  // warm-up
     GPU_OK(spiral_gpu_pack_server_answer(srv, query.data(), resp.data(), nullptr, us));
+    // the response travels in its wire form (bit-packed on the device, include/spiral_gpu.h); the client unpacks and decodes it
+    std::vector<uint8_t> wire(spiral_gpu_response_wire_bytes(&p, out_n));
+    GPU_OK(spiral_gpu_pack_server_read_response_wire(srv, wire.data(), wire.size()));
     t0 = now_us();
+    GPU_OK(spiral_gpu_response_from_wire(&p, out_n, wire.data(), resp.data()));
     Poly pt = cl.decode(resp.data());
     const double time_decoding = (double)(now_us() - t0);
     Poly corr = pack_db_item(db_seed, idx_target, total_n, out_n, p.p_db);
@@ -227,7 +231,11 @@ int main(int argc, char** argv) {
     cout << "Done with query processing!" << endl;
 
     // ---- client decode + check_final (src/spiral.cpp:1412-1494)
+    // the response travels in its wire form (bit-packed on the device, include/spiral_gpu.h); the client unpacks and decodes it
+    std::vector<uint8_t> wire(spiral_gpu_response_wire_bytes(&p, 2));
+    GPU_OK(spiral_gpu_server_read_response_wire(srv, wire.data(), wire.size()));
     t0 = now_us();
+    GPU_OK(spiral_gpu_response_from_wire(&p, 2, wire.data(), resp.data()));
     Poly pt = cl.decode(resp.data());
     time_decoding = (double)(now_us() - t0);
     Poly corr = db_item(db_seed, idx_target, p.p_db);
@@ -242,7 +250,7 @@ int main(int argc, char** argv) {
     const size_t pt_elem_size = (size_t)((2.0 * 2 * N * pt_mod) / 8.0);
     const size_t b_per_elem = (size_t)((double)N * 56 / 8.0);
     const size_t dim0_query_size = (size_t)(qnum_first + qnum_rest) * 2 * b_per_elem;
-    const size_t total_resp_size = (size_t)(((2 * 2 * (double)N * (pt_mod + 2)) + (2 * (double)N * (double)p.qprime_bits)) / 8.0);
+    const size_t total_resp_size = wire.size();  // = ((n0 n0 N (log2 p + 2)) + (n0 N q'bits)) / 8, src/spiral.cpp:231-233
     cout << endl;
     cout << "PIR over n=" << total_n << " elements of size " << pt_elem_size << " bytes each." << endl;
     cout << "The database is structured as " << (1 << nu1) << " x 2^" << nu2 << "." << endl;

@@ -77,6 +77,12 @@ inline int shape_of(const spiral_gpu_params* p, spiral_gpu_shape* s) {
     return 0;
 }
 
+// wire form of a switched response (include/spiral_gpu.h): row 0 at qprime_bits, the rest at the bits that hold a value < 4 p_db
+inline uint32_t wire_bits_rest(const spiral_gpu_params* p) { return ceil_log2(4 * p->p_db); }
+inline size_t wire_bytes(const spiral_gpu_params* p, uint32_t out_n) {
+    return ((size_t)out_n * kN * p->qprime_bits + (size_t)out_n * out_n * kN * wire_bits_rest(p)) / 8;
+}
+
 inline uint32_t inv_mod_2n(uint32_t t) {  // t odd, inverse modulo 2N = 4096
     uint32_t x = 1;
     for (int i = 0; i < 12; i++) x = x * (2 - t * x);  // Newton, doubles the valid bits

@@ -183,6 +183,7 @@ void launch_invert(const uint64_t* in, uint64_t* out, uint32_t npolys, hipStream
 void launch_gadget_invert(const uint64_t* in, uint64_t* out, uint32_t mx, uint32_t rdim, uint32_t cols, hipStream_t s);
 // response modulus switch (src/poly.cpp:578-601, src/spiral.cpp:1441-1447)
 void launch_rescale(const uint64_t* in, uint64_t* out, uint32_t n, uint64_t inp_mod, uint64_t out_mod, hipStream_t s);
+void launch_response_wire(const uint64_t* in, uint64_t* out, uint32_t n0, uint32_t w0, uint32_t n1, uint32_t w1, hipStream_t s);
 void launch_rescale2(const uint64_t* in, uint64_t* out, uint32_t n0, uint32_t n, uint64_t inp_mod, uint64_t out_mod0, uint64_t out_mod1, hipStream_t s);
 
 // ---- expansion / conversion / fold specials ----------------------------------------------------------

@@ -16,7 +16,7 @@ struct spiral_gpu_pack_server {
     uint32_t n_cv = 0;
     size_t db_words = 0;  // per trial
     DevBuf db, w_left, w_right, v, v_w, query, cv, ex_raw, ex_g;
-    DevBuf gs_raw, gs_chat, gs_tmp, gsw, key, qs1, acc, raw, fold_d, fold_c, pk_ginv, pk_ct2, pk_res, pk_raw, resp, stage;
+    DevBuf gs_raw, gs_chat, gs_tmp, gsw, key, qs1, acc, raw, fold_d, fold_c, pk_ginv, pk_ct2, pk_res, pk_raw, resp, stage, wire;
     hipEvent_t ev[8] = {};
 };
 
@@ -51,7 +51,7 @@ int pack_shape_of(const spiral_gpu_params* p, uint32_t out_n, spiral_gpu_pack_sh
 void pk_free(spiral_gpu_pack_server* S) {
     DevBuf* all[] = {&S->db, &S->w_left, &S->w_right, &S->v, &S->v_w, &S->query, &S->cv, &S->ex_raw, &S->ex_g, &S->gs_raw, &S->gs_chat, &S->gs_tmp,
                      &S->gsw, &S->key, &S->qs1, &S->acc, &S->raw, &S->fold_d, &S->fold_c, &S->pk_ginv, &S->pk_ct2, &S->pk_res, &S->pk_raw, &S->resp,
-                     &S->stage};
+                     &S->stage, &S->wire};
     for (DevBuf* b : all) b->release();
     for (auto& e : S->ev)
         if (e) (void)hipEventDestroy(e);
@@ -424,6 +424,18 @@ int spiral_gpu_pack_server_answer(spiral_gpu_pack_server* S, const uint64_t* que
         stage_us[6] = total * 1e3;
         stage_us[7] = 0;
     }
+    return 0;
+}
+
+int spiral_gpu_pack_server_read_response_wire(spiral_gpu_pack_server* S, void* out, size_t capacity) {
+    if (!S || !out) return fail("null argument");
+    HIP_OK(hipSetDevice(S->device));
+    const size_t nbytes = wire_bytes(&S->p, S->out_n);
+    if (capacity < nbytes) return fail("response buffer of %zu bytes, the wire form needs %zu", capacity, nbytes);
+    if (S->wire.words * 8 < nbytes && (S->wire.release(), S->wire.alloc(nbytes / 8))) return -1;
+    launch_response_wire(S->resp.p, S->wire.p, S->out_n * kN, S->p.qprime_bits, S->out_n * S->out_n * kN, wire_bits_rest(&S->p), S->stream);
+    HIP_OK(hipMemcpyAsync(out, S->wire.p, nbytes, hipMemcpyDeviceToHost, S->stream));
+    HIP_OK(hipStreamSynchronize(S->stream));
     return 0;
 }
 

@@ -179,6 +179,31 @@ __global__ __launch_bounds__(kTpb) void rescale2_kernel(const uint64_t* in, uint
     const uint32_t i = blockIdx.x * kTpb + threadIdx.x;
     if (i < n) out[i] = rescale_dev(in[i] % kQ, inp_mod, i < n0 ? out_mod0 : out_mod1);
 }
+// wire form of a switched response (the bit stream write_arbitrary_bits builds, src/core.cpp:32-52, along modswitch's walk,
+// src/spiral.cpp:40-76): values [0, n0) at w0 bits each, then values [n0, n0 + n1) at w1 bits; one thread per 64-bit output
+// word gathers the fields that overlap it (both segments are whole words: N = 2048 values per polynomial)
+__global__ __launch_bounds__(kTpb) void response_wire_kernel(const uint64_t* in, uint64_t* out, uint32_t n0, uint32_t w0, uint32_t n1, uint32_t w1) {
+    const uint32_t k = blockIdx.x * kTpb + threadIdx.x;
+    const uint32_t words0 = n0 / 64u * w0, words1 = n1 / 64u * w1;
+    if (k >= words0 + words1) return;
+    const bool second = k >= words0;
+    const uint32_t w = second ? w1 : w0;
+    const uint64_t bit0 = (uint64_t)(second ? k - words0 : k) * 64u;  // first bit of this word inside its segment
+    const uint64_t* v = in + (second ? n0 : 0);
+    const uint32_t nv = second ? n1 : n0;
+    const uint64_t mask = (1ull << w) - 1;
+    uint64_t word = 0;
+    for (uint32_t i = (uint32_t)(bit0 / w); i < nv && (uint64_t)i * w < bit0 + 64; i++) {
+        const uint64_t x = v[i] & mask;
+        const int64_t sh = (int64_t)((uint64_t)i * w) - (int64_t)bit0;  // position of the field's bit 0 relative to this word
+        word |= sh >= 0 ? x << sh : x >> (-sh);
+    }
+    out[k] = word;
+}
+void launch_response_wire(const uint64_t* in, uint64_t* out, uint32_t n0, uint32_t w0, uint32_t n1, uint32_t w1, hipStream_t s) {
+    const uint32_t words = n0 / 64u * w0 + n1 / 64u * w1;
+    hipLaunchKernelGGL(response_wire_kernel, dim3((words + kTpb - 1) / kTpb), dim3(kTpb), 0, s, in, out, n0, w0, n1, w1);
+}
 void launch_rescale2(const uint64_t* in, uint64_t* out, uint32_t n0, uint32_t n, uint64_t inp_mod, uint64_t out_mod0, uint64_t out_mod1, hipStream_t s) {
     if (n) hipLaunchKernelGGL(rescale2_kernel, dim3((n + kTpb - 1) / kTpb), dim3(kTpb), 0, s, in, out, n0, n, inp_mod, out_mod0, out_mod1);
 }

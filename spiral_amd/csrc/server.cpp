@@ -20,6 +20,7 @@ struct spiral_gpu_server {
     hipStream_t own_stream = nullptr, stream = nullptr;
     DeviceTables tb;
     bool keep_cts = false, have_db = false, have_pp = false, have_query = false;
+    DevBuf wire;  // bit-packed response (read_response_wire)
     bool db_shared = false;  // db.p is another server's image (share_db): never written, never freed here
     // expanded-ciphertext positions inside cv: first-dim j at j*pos_stride + pos_first, rest i at i*pos_stride + pos_rest
     uint32_t pos_stride = 1, pos_first = 0, pos_rest = 0, n_cv = 0;
@@ -125,7 +126,7 @@ void srv_free(spiral_gpu_server* S) {
     srv_drop_graphs(S);
     DevBuf* all[] = {&S->db, &S->w_left, &S->w_right, &S->w, &S->v, &S->query, &S->cv, &S->ex_raw, &S->ex_g, &S->cv_raw,
                      &S->cv_g, &S->gsw, &S->key, &S->cts_keep, &S->qs, &S->acc_own, &S->raw, &S->fold_d, &S->fold_c, &S->fold_p[0], &S->fold_p[1],
-                     &S->resp, &S->stage};
+                     &S->resp, &S->stage, &S->wire};
     if (S->db_shared) S->db.p = nullptr;
     for (DevBuf* b : all) b->release();
     for (auto& e : S->ev)
@@ -1422,6 +1423,42 @@ int spiral_gpu_server_read(spiral_gpu_server* S, int which, uint64_t* out) {
         case SPIRAL_GPU_BUF_RESPONSE: HIP_OK(hipMemcpy(out, S->resp.p, 6 * kPolyBytes, hipMemcpyDeviceToHost)); return 0;
         default: return fail("unknown buffer %d", which);
     }
+}
+
+size_t spiral_gpu_response_wire_bytes(const spiral_gpu_params* p, uint32_t out_n) {
+    if (!p || out_n < 1 || out_n > 16 || p->qprime_bits < 1 || p->qprime_bits > 36 || p->p_db < 2 || p->p_db > (1ull << 40)) return 0;
+    return wire_bytes(p, out_n);
+}
+
+int spiral_gpu_server_read_response_wire(spiral_gpu_server* S, void* out, size_t capacity) {
+    if (!S || !out) return fail("null argument");
+    HIP_OK(hipSetDevice(S->device));
+    const size_t nbytes = wire_bytes(&S->p, 2);
+    if (capacity < nbytes) return fail("response buffer of %zu bytes, the wire form needs %zu", capacity, nbytes);
+    if (S->wire.words * 8 < nbytes && (S->wire.release(), S->wire.alloc(nbytes / 8))) return -1;
+    launch_response_wire(S->resp.p, S->wire.p, 2 * kN, S->p.qprime_bits, 4 * kN, wire_bits_rest(&S->p), S->stream);
+    HIP_OK(hipMemcpyAsync(out, S->wire.p, nbytes, hipMemcpyDeviceToHost, S->stream));
+    HIP_OK(hipStreamSynchronize(S->stream));
+    return 0;
+}
+
+// client side of the wire form (load_modswitched_into_ct, src/client.cpp:90-110): plain host code, no device involved
+int spiral_gpu_response_from_wire(const spiral_gpu_params* p, uint32_t out_n, const void* wire, uint64_t* response) {
+    if (!p || !wire || !response) return fail("null argument");
+    if (spiral_gpu_response_wire_bytes(p, out_n) == 0) return fail("unsupported parameters for the wire form");
+    const uint8_t* b = (const uint8_t*)wire;
+    const size_t total = wire_bytes(p, out_n);
+    size_t bit = 0;
+    for (uint32_t r = 0; r <= out_n; r++) {
+        const uint32_t w = r == 0 ? p->qprime_bits : wire_bits_rest(p);
+        for (size_t i = 0; i < (size_t)out_n * kN; i++, bit += w) {
+            unsigned __int128 acc = 0;  // up to 42 + 7 bits starting at a byte boundary
+            const size_t first = bit / 8;
+            for (size_t k = 0; k < 8 && first + k < total; k++) acc |= (unsigned __int128)b[first + k] << (8 * k);
+            response[(size_t)r * out_n * kN + i] = (uint64_t)(acc >> (bit % 8)) & ((1ull << w) - 1);
+        }
+    }
+    return 0;
 }
 
 int spiral_gpu_server_write_raw(spiral_gpu_server* S, const uint64_t* raw_cts) {

@@ -16,7 +16,7 @@ Q = P * B
 __all__ = [
     "N", "P", "B", "Q", "make_params", "get_shape", "get_tables", "ntt_forward", "ntt_inverse", "to_ntt", "to_ntt_no_reduce", "from_ntt",
     "multiply", "add", "mul_by_const", "automorph", "invert", "gadget_invert", "getRescaled", "multiplyQueryByDatabase", "split_and_crt",
-    "foldOneFurtherDimension", "expandImproved", "scalToMat", "regevToGSW", "time_ntt",
+    "foldOneFurtherDimension", "expandImproved", "scalToMat", "regevToGSW", "time_ntt", "response_wire_bytes", "response_from_wire",
 ]
 
 
@@ -128,6 +128,20 @@ def getRescaled(a, inp_mod, out_mod) -> np.ndarray:
     a = _c(a)
     out = np.zeros_like(a)
     check(lib().spiral_gpu_get_rescaled(_p(out), _p(a), a.size, int(inp_mod), int(out_mod)))
+    return out
+
+
+def response_wire_bytes(params, out_n: int = 2) -> int:
+    """size of a response's wire form (include/spiral_gpu.h): the "Response size" of the reference's summary"""
+    return int(lib().spiral_gpu_response_wire_bytes(C.byref(params), out_n))
+
+
+def response_from_wire(params, wire, out_n: int = 2) -> np.ndarray:
+    """client half of the wire form (load_modswitched_into_ct, src/client.cpp:90): bytes -> [(out_n+1)][out_n][N] values; host code"""
+    wire = np.ascontiguousarray(wire, dtype=np.uint8)
+    assert wire.size >= response_wire_bytes(params, out_n)
+    out = np.zeros((out_n + 1, out_n, N), dtype=np.uint64)
+    check(lib().spiral_gpu_response_from_wire(C.byref(params), out_n, wire.ctypes.data_as(C.c_void_p), _p(out)))
     return out
 
 

@@ -78,6 +78,13 @@ class PackServer:
         check(lib().spiral_gpu_pack_server_read_acc(self.h, trial, _p(out)))
         return out
 
+    def read_response_wire(self) -> np.ndarray:
+        """the last answer's response in its wire form (bit-packed on the device): bytes"""
+        n = lib().spiral_gpu_response_wire_bytes(C.byref(self.params), self.out_n)
+        out = np.zeros(n, dtype=np.uint8)
+        check(lib().spiral_gpu_pack_server_read_response_wire(self.h, out.ctypes.data_as(C.c_void_p), n))
+        return out
+
     def fill_db_random(self, seed: int):
         check(lib().spiral_gpu_pack_server_fill_db_random(self.h, seed))
 

@@ -192,6 +192,13 @@ class Server:
     def keep_cts(self, on: bool = True):
         check(lib().spiral_gpu_server_keep_cts(self.h, 1 if on else 0))
 
+    def read_response_wire(self) -> np.ndarray:
+        """the last answer's response in its wire form (bit-packed on the device): bytes"""
+        n = lib().spiral_gpu_response_wire_bytes(C.byref(self.params), 2)
+        out = np.zeros(n, dtype=np.uint8)
+        check(lib().spiral_gpu_server_read_response_wire(self.h, out.ctypes.data_as(C.c_void_p), n))
+        return out
+
     def read(self, which: int) -> np.ndarray:
         words = lib().spiral_gpu_server_buffer_words(self.h, which)
         out = np.zeros(words, dtype=np.uint64)

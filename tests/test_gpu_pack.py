@@ -105,6 +105,26 @@ def test_pack_server_matches_oracle(sa, oracle, nu1, nu2, out_n, kw):
     srv2.close()
 
 
+@pytest.mark.parametrize("nu1,nu2,out_n,kw", [(4, 2, 2, dict(t_gsw=4)), (3, 2, 5, dict(t_gsw=3, t_conv=56, t_exp=56, qprime_bits=31, p_db=524288, direct_upload=1))])
+def test_pack_response_wire_form(sa, oracle, nu1, nu2, out_n, kw):
+    """SpiralPack response bit-packed on the device: n polynomials at q' bits, n^2 at log2(4p) bits == the oracle's wire bytes"""
+    O = oracle
+    po, pg = O.make_params(nu1, nu2, **kw), sa.make_params(nu1, nu2, **kw)
+    cl = O.PackClient(po, out_n, seed=4)
+    srv = sa.PackServer(pg, out_n)
+    srv.gen_db(11)
+    srv.set_pub_params(*cl.pub_params())
+    s = O.pack_shape_of(po, out_n)
+    for idx in (1, s.dim0 * s.num_per - 1):
+        resp, _, _ = srv.answer(cl.query(idx), want_packed=False)
+        wire = srv.read_response_wire()
+        assert wire.size == O.response_wire_bytes(po, out_n)
+        assert_eq(wire, O.response_to_wire(po, resp, out_n), "wire bytes")
+        assert_eq(sa.response_from_wire(pg, wire, out_n), resp, "client unpack")
+        assert_eq(cl.decode(sa.response_from_wire(pg, wire, out_n)), O.pack_db_item(po, out_n, 11, idx), "decoded from the wire form")
+    srv.close()
+
+
 def _random_pack_sets(count, seed):
     rng = np.random.default_rng(seed)
     out = []

@@ -371,6 +371,29 @@ def test_graph_replay_matches_eager(sa, oracle, graphs, overlap):
     srv.close()
 
 
+@pytest.mark.parametrize("kw", [dict(t_gsw=4), dict(t_gsw=4, qprime_bits=27, p_db=32768, direct_upload=1), dict(t_gsw=5, qprime_bits=36, p_db=8388592),
+                                dict(t_gsw=4, qprime_bits=14, p_db=4)])
+def test_response_wire_form(sa, oracle, kw):
+    """the response bit-packed on the device == the oracle's wire bytes of the same response; unpacked by the client half it is the
+    response again and decodes to the item where the parameters allow"""
+    O = oracle
+    from spiral_amd import server as SV
+
+    po, pg = O.make_params(4, 3, **kw), sa.make_params(4, 3, **kw)
+    cl = O.Client(po, seed=3)
+    srv = sa.Server(pg)
+    srv.gen_db(9)
+    srv.set_pub_params(*cl.pub_params())
+    for idx in (0, 77, 127):
+        fin, resp, _ = srv.answer(cl.query(idx))
+        wire = srv.read_response_wire()
+        assert wire.size == sa.response_wire_bytes(pg) and wire.size < resp.size * 8 // 2
+        assert_eq(wire, O.response_to_wire(po, resp), f"wire bytes idx={idx}")
+        assert_eq(sa.response_from_wire(pg, wire), resp, "client unpack")
+        assert_eq(srv.read(SV.BUF_RESPONSE), resp, "response buffer untouched")
+    srv.close()
+
+
 def _random_parameter_sets(count, seed):
     """valid parameter sets the fixed cases do not visit: odd gadget dimensions, every q' width, tiny and large plaintext moduli, both
     query forms, expansions with and without a stop round"""

@@ -213,3 +213,31 @@ def test_threaded_native_build_gives_identical_results(oracle, oracle_mt):
     zs = [0, 5, 2047, 1024]
     sub = O.multiply_query_by_database_slots(re[zs], dbr.reshape(O.N, -1)[zs], dim0, num_per)
     assert np.array_equal(sub, full[..., zs])
+
+
+def test_response_wire_form_round_trip_and_host_unpack(oracle):
+    """the bit-packed response (write_arbitrary_bits along modswitch's walk, src/core.cpp:20-52, src/spiral.cpp:40-76) at the two widths
+    of the summary's response size: size == the reference's formula (20 480 B at config 2), fields at their bit offsets, the
+    oracle's and the library's host-side unpack both invert it"""
+    import spiral_amd as sa
+
+    O = oracle
+    rng = np.random.default_rng(3)
+    assert O.response_wire_bytes(O.make_params(8, 7)) == 20480  # BASELINE.md: response 20 480 B at (20, 256)
+    for kw in (dict(), dict(qprime_bits=27, p_db=32768), dict(qprime_bits=36, p_db=8388592), dict(qprime_bits=14, p_db=2), dict(qprime_bits=31, p_db=524288)):
+        for out_n in (2, 3, 12):
+            po, pg = O.make_params(8, 7, **kw), sa.make_params(8, 7, **kw)
+            w0, w1 = po.qprime_bits, int(np.ceil(np.log2(4 * po.p_db)))
+            resp = np.zeros((out_n + 1, out_n, N), dtype=np.uint64)
+            resp[0] = rng.integers(0, 1 << w0, size=(out_n, N), dtype=np.uint64)
+            resp[1:] = rng.integers(0, 4 * po.p_db, size=(out_n, out_n, N), dtype=np.uint64)
+            resp[0, 0, :2] = [(1 << w0) - 1, 0]
+            resp[-1, -1, -1] = 4 * po.p_db - 1
+            wire = O.response_to_wire(po, resp, out_n)
+            assert len(wire) == (out_n * N * w0 + out_n * out_n * N * w1) // 8 == sa.response_wire_bytes(pg, out_n)
+            bits = np.unpackbits(wire, bitorder="little")
+            val = lambda off, w: int(sum(int(b) << i for i, b in enumerate(bits[off:off + w])))
+            assert val(0, w0) == (1 << w0) - 1 and val(w0, w0) == 0 and val(7 * w0, w0) == int(resp[0, 0, 7])
+            assert val(out_n * N * w0 + 5 * w1, w1) == int(resp[1, 0, 5]) and val(len(bits) - w1, w1) == 4 * po.p_db - 1
+            assert (O.response_from_wire(po, wire, out_n) == resp).all()
+            assert (sa.response_from_wire(pg, wire, out_n) == resp).all()
