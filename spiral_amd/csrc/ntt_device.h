@@ -27,6 +27,15 @@ struct TwTable {
         return make_uint4(v.x, v.y, v.z, v.w);
     }
 };
+// tuning hook (tools/build_variants.sh): -DNTT_PRIO=n raises the wave's issue priority from the LDS stores of a pass up to the
+// twiddle loads of the next one (the memory-pipe part of the exchange) and drops it to 0 for the butterflies
+#ifdef NTT_PRIO
+#define NTT_PRIO_HI() __builtin_amdgcn_s_setprio(NTT_PRIO)
+#define NTT_PRIO_LO() __builtin_amdgcn_s_setprio(0)
+#else
+#define NTT_PRIO_HI() ((void)0)
+#define NTT_PRIO_LO() ((void)0)
+#endif
 #ifdef NTT_ABLATE_BARRIER
 #define NTT_SYNC() ((void)0)
 #else
@@ -295,24 +304,30 @@ __device__ __forceinline__ void ntt_forward_block(uint32_t* lo, uint32_t* hi, ui
     const TwTable tb(tw);
     Tw7 wb = tw_load8(tb, 8 + (tid >> 5), 16 + 2 * (tid >> 5), 32 + 4 * (tid >> 5));
     ct_radix8(lo, hi, tw, 1, 2, 4);
+    NTT_PRIO_HI();
     lds_put<ix_a>(sh, tid, lo, hi);
     NTT_SYNC();
     lds_get<ix_b>(sh, tid, lo, hi);
     Tw7 wc = tw_load8(tb, 64 + (tid >> 2), 128 + 2 * (tid >> 2), 256 + 4 * (tid >> 2));
+    NTT_PRIO_LO();
     ct_radix8_pre(lo, hi, wb);
+    NTT_PRIO_HI();
     lds_put<ix_b>(sh, tid, lo, hi);
     NTT_SYNC();
     lds_get<ix_c>(sh, tid, lo, hi);
+    Tw7 wd = tw_load4x2(tb, 512 + 2 * tid, 1024 + 4 * tid);
+    NTT_PRIO_LO();
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         lo[k] = lazy_reduce(lo[k], kP);
         hi[k] = lazy_reduce(hi[k], kB);
     }
-    Tw7 wd = tw_load4x2(tb, 512 + 2 * tid, 1024 + 4 * tid);
     ct_radix8_pre(lo, hi, wc);
+    NTT_PRIO_HI();
     lds_put<ix_c>(sh, tid, lo, hi);
     NTT_SYNC();
     lds_get<ix_d>(sh, tid, lo, hi);
+    NTT_PRIO_LO();
     ct_radix4x2_pre(lo, hi, wd);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -334,19 +349,25 @@ __device__ __forceinline__ void ntt_inverse_block(uint32_t* lo, uint32_t* hi, ui
     Tw7 wd = tw_load4x2(tb, 512 + 2 * tid, 1024 + 4 * tid);
     Tw7 wc = tw_load8(tb, 64 + (tid >> 2), 128 + 2 * (tid >> 2), 256 + 4 * (tid >> 2));
     gs_radix4x2_pre(lo, hi, wd);
+    NTT_PRIO_HI();
     lds_put<ix_d>(sh, tid, lo, hi);
     __syncthreads();
     lds_get<ix_c>(sh, tid, lo, hi);
     Tw7 wb = tw_load8(tb, 8 + (tid >> 5), 16 + 2 * (tid >> 5), 32 + 4 * (tid >> 5));
+    NTT_PRIO_LO();
     gs_radix8_pre(lo, hi, wc);
+    NTT_PRIO_HI();
     lds_put<ix_c>(sh, tid, lo, hi);
     __syncthreads();
     lds_get<ix_b>(sh, tid, lo, hi);
     Tw7 wa = tw_load8(tw, 1, 2, 4);
+    NTT_PRIO_LO();
     gs_radix8_pre(lo, hi, wb);
+    NTT_PRIO_HI();
     lds_put<ix_b>(sh, tid, lo, hi);
     __syncthreads();
     lds_get<ix_a>(sh, tid, lo, hi);
+    NTT_PRIO_LO();
     gs_radix8_pre(lo, hi, wa);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
