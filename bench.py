@@ -129,47 +129,99 @@ WORKLOADS = {
 
 def bench_pack(args):
     """--workload pack: BASELINE.json configs[4], SpiralPack 2^18 x 30 KB (all_parameter_choices.txt "(18, 30000)"/spiral-pack:
-    nu1=10, nu2=8, n=4, p=256, q'=2^20, t_GSW=8, t_conv=4, t_exp=16) -- 16 trial databases of 4 GiB, one GPU.  A step is one
-    whole answer (expansion, conversion, 16 first-dimension sweeps, folding, packing, modulus switch), timed on the host
-    around PackServer.answer (query upload and response download included: 64 KiB + 160 KiB against 11 ms)."""
+    nu1=10, nu2=8, n=4, p=256, q'=2^20, t_GSW=8, t_conv=4, t_exp=16) -- 16 trial databases of 4 GiB.  A step is one whole answer
+    (expansion, conversion, 16 first-dimension sweeps, folding, packing, modulus switch).  One GPU: timed on the host around
+    PackServer.answer (query upload and response download included: 64 KiB + 160 KiB against 11 ms).  N GPUs: the trials are
+    independent up to the packing step, so the ranks split them (16 / N each); one all-gather of the 16 folded ciphertexts
+    (512 KiB), rank 0 packs (include/spiral_gpu.h, spiral_gpu_pack_server_create_sharded)."""
     import numpy as np
     import torch
 
     import spiral_amd as sa
 
-    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
-        raise SystemExit("--workload pack runs on one GPU")
+    world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     out_n = 4
     pg = sa.make_params(10, 8, t_gsw=8, t_conv=4, t_exp=16, t_exp_right=56, qprime_bits=20, p_db=256)
     shp = sa.get_pack_shape(pg, out_n)
-    srv = sa.PackServer(pg, out_n)
+    if shp.trials % world:
+        raise SystemExit(f"{shp.trials} trials do not split evenly over {world} ranks")
+    use_dist = world > 1 or args.force_dist
+    if args.shared_device:
+        local_rank = 0
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if use_dist:
+        import torch.distributed as dist
+
+        kw = {"device_id": dev} if args.backend == "nccl" else {}
+        dist.init_process_group(args.backend, rank=rank, world_size=world, **kw)
+    per = shp.trials // world
+    srv = sa.PackServer(pg, out_n, local_rank, rank * per, (rank + 1) * per)
+    stream = torch.cuda.Stream(device=dev)
+    srv.set_stream(stream.cuda_stream)
     srv.gen_db(2024)
-    rng = np.random.default_rng(1)
+    rng = np.random.default_rng(1)  # the same synthetic keys and query on every rank
     srv.set_pub_params(synth_residues(rng, np, (shp.n_left, 2, pg.t_exp)), synth_residues(rng, np, (shp.n_right, 2, pg.t_exp_right)),
                        synth_residues(rng, np, (2, 2 * pg.t_conv)), synth_residues(rng, np, (out_n, out_n + 1, pg.t_conv)))
     q = synth_residues(rng, np, (shp.n_query_cts, 2))
-    for _ in range(args.warmup):
-        srv.answer(q, want_packed=False)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    us = [srv.answer(q, want_packed=False)[2] for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    mine = torch.zeros(per * 2 * sa.N, dtype=torch.int64, device=dev)
+    gathered = torch.zeros(shp.trials * 2 * sa.N, dtype=torch.int64, device=dev)
+    us = []
+
+    def step():
+        if not use_dist:
+            us.append(srv.answer(q, want_packed=False)[2])
+            return
+        srv.fold_trials(q, mine.data_ptr())
+        dist.all_gather_into_tensor(gathered, mine)  # 32 KiB per trial
+        if rank == 0:
+            srv.pack_gathered(gathered.data_ptr())
+        us.append(srv.stage_us())
+
+    def fence():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            step()
+        us.clear()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+    ms = dt * 1e3 / args.steps
     sweep_ms = sum(u["sweep_kernels_us"] for u in us) / len(us) / 1e3
-    nbytes = shp.trials * srv.sweep_bytes()
+    nbytes = per * srv.sweep_bytes()
     achieved = nbytes / (sweep_ms * 1e-3) / 1e9
-    out = {"metric": "server ms/query + DB GB/s vs HBM roofline (pack)", "value": round(ms, 4), "unit": "ms/query", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+    out = {"metric": "server ms/query + DB GB/s vs HBM roofline (pack)", "value": round(ms, 4), "unit": "ms/query", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms, 4), "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
            "dtype": "u32 residues, 32x32->64-bit integer MAC (two 28-bit CRT primes)", "data": "synthetic",
            "config": {"workload": "configs[4]: SpiralPack 2^18 x 30KB (nu1=10, nu2=8, n=4, p=256, t_GSW=8, t_conv=4, t_exp=16, q'=2^20), 16 explicit trial databases generated on device",
-                      "db_bytes_ntt_form": int(shp.trials) * int(shp.dim0) * int(shp.num_per) * sa.N * 8},
+                      "db_bytes_ntt_form": int(shp.trials) * int(shp.dim0) * int(shp.num_per) * sa.N * 8,
+                      "parallelism": f"trials x{world} ({per} per rank), one all-gather of the folded ciphertexts, rank 0 packs" if use_dist else "one GPU"},
            "stages_us": {k: round(sum(u[k] for u in us) / len(us), 1) for k in us[0]},
-           "roofline": {"bound": "hbm", "kernel": "sweep1_kernel (16 trials)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+           "roofline": {"bound": "hbm", "kernel": f"sweep1_kernel ({per} trials per launch group, rank 0)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                         "traffic": None, "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_ms": round(sweep_ms, 4)}}
     srv.close()
-    print(json.dumps(out), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+    if rank == 0:
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 def main():

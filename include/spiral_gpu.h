@@ -295,6 +295,20 @@ int spiral_gpu_fast_multiply_query_by_database_dim1(uint64_t *out, const uint64_
 
 /* resident server for testHighRate's server half (src/testing.cpp:1009-1081) */
 int spiral_gpu_pack_server_create(const spiral_gpu_params *p, uint32_t out_n, int device, spiral_gpu_pack_server **out);
+/* N GPUs (pack variant): the out_n^2 trials are independent up to the packing step, so the ranks split THEM -- a server
+ * for trials [trial0, trial1) holds only those database images (trial indices in load_db / load_db_items / read_acc stay global).
+ * Per query: every rank runs fold_trials (expansion + conversion, replicated; its trials' sweeps and folding; leaves their folded
+ * ciphertexts, [n_local][2][N] raw words, in the caller's device buffer), ONE all-gather of out_n^2 x 32 KiB collects them in trial
+ * order, the root runs pack_gathered (pack + modulus switch).  No reduction of accumulators is needed: the j-shard + reduce of the
+ * base path would move out_n^2 x num_per x 32 KiB here (128 MiB at configs[4]) over point-to-point xGMI, this moves 512 KiB.
+ * (0, 0) = all trials = spiral_gpu_pack_server_create.  set_stream: run on the caller's stream (the one its collectives use). */
+int spiral_gpu_pack_server_create_sharded(const spiral_gpu_params *p, uint32_t out_n, int device, uint32_t trial0, uint32_t trial1,
+                                          spiral_gpu_pack_server **out);
+int spiral_gpu_pack_server_set_stream(spiral_gpu_pack_server *s, void *hip_stream);
+int spiral_gpu_pack_server_fold_trials(spiral_gpu_pack_server *s, const uint64_t *query, void *folded_dev);
+/* stage times (as answer's stage_us) of the last answer or fold_trials from the events between its stages; synchronises */
+int spiral_gpu_pack_server_stage_us(spiral_gpu_pack_server *s, double stage_us[8]);
+int spiral_gpu_pack_server_pack_gathered(spiral_gpu_pack_server *s, const void *gathered_dev, uint64_t *response, uint64_t *packed_ct);
 void spiral_gpu_pack_server_destroy(spiral_gpu_pack_server *s);
 /* the out_n^2 trial databases: seeded explicit data generated on the device (coefficient z of item i of trial t =
  * splitmix64(seed ^ ((t*n + i)*N + z)) % p_db), one trial from host memory in convertDb's layout, or arbitrary words */

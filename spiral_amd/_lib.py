@@ -134,6 +134,11 @@ PROTOTYPES = {
     "spiral_gpu_pack": (C.c_int, [U64P, C.c_uint32, C.c_uint32, U64P, U64P]),
     "spiral_gpu_fast_multiply_query_by_database_dim1": (C.c_int, [U64P, U64P, U64P, C.c_size_t, C.c_size_t]),
     "spiral_gpu_pack_server_create": (C.c_int, [C.POINTER(Params), C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]),
+    "spiral_gpu_pack_server_create_sharded": (C.c_int, [C.POINTER(Params), C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "spiral_gpu_pack_server_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "spiral_gpu_pack_server_stage_us": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "spiral_gpu_pack_server_fold_trials": (C.c_int, [C.c_void_p, U64P, C.c_void_p]),
+    "spiral_gpu_pack_server_pack_gathered": (C.c_int, [C.c_void_p, C.c_void_p, U64P, U64P]),
     "spiral_gpu_pack_server_destroy": (None, [C.c_void_p]),
     "spiral_gpu_pack_server_gen_db": (C.c_int, [C.c_void_p, C.c_uint64]),
     "spiral_gpu_pack_server_load_db": (C.c_int, [C.c_void_p, C.c_uint32, U64P]),

@@ -9,10 +9,13 @@ struct spiral_gpu_pack_server {
     spiral_gpu_params p;
     spiral_gpu_pack_shape s;
     uint32_t out_n = 0;
+    uint32_t t0 = 0, nt = 0;  // this server's trials [t0, t0 + nt) of the out_n^2 (all of them unless created sharded)
     int device = 0;
     hipStream_t stream = nullptr;
+    bool own_stream = true;
     DeviceTables tb;
     bool have_db = false, have_pp = false;
+    bool packed_after_front = false;  // event 6 belongs to the same answer as events 0..5
     uint32_t n_cv = 0;
     size_t db_words = 0;  // per trial
     DevBuf db, w_left, w_right, v, v_w, query, cv, ex_raw, ex_g;
@@ -55,7 +58,7 @@ void pk_free(spiral_gpu_pack_server* S) {
     for (DevBuf* b : all) b->release();
     for (auto& e : S->ev)
         if (e) (void)hipEventDestroy(e);
-    if (S->stream) (void)hipStreamDestroy(S->stream);
+    if (S->stream && S->own_stream) (void)hipStreamDestroy(S->stream);
 }
 
 int pk_alloc(spiral_gpu_pack_server* S) {
@@ -63,7 +66,7 @@ int pk_alloc(spiral_gpu_pack_server* S) {
     const spiral_gpu_pack_shape& s = S->s;
     const size_t ngs = (size_t)p.nu2 * s.ell, rows = S->out_n + 1;
     S->db_words = db1_device_words(s.num_per, s.dim0);  // u64 words of one trial in the device layout
-    if (S->db.alloc(S->db_words * s.trials)) return -1;
+    if (S->db.alloc(S->db_words * S->nt)) return -1;
     if (S->w_left.alloc((size_t)s.n_left * 2 * p.t_exp * kN)) return -1;
     if (S->w_right.alloc((size_t)s.n_right * 2 * p.t_exp_right * kN)) return -1;
     if (S->v.alloc((size_t)2 * 2 * p.t_conv * kN)) return -1;
@@ -82,11 +85,11 @@ int pk_alloc(spiral_gpu_pack_server* S) {
     if (S->gsw.alloc((size_t)p.nu2 * 2 * 2 * s.ell * kN)) return -1;
     if (S->key.alloc((size_t)p.nu2 * 2 * 4 * s.ell * kN)) return -1;
     if (S->qs1.alloc((size_t)kN * s.dim0 * 2)) return -1;  // 4 u32 per (z, j)
-    if (S->acc.alloc((size_t)s.trials * s.num_per * 2 * kN)) return -1;
-    if (S->raw.alloc((size_t)s.trials * s.num_per * 2 * kN)) return -1;
+    if (S->acc.alloc((size_t)S->nt * s.num_per * 2 * kN)) return -1;
+    if (S->raw.alloc((size_t)S->nt * s.num_per * 2 * kN)) return -1;
     const size_t half = s.num_per / 2;
-    if (S->fold_d.alloc((size_t)s.trials * half * 4 * s.ell * kN)) return -1;
-    if (S->fold_c.alloc((size_t)s.trials * half * 2 * kN)) return -1;
+    if (S->fold_d.alloc((size_t)S->nt * half * 4 * s.ell * kN)) return -1;
+    if (S->fold_c.alloc((size_t)S->nt * half * 2 * kN)) return -1;
     if (S->pk_ginv.alloc((size_t)s.trials * p.t_conv * kN)) return -1;
     if (S->pk_ct2.alloc((size_t)s.trials * kN)) return -1;
     if (S->pk_res.alloc(rows * S->out_n * kN)) return -1;
@@ -177,14 +180,26 @@ int spiral_gpu_fast_multiply_query_by_database_dim1(uint64_t* out, const uint64_
 }
 
 int spiral_gpu_pack_server_create(const spiral_gpu_params* p, uint32_t out_n, int device, spiral_gpu_pack_server** out) {
+    return spiral_gpu_pack_server_create_sharded(p, out_n, device, 0, 0, out);
+}
+
+// The out_n^2 trials are independent up to the packing step (each has its own database image, sweep and folding), so N GPUs split
+// them: a server created for trials [trial0, trial1) holds only those images; fold_trials leaves their folded ciphertexts in a
+// caller-provided device buffer, one all-gather of out_n^2 x 2 polynomials collects them, pack_gathered finishes on the root.
+int spiral_gpu_pack_server_create_sharded(const spiral_gpu_params* p, uint32_t out_n, int device, uint32_t trial0, uint32_t trial1,
+                                          spiral_gpu_pack_server** out) {
     if (!p || !out) return fail("null argument");
     spiral_gpu_pack_shape s;
     if (pack_shape_of(p, out_n, &s)) return -1;
+    if (trial0 == 0 && trial1 == 0) trial1 = s.trials;
+    if (trial0 >= trial1 || trial1 > s.trials) return fail("bad trial range [%u, %u) of %u", trial0, trial1, s.trials);
     HIP_OK(hipSetDevice(device));
     auto* S = new spiral_gpu_pack_server();
     S->p = *p;
     S->s = s;
     S->out_n = out_n;
+    S->t0 = trial0;
+    S->nt = trial1 - trial0;
     S->device = device;
     if (tables_get(device, &S->tb) != 0) {
         delete S;
@@ -214,7 +229,7 @@ int spiral_gpu_pack_server_gen_db(spiral_gpu_pack_server* S, uint64_t seed) {
     if (!S) return fail("null server");
     HIP_OK(hipSetDevice(S->device));
     const uint64_t total = (uint64_t)S->s.dim0 * S->s.num_per, chunk = 1u << 18;
-    for (uint32_t t = 0; t < S->s.trials; t++) {
+    for (uint32_t t = 0; t < S->nt; t++) {
         FwdParams fp{};
         fp.dst = S->db.p + (size_t)t * S->db_words;
         fp.src_map = fp.dst_map = identity_map();
@@ -223,7 +238,7 @@ int spiral_gpu_pack_server_gen_db(spiral_gpu_pack_server* S, uint64_t seed) {
         fp.p_db = S->p.p_db;
         fp.num_per = S->s.num_per;
         fp.dim0_shard = S->s.dim0;
-        fp.trial = t;
+        fp.trial = S->t0 + t;
         fp.total_n = total;
         for (uint64_t done = 0; done < total; done += chunk) {
             fp.item_base = done;
@@ -238,14 +253,13 @@ int spiral_gpu_pack_server_gen_db(spiral_gpu_pack_server* S, uint64_t seed) {
 int spiral_gpu_pack_server_load_db(spiral_gpu_pack_server* S, uint32_t trial, const uint64_t* db) {
     if (!S || !db) return fail("null argument");
     HIP_OK(hipSetDevice(S->device));
-    if (trial >= S->s.trials) return fail("trial out of range");
-    HIP_OK(hipSetDevice(S->device));
+    if (trial < S->t0 || trial >= S->t0 + S->nt) return fail("trial %u is not one of this server's [%u, %u)", trial, S->t0, S->t0 + S->nt);
     DevBuf st;
     const size_t ref_words = (size_t)kN * S->s.dim0 * S->s.num_per;
     if (st.alloc(ref_words)) return -1;
     hipError_t e = hipMemcpy(st.p, db, ref_words * sizeof(uint64_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        launch_db1_relayout(st.p, S->db.p + (size_t)trial * S->db_words, S->s.num_per, S->s.dim0, S->stream);
+        launch_db1_relayout(st.p, S->db.p + (size_t)(trial - S->t0) * S->db_words, S->s.num_per, S->s.dim0, S->stream);
         e = hipStreamSynchronize(S->stream);
     }
     st.release();
@@ -259,11 +273,11 @@ int spiral_gpu_pack_server_load_db_items(spiral_gpu_pack_server* S, uint32_t tri
                                          uint64_t n_items) {
     if (!S) return fail("null server");
     HIP_OK(hipSetDevice(S->device));
-    if (trial >= S->s.trials) return fail("trial out of range");
+    if (trial < S->t0 || trial >= S->t0 + S->nt) return fail("trial %u is not one of this server's [%u, %u)", trial, S->t0, S->t0 + S->nt);
     const uint64_t total = (uint64_t)S->s.dim0 * S->s.num_per;
     if (first_item > total || n_items > total - first_item) return fail("items outside the database");
     FwdParams fp{};
-    fp.dst = S->db.p + (size_t)trial * S->db_words;
+    fp.dst = S->db.p + (size_t)(trial - S->t0) * S->db_words;
     fp.src_map = fp.dst_map = identity_map();
     fp.n_digits = 1;
     fp.p_db = S->p.p_db;
@@ -287,7 +301,7 @@ int spiral_gpu_pack_server_load_db_items(spiral_gpu_pack_server* S, uint32_t tri
 int spiral_gpu_pack_server_fill_db_random(spiral_gpu_pack_server* S, uint64_t seed) {
     if (!S) return fail("null server");
     HIP_OK(hipSetDevice(S->device));
-    for (uint32_t t = 0; t < S->s.trials; t++) launch_fill_db1_random(S->db.p + (size_t)t * S->db_words, S->s.num_per, S->s.dim0, seed + t, S->stream);
+    for (uint32_t t = 0; t < S->nt; t++) launch_fill_db1_random(S->db.p + (size_t)t * S->db_words, S->s.num_per, S->s.dim0, seed + S->t0 + t, S->stream);
     HIP_OK(hipStreamSynchronize(S->stream));
     S->have_db = true;
     return 0;
@@ -308,15 +322,13 @@ int spiral_gpu_pack_server_set_pub_params(spiral_gpu_pack_server* S, const uint6
     return 0;
 }
 
-int spiral_gpu_pack_server_answer(spiral_gpu_pack_server* S, const uint64_t* query, uint64_t* response, uint64_t* packed_ct, double stage_us[8]) {
-    if (!S || !query) return fail("null argument");
-    HIP_OK(hipSetDevice(S->device));
-    if (!S->have_db || !S->have_pp) return fail("database and public parameters must be set first");
-    HIP_OK(hipSetDevice(S->device));
+// everything up to and including the folding, for this server's trials: their folded ciphertexts end up at the head of each trial's
+// num_per slots of S->raw (events 0..5 bracket the stages)
+static int pk_front(spiral_gpu_pack_server* S, const uint64_t* query) {
     const spiral_gpu_params& p = S->p;
     const spiral_gpu_pack_shape& s = S->s;
     hipStream_t st = S->stream;
-    const uint32_t ell = s.ell, ngs = p.nu2 * ell, rows = S->out_n + 1;
+    const uint32_t ell = s.ell, ngs = p.nu2 * ell, nt = S->nt;
     if (pk_upload_ref_ntt(S, query, S->query.p, (size_t)s.n_query_cts * 2)) return -1;
 
     HIP_OK(hipEventRecord(S->ev[0], st));
@@ -356,7 +368,7 @@ int spiral_gpu_pack_server_answer(spiral_gpu_pack_server* S, const uint64_t* que
     launch_pack_fold_key(S->gsw.p, S->key.p, ell, p.nu2, st);
     HIP_OK(hipEventRecord(S->ev[2], st));
     // ---- first dimension for every trial (:1049-1051), then one INTT + CRT lift (:1055-1057)
-    launch_sweep1(S->db.p, (const uint32_t*)S->qs1.p, S->acc.p, s.num_per, s.dim0, s.trials, S->db_words, (size_t)s.num_per * 2 * kN, st);
+    launch_sweep1(S->db.p, (const uint32_t*)S->qs1.p, S->acc.p, s.num_per, s.dim0, nt, S->db_words, (size_t)s.num_per * 2 * kN, st);
     HIP_OK(hipEventRecord(S->ev[3], st));
     HIP_OK(hipEventRecord(S->ev[4], st));  // (the lift is chained into the first fold round's digit transforms)
     // ---- foldCiphertextsDim1 (:596-624), all trials batched: each round = fold_chain_kernel (lift of the previous
@@ -374,12 +386,12 @@ int spiral_gpu_pack_server_answer(spiral_gpu_pack_server* S, const uint64_t* que
         cp.fold_np = np;
         cp.pack = 1;
         cp.src_stride = src_stride;
-        const uint32_t n_src = s.trials * 2 * np * 2;
+        const uint32_t n_src = nt * 2 * np * 2;
         uint32_t dpb = ell;
         while (dpb > 1 && n_src * ((ell + dpb - 1) / dpb) < 768u) dpb = (dpb + 1) / 2;
         cp.dpb = dpb;
         launch_fold_chain(S->tb, cp, n_src, st);
-        launch_pack_fold_mac(S->key.p + (size_t)cur * 2 * 4 * ell * kN, S->fold_d.p, S->fold_c.p, 4 * ell, s.trials * np, st);
+        launch_pack_fold_mac(S->key.p + (size_t)cur * 2 * 4 * ell * kN, S->fold_d.p, S->fold_c.p, 4 * ell, nt * np, st);
         src = S->fold_c.p;
         src_stride = np;
     }
@@ -389,41 +401,104 @@ int spiral_gpu_pack_server_answer(spiral_gpu_pack_server* S, const uint64_t* que
         ip.dst = S->raw.p;
         ip.src_map = p.nu2 ? identity_map() : IndexMap{2 * s.num_per, 2 * s.num_per, 0};
         ip.dst_map = IndexMap{2 * np, 2 * s.num_per, 0};  // the trial's surviving np cts at the head of its num_per slots
-        launch_ntt_inverse(S->tb, ip, IST_CRT, s.trials * np * 2, st);
+        launch_ntt_inverse(S->tb, ip, IST_CRT, nt * np * 2, st);
     }
     HIP_OK(hipEventRecord(S->ev[5], st));
-    // ---- pack + modulus switch (:1064-1081)
-    run_pack(S->tb, S->raw.p, s.num_per, S->v_w.p, S->pk_ginv.p, S->pk_ct2.p, S->pk_res.p, S->out_n, p.t_conv, st);
-    {
-        InvParams ip{};
-        ip.src = S->pk_res.p;
-        ip.dst = S->pk_raw.p;
-        ip.src_map = ip.dst_map = identity_map();
-        launch_ntt_inverse(S->tb, ip, IST_CRT, rows * S->out_n, st);
-        launch_rescale(S->pk_raw.p, S->resp.p, S->out_n * kN, kQ, s.qprime, st);
-        launch_rescale(S->pk_raw.p + (size_t)S->out_n * kN, S->resp.p + (size_t)S->out_n * kN, S->out_n * S->out_n * kN, kQ, 4 * p.p_db, st);
-    }
+    S->packed_after_front = false;
+    return 0;
+}
+
+// pack + modulus switch (:1064-1081) of out_n^2 folded ciphertexts at a stride of `ct_stride` ciphertexts; event 6 closes it
+static int pk_back(spiral_gpu_pack_server* S, const uint64_t* folded, uint32_t ct_stride) {
+    const spiral_gpu_params& p = S->p;
+    hipStream_t st = S->stream;
+    const uint32_t rows = S->out_n + 1;
+    run_pack(S->tb, folded, ct_stride, S->v_w.p, S->pk_ginv.p, S->pk_ct2.p, S->pk_res.p, S->out_n, p.t_conv, st);
+    InvParams ip{};
+    ip.src = S->pk_res.p;
+    ip.dst = S->pk_raw.p;
+    ip.src_map = ip.dst_map = identity_map();
+    launch_ntt_inverse(S->tb, ip, IST_CRT, rows * S->out_n, st);
+    launch_rescale(S->pk_raw.p, S->resp.p, S->out_n * kN, kQ, S->s.qprime, st);
+    launch_rescale(S->pk_raw.p + (size_t)S->out_n * kN, S->resp.p + (size_t)S->out_n * kN, S->out_n * S->out_n * kN, kQ, 4 * p.p_db, st);
     HIP_OK(hipEventRecord(S->ev[6], st));
-    HIP_OK(hipStreamSynchronize(st));
+    S->packed_after_front = folded == S->raw.p;  // (a gathered buffer was filled by other servers too: no common time line)
+    return 0;
+}
+
+static int pk_download(spiral_gpu_pack_server* S, uint64_t* response, uint64_t* packed_ct) {
+    const uint32_t rows = S->out_n + 1;
+    HIP_OK(hipStreamSynchronize(S->stream));
     HIP_OK(hipGetLastError());
     if (response) HIP_OK(hipMemcpy(response, S->resp.p, (size_t)rows * S->out_n * kPolyBytes, hipMemcpyDeviceToHost));
     if (packed_ct) {
         Scratch sc;
         if (download_pk(sc, S->pk_res.p, identity_map(), packed_ct, (size_t)rows * S->out_n)) return -1;
     }
-    if (stage_us) {
-        float ms[6], total = 0;
-        for (int i = 0; i < 6; i++) HIP_OK(hipEventElapsedTime(&ms[i], S->ev[i], S->ev[i + 1]));
-        HIP_OK(hipEventElapsedTime(&total, S->ev[0], S->ev[6]));
-        stage_us[0] = ms[0] * 1e3;
-        stage_us[1] = ms[1] * 1e3;
-        stage_us[2] = (ms[2] + ms[3]) * 1e3;
-        stage_us[3] = ms[4] * 1e3;
-        stage_us[4] = ms[5] * 1e3;
-        stage_us[5] = ms[2] * 1e3;
-        stage_us[6] = total * 1e3;
-        stage_us[7] = 0;
+    return 0;
+}
+
+int spiral_gpu_pack_server_answer(spiral_gpu_pack_server* S, const uint64_t* query, uint64_t* response, uint64_t* packed_ct, double stage_us[8]) {
+    if (!S || !query) return fail("null argument");
+    HIP_OK(hipSetDevice(S->device));
+    if (!S->have_db || !S->have_pp) return fail("database and public parameters must be set first");
+    if (S->nt != S->s.trials) return fail("this server holds trials [%u, %u) only: fold_trials + pack_gathered", S->t0, S->t0 + S->nt);
+    if (pk_front(S, query) || pk_back(S, S->raw.p, S->s.num_per) || pk_download(S, response, packed_ct)) return -1;
+    return stage_us ? spiral_gpu_pack_server_stage_us(S, stage_us) : 0;
+}
+
+// stage times of the last answer (or fold_trials [+ pack_gathered]) from the events between its stages; synchronises the stream.
+// [4] packing and [6] total are 0 when no packing followed the last fold_trials on this server.
+int spiral_gpu_pack_server_stage_us(spiral_gpu_pack_server* S, double stage_us[8]) {
+    if (!S || !stage_us) return fail("null argument");
+    HIP_OK(hipSetDevice(S->device));
+    HIP_OK(hipStreamSynchronize(S->stream));
+    float ms[6] = {}, total = 0;
+    for (int i = 0; i < (S->packed_after_front ? 6 : 5); i++) HIP_OK(hipEventElapsedTime(&ms[i], S->ev[i], S->ev[i + 1]));
+    if (S->packed_after_front) HIP_OK(hipEventElapsedTime(&total, S->ev[0], S->ev[6]));
+    stage_us[0] = ms[0] * 1e3;
+    stage_us[1] = ms[1] * 1e3;
+    stage_us[2] = (ms[2] + ms[3]) * 1e3;
+    stage_us[3] = ms[4] * 1e3;
+    stage_us[4] = ms[5] * 1e3;
+    stage_us[5] = ms[2] * 1e3;
+    stage_us[6] = total * 1e3;
+    stage_us[7] = 0;
+    return 0;
+}
+
+// trial-sharded answer, part 1: expansion and conversion (replicated: they are database-independent), then the sweeps and the folding
+// of this server's trials; their folded ciphertexts ([nt][2][N] raw words) are left at `folded_dev`, a device buffer of the caller
+// (the send buffer of the all-gather).  Asynchronous on the server's stream.
+int spiral_gpu_pack_server_fold_trials(spiral_gpu_pack_server* S, const uint64_t* query, void* folded_dev) {
+    if (!S || !query || !folded_dev) return fail("null argument");
+    HIP_OK(hipSetDevice(S->device));
+    if (!S->have_db || !S->have_pp) return fail("database and public parameters must be set first");
+    if (pk_front(S, query)) return -1;
+    HIP_OK(hipMemcpy2DAsync(folded_dev, 2 * kPolyBytes, S->raw.p, (size_t)S->s.num_per * 2 * kPolyBytes, 2 * kPolyBytes, S->nt, hipMemcpyDeviceToDevice,
+                            S->stream));
+    return 0;
+}
+
+// part 2, on the root: pack + modulus switch of all out_n^2 folded ciphertexts (`gathered_dev`: [out_n^2][2][N] raw words in trial
+// order, device memory -- the receive buffer of the all-gather)
+int spiral_gpu_pack_server_pack_gathered(spiral_gpu_pack_server* S, const void* gathered_dev, uint64_t* response, uint64_t* packed_ct) {
+    if (!S || !gathered_dev) return fail("null argument");
+    HIP_OK(hipSetDevice(S->device));
+    if (!S->have_pp) return fail("public parameters must be set first");
+    if (pk_back(S, (const uint64_t*)gathered_dev, 1)) return -1;
+    return pk_download(S, response, packed_ct);
+}
+
+int spiral_gpu_pack_server_set_stream(spiral_gpu_pack_server* S, void* stream) {
+    if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
+    HIP_OK(hipStreamSynchronize(S->stream));
+    if (S->own_stream) {
+        (void)hipStreamDestroy(S->stream);
+        S->own_stream = false;
     }
+    S->stream = (hipStream_t)stream;
     return 0;
 }
 
@@ -442,10 +517,10 @@ int spiral_gpu_pack_server_read_response_wire(spiral_gpu_pack_server* S, void* o
 int spiral_gpu_pack_server_read_acc(spiral_gpu_pack_server* S, uint32_t trial, uint64_t* out) {
     if (!S || !out) return fail("null argument");
     HIP_OK(hipSetDevice(S->device));
-    if (trial >= S->s.trials) return fail("trial out of range");
+    if (trial < S->t0 || trial >= S->t0 + S->nt) return fail("trial %u is not one of this server's [%u, %u)", trial, S->t0, S->t0 + S->nt);
     HIP_OK(hipStreamSynchronize(S->stream));
     Scratch sc;
-    return download_pk(sc, S->acc.p + (size_t)trial * S->s.num_per * 2 * kN, identity_map(), out, (size_t)S->s.num_per * 2);
+    return download_pk(sc, S->acc.p + (size_t)(trial - S->t0) * S->s.num_per * 2 * kN, identity_map(), out, (size_t)S->s.num_per * 2);
 }
 
 uint64_t spiral_gpu_pack_server_sweep_bytes(spiral_gpu_pack_server* S) {

@@ -41,12 +41,36 @@ def fastMultiplyQueryByDatabaseDim1(db, v_firstdim, dim0, num_per) -> np.ndarray
 
 
 class PackServer:
-    def __init__(self, params: Params, out_n: int, device: int = 0):
+    def __init__(self, params: Params, out_n: int, device: int = 0, trial0: int = 0, trial1: int = 0):
+        """trial0, trial1: this server's share [trial0, trial1) of the out_n^2 trials (N GPUs); 0, 0 = all of them"""
         self.params, self.out_n = params, out_n
         self.shape = get_pack_shape(params, out_n)
         h = C.c_void_p()
-        check(lib().spiral_gpu_pack_server_create(C.byref(params), out_n, device, C.byref(h)))
+        check(lib().spiral_gpu_pack_server_create_sharded(C.byref(params), out_n, device, trial0, trial1, C.byref(h)))
         self.h = h
+        self.trial0, self.trial1 = (trial0, trial1) if trial1 else (0, self.shape.trials)
+
+    def set_stream(self, hip_stream: int):
+        check(lib().spiral_gpu_pack_server_set_stream(self.h, C.c_void_p(hip_stream)))
+
+    def fold_trials(self, query, folded_ptr: int):
+        """expansion + conversion + this server's sweeps and folding; the folded ciphertexts ([n_local][2][N] raw u64) are written to
+        the device buffer at folded_ptr (asynchronous on the server's stream)"""
+        check(lib().spiral_gpu_pack_server_fold_trials(self.h, _p(_c(query)), C.c_void_p(folded_ptr)))
+
+    def stage_us(self) -> dict:
+        """stage times of the last answer / fold_trials (synchronises the stream)"""
+        us = (C.c_double * 8)()
+        check(lib().spiral_gpu_pack_server_stage_us(self.h, us))
+        return dict(zip(PACK_STAGE_NAMES, list(us)))
+
+    def pack_gathered(self, gathered_ptr: int, want_packed: bool = False):
+        """pack + modulus switch of all out_n^2 folded ciphertexts (device buffer in trial order): (response, packed or None)"""
+        n = self.out_n
+        resp = np.zeros((n + 1, n, N), dtype=np.uint64)
+        packed = np.zeros((n + 1, n, 2, N), dtype=np.uint64) if want_packed else None
+        check(lib().spiral_gpu_pack_server_pack_gathered(self.h, C.c_void_p(gathered_ptr), _p(resp), _p(packed) if want_packed else None))
+        return resp, packed
 
     def close(self):
         if getattr(self, "h", None):

@@ -153,3 +153,23 @@ def test_bench_rccl_world_size_one(extra):
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["roofline"]["achieved"] > 0
     assert ("1 reduce" in out["config"]["parallelism"]) == bool(extra)
+
+
+def test_bench_pack_trial_shards():
+    """bench.py --workload pack on two ranks sharing the one device (gloo standing in for RCCL): each rank sweeps and folds 8 of the
+    16 trials, the folded ciphertexts are all-gathered, rank 0 packs; and the same flow through RCCL with a world of one rank"""
+    import json
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(ROOT, "bench.py"), "--workload", "pack", "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--shared-device"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and "trials x2 (8 per rank)" in out["config"]["parallelism"] and out["roofline"]["achieved"] > 0
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "pack", "--gpus", "1", "--steps", "3", "--warmup", "1", "--force-dist", "--backend", "nccl"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and "trials x1 (16 per rank)" in out["config"]["parallelism"] and out["roofline"]["frac"] > 0.5

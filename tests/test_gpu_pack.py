@@ -125,6 +125,49 @@ def test_pack_response_wire_form(sa, oracle, nu1, nu2, out_n, kw):
     srv.close()
 
 
+@pytest.mark.parametrize("nu1,nu2,out_n,kw,cuts", [(4, 2, 2, dict(t_gsw=4), (0, 1, 3, 4)), (3, 3, 3, dict(t_gsw=3, t_conv=56, t_exp=56, qprime_bits=27, p_db=4096, direct_upload=1), (0, 5, 9)),
+                                                   (4, 1, 4, dict(t_gsw=4), (0, 2, 4, 6, 8, 10, 12, 14, 16))])
+def test_trial_sharded_servers_equal_one_server(sa, oracle, nu1, nu2, out_n, kw, cuts):
+    """N GPUs split the out_n^2 trials (emulated on one device): every shard folds its own trials into its slice of the buffer an
+    all-gather would fill, the root packs the gathered ciphertexts -- packed ciphertext and response == the oracle's whole answer"""
+    import torch
+
+    O = oracle
+    po, pg = O.make_params(nu1, nu2, **kw), sa.make_params(nu1, nu2, **kw)
+    s = O.pack_shape_of(po, out_n)
+    db = O.pack_gen_db(po, out_n, 13)
+    cl = O.PackClient(po, out_n, seed=2)
+    pp = cl.pub_params()
+    shards = [sa.PackServer(pg, out_n, 0, a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+    for k, sh in enumerate(shards):
+        if k % 2 == 0:
+            sh.gen_db(13)  # generated on the device with the global trial index
+        else:
+            for t in range(sh.trial0, sh.trial1):
+                sh.load_db(t, db[t])
+            with pytest.raises(RuntimeError):
+                sh.load_db(sh.trial1 % s.trials if sh.trial1 % s.trials not in range(sh.trial0, sh.trial1) else (sh.trial0 - 1) % s.trials, db[0])
+        sh.set_pub_params(*pp)
+    if len(shards) > 1:
+        with pytest.raises(RuntimeError):
+            shards[0].answer(cl.query(0))
+    gathered = torch.zeros(s.trials * 2 * N, dtype=torch.int64, device="cuda")
+    total = s.dim0 * s.num_per
+    for idx in (0, total - 1, total // 2 + 1):
+        q = cl.query(idx)
+        for sh in shards:
+            sh.fold_trials(q, gathered.data_ptr() + sh.trial0 * 2 * N * 8)
+        torch.cuda.synchronize()
+        resp, packed = shards[0].pack_gathered(gathered.data_ptr(), want_packed=True)
+        exp_resp, exp_packed = O.pack_answer(po, out_n, q, *pp, db)
+        assert_eq(packed, exp_packed, f"packed ciphertext idx={idx}")
+        assert_eq(resp, exp_resp, "response")
+        if "p_db" not in kw:
+            assert_eq(cl.decode(resp), O.pack_db_item(po, out_n, 13, idx), "decoded items")
+    for sh in shards:
+        sh.close()
+
+
 def _random_pack_sets(count, seed):
     rng = np.random.default_rng(seed)
     out = []
