@@ -454,17 +454,31 @@ void launch_expand_mac_round(const ExpandMacParams& p, hipStream_t s) {
 // out = prod + pad(cv row 1) at (1,0) and (2,1)
 __device__ __forceinline__ void scal2mat_slot(const uint64_t* w, const uint64_t* g, uint32_t t_conv, uint64_t cv1, uint32_t z, uint64_t out[3][2]) {
     Acc2 acc[3][2];
-    for (uint32_t k = 0; k < t_conv; k++) {
-#ifndef S2M_PLAIN_LOADS  // digits are read once
-        uint64_t gv = __builtin_nontemporal_load(&g[(size_t)k * kN]);
-#else
-        uint64_t gv = g[(size_t)k * kN];
-#endif
+    // the digits stream from HBM once (t_conv polynomials per ciphertext, 1.9 GB at the SpiralStream sets' t_conv = 56): eight of them
+    // are requested before the first is used -- with one 8-byte load in flight per thread the product ran at 1.8 TB/s
+    constexpr uint32_t kAhead = 8;
+    for (uint32_t k0 = 0; k0 < t_conv; k0 += kAhead) {
+        uint64_t gv[kAhead];
 #pragma unroll
-        for (uint32_t r = 0; r < 3; r++) {
-            const uint64_t* wr = w + ((size_t)r * 2 * t_conv + 2 * k) * kN + z;
-            acc[r][0].mac(wr[0], gv);
-            acc[r][1].mac(wr[kN], gv);
+        for (uint32_t u = 0; u < kAhead; u++) {
+            const uint32_t k = min(k0 + u, t_conv - 1);
+#ifndef S2M_PLAIN_LOADS  // digits are read once
+            gv[u] = __builtin_nontemporal_load(&g[(size_t)k * kN]);
+#else
+            gv[u] = g[(size_t)k * kN];
+#endif
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kAhead; u++) {
+            const uint32_t k = k0 + u;
+            if (k < t_conv) {
+#pragma unroll
+                for (uint32_t r = 0; r < 3; r++) {
+                    const uint64_t* wr = w + ((size_t)r * 2 * t_conv + 2 * k) * kN + z;
+                    acc[r][0].mac(wr[0], gv[u]);
+                    acc[r][1].mac(wr[kN], gv[u]);
+                }
+            }
         }
     }
 #pragma unroll
@@ -526,11 +540,77 @@ __device__ __forceinline__ void scal2mat_rec_body(const Scal2MatParams& p, uint3
 #endif
     }
 }
+// Large t_conv (the SpiralStream sets: 56 digit polynomials per ciphertext, 1.9 GB of digits): 64 slots x 16 ciphertexts per
+// workgroup, a thread takes one slot of FOUR ciphertexts, so a W word is fetched once per four digit words (the 16 x 16 tile above
+// fetches six per digit word and ran at 1.8 TB/s of digits, bound by the L1/L2 request rate) and a wave reads 512 contiguous bytes.
+__device__ __forceinline__ void scal2mat_rec4_body(const Scal2MatParams& p, uint32_t bx, uint32_t by) {
+    __shared__ uint4 sh[64][16][3];  // [slot][ct][piece]
+    const uint32_t zl = threadIdx.x & 63u, cg = threadIdx.x >> 6, z = bx * 64u + zl, a0 = by * 16u, tc = p.t_conv;
+    Acc2 acc[4][3][2];
+    const uint64_t* g = p.g + (size_t)(a0 + cg * 4u) * tc * kN + z;
+    const uint64_t* w = p.w + z;
+#pragma unroll 2
+    for (uint32_t k = 0; k < tc; k++) {
+        uint64_t gv[4], wv[3][2];
+#pragma unroll
+        for (uint32_t c = 0; c < 4; c++) gv[c] = __builtin_nontemporal_load(&g[((size_t)c * tc + k) * kN]);
+#pragma unroll
+        for (uint32_t r = 0; r < 3; r++) {
+            wv[r][0] = w[((size_t)r * 2 * tc + 2 * k) * kN];
+            wv[r][1] = w[((size_t)r * 2 * tc + 2 * k + 1) * kN];
+        }
+#pragma unroll
+        for (uint32_t c = 0; c < 4; c++)
+#pragma unroll
+            for (uint32_t r = 0; r < 3; r++) {
+                acc[c][r][0].mac(wv[r][0], gv[c]);
+                acc[c][r][1].mac(wv[r][1], gv[c]);
+            }
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < 4; c++) {
+        const uint32_t al = cg * 4u + c;
+        const uint64_t cv1 = p.cv[((size_t)p.cv_pos(a0 + al) * 2 + 1) * kN + z];
+        uint64_t out[3][2];
+#pragma unroll
+        for (uint32_t r = 0; r < 3; r++)
+#pragma unroll
+            for (uint32_t cc = 0; cc < 2; cc++) {
+                uint64_t v = acc[c][r][cc].reduced();
+                if ((r == 1 && cc == 0) || (r == 2 && cc == 1)) v = add_pk(v, cv1);
+                out[r][cc] = v;
+            }
+        sh[zl][al][0] = make_uint4(lo32(out[0][0]), lo32(out[1][0]), lo32(out[2][0]), hi32(out[0][0]));
+        sh[zl][al][1] = make_uint4(hi32(out[1][0]), hi32(out[2][0]), lo32(out[0][1]), lo32(out[1][1]));
+        sh[zl][al][2] = make_uint4(lo32(out[2][1]), hi32(out[0][1]), hi32(out[1][1]), hi32(out[2][1]));
+    }
+    __syncthreads();
+    const uint4* flat = &sh[0][0][0];
+#pragma unroll
+    for (uint32_t m = 0; m < 12; m++) {
+        const uint32_t q = threadIdx.x + 256u * m, zz = q / 48u, within = q - zz * 48u;  // 48 pieces per slot
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        u32x4* rec = reinterpret_cast<u32x4*>(p.qs + ((size_t)(bx * 64u + zz) * (p.jm_total / 2) + p.j_base + a0) * 12);
+        const uint4 v = flat[q];
+        __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, rec + within);
+    }
+}
+static uint32_t scal2mat_wide_min() {
+    static const uint32_t v = [] {
+        const char* e = getenv("SPIRAL_S2M_WIDE_MIN");  // tuning only: smallest t_conv that takes the 64 x 16 tile
+        return e ? (uint32_t)strtoul(e, nullptr, 10) : 16u;
+    }();
+    return v;
+}
+__global__ __launch_bounds__(kTpb) void scal2mat_rec4_kernel(Scal2MatParams p) { scal2mat_rec4_body(p, blockIdx.x, blockIdx.y); }
 __global__ __launch_bounds__(kTpb) void scal2mat_rec_kernel(Scal2MatParams p) { scal2mat_rec_body(p, blockIdx.x, blockIdx.y); }
 static bool scal2mat_rec_ok(const Scal2MatParams& p) { return p.count && p.count % 16 == 0 && p.qs && !p.out; }
 void launch_scal2mat(const Scal2MatParams& p, hipStream_t s) {
     if (scal2mat_rec_ok(p)) {
-        hipLaunchKernelGGL(scal2mat_rec_kernel, dim3(kN / 16, p.count / 16), dim3(kTpb), 0, s, p);
+        if (p.t_conv >= scal2mat_wide_min())
+            hipLaunchKernelGGL(scal2mat_rec4_kernel, dim3(kN / 64, p.count / 16), dim3(kTpb), 0, s, p);
+        else
+            hipLaunchKernelGGL(scal2mat_rec_kernel, dim3(kN / 16, p.count / 16), dim3(kTpb), 0, s, p);
         return;
     }
     if (p.count) hipLaunchKernelGGL(scal2mat_kernel, dim3(kBpp, p.count), dim3(kTpb), 0, s, p);
@@ -574,10 +654,14 @@ __device__ __forceinline__ void regev_to_gsw_body(const GswParams& p, uint32_t b
 }
 __global__ __launch_bounds__(kTpb) void regev_to_gsw_kernel(GswParams p) { regev_to_gsw_body(p, blockIdx.x, blockIdx.y); }
 // the two conversion products are independent: one launch, the first n1 blocks ScalToMat, the rest Regev->GSW
+template <bool WIDE>
 __global__ __launch_bounds__(kTpb) void convert_products_kernel(Scal2MatParams sp, GswParams gp, uint32_t n1) {
     const uint32_t b = blockIdx.x;
     if (b < n1) {
-        scal2mat_rec_body(sp, b % (kN / 16u), b / (kN / 16u));
+        if constexpr (WIDE)
+            scal2mat_rec4_body(sp, b % (kN / 64u), b / (kN / 64u));
+        else
+            scal2mat_rec_body(sp, b % (kN / 16u), b / (kN / 16u));
     } else {
         const uint32_t bb = b - n1;
         regev_to_gsw_body(gp, bb % kBpp, bb / kBpp);
@@ -585,8 +669,12 @@ __global__ __launch_bounds__(kTpb) void convert_products_kernel(Scal2MatParams s
 }
 void launch_convert_products(const Scal2MatParams& sp, const GswParams& gp, hipStream_t s) {
     if (scal2mat_rec_ok(sp) && gp.dims) {
-        const uint32_t n1 = (kN / 16u) * (sp.count / 16u), n2 = kBpp * gp.dims * gp.ell;
-        hipLaunchKernelGGL(convert_products_kernel, dim3(n1 + n2), dim3(kTpb), 0, s, sp, gp, n1);
+        const bool wide = sp.t_conv >= scal2mat_wide_min();
+        const uint32_t n1 = (kN / (wide ? 64u : 16u)) * (sp.count / 16u), n2 = kBpp * gp.dims * gp.ell;
+        if (wide)
+            hipLaunchKernelGGL(convert_products_kernel<true>, dim3(n1 + n2), dim3(kTpb), 0, s, sp, gp, n1);
+        else
+            hipLaunchKernelGGL(convert_products_kernel<false>, dim3(n1 + n2), dim3(kTpb), 0, s, sp, gp, n1);
     } else {
         launch_scal2mat(sp, s);
         launch_regev_to_gsw(gp, s);
