@@ -78,6 +78,9 @@ int spiral_gpu_from_ntt(uint64_t *out, const uint64_t *in, size_t npolys);
 /* measurement helper: average duration (ms) of one batched to_ntt and one batched from_ntt launch over npolys polynomials
  * resident in HBM (HIP events, default stream): the transform kernels' cost per limb-pair transform */
 int spiral_gpu_time_ntt(size_t npolys, int iters, float *fwd_ms, float *inv_ms);
+/* the same for the digit-transform launch the stages are built from: n_digits gadget digits of each of npolys raw polynomials
+ * (gadget_invert + to_ntt_no_reduce), npolys * n_digits transforms per launch; ms per launch */
+int spiral_gpu_time_ntt_digits(size_t npolys, uint32_t n_digits, int iters, float *ms);
 /* multiply, src/poly.cpp:34 : out(rs x cs) = a(rs x ms) * b(ms x cs), NTT form */
 int spiral_gpu_multiply(uint64_t *out, const uint64_t *a, const uint64_t *b, size_t rs, size_t ms, size_t cs);
 /* add, mul_by_const, src/poly.cpp:138,190 */

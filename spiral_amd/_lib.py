@@ -66,6 +66,7 @@ PROTOTYPES = {
     "spiral_gpu_to_ntt": (C.c_int, [U64P, U64P, C.c_size_t, C.c_int]),
     "spiral_gpu_from_ntt": (C.c_int, [U64P, U64P, C.c_size_t]),
     "spiral_gpu_time_ntt": (C.c_int, [C.c_size_t, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "spiral_gpu_time_ntt_digits": (C.c_int, [C.c_size_t, C.c_uint32, C.c_int, C.POINTER(C.c_float)]),
     "spiral_gpu_multiply": (C.c_int, [U64P, U64P, U64P, C.c_size_t, C.c_size_t, C.c_size_t]),
     "spiral_gpu_add": (C.c_int, [U64P, U64P, U64P, C.c_size_t]),
     "spiral_gpu_mul_by_const": (C.c_int, [U64P, U64P, U64P, C.c_size_t]),

@@ -321,6 +321,37 @@ int spiral_gpu_time_ntt(size_t npolys, int iters, float* fwd_ms, float* inv_ms) 
     return 0;
 }
 
+// the gadget-digit transform launch the conversion / expansion / folding stages are made of: n_digits unsigned digits of each of
+// npolys raw polynomials (gadget_invert + to_ntt_no_reduce), one workgroup per digit polynomial -- the source polynomial is read
+// n_digits times (cache hits after the first), every transform writes its 16 KiB
+int spiral_gpu_time_ntt_digits(size_t npolys, uint32_t n_digits, int iters, float* ms) {
+    if (!ms || iters <= 0 || npolys == 0 || n_digits < 1 || n_digits > 56) return fail("bad argument");
+    DeviceTables tb;
+    if (current_tables(&tb)) return -1;
+    Scratch sc;
+    uint64_t* d_raw = sc.get(npolys * kN);
+    uint64_t* d_pk = sc.get(npolys * n_digits * kN);
+    if (!d_raw || !d_pk) return fail("device allocation failed");
+    HIP_OK(hipMemset(d_raw, 0x5a, npolys * kN * sizeof(uint64_t)));
+    hipEvent_t e[2];
+    for (auto& x : e) HIP_OK(hipEventCreate(&x));
+    FwdParams fp{};
+    fp.src = d_raw;
+    fp.dst = d_pk;
+    fp.src_map = fp.dst_map = identity_map();
+    fp.n_digits = n_digits;
+    fp.bits = get_bits_per(n_digits);
+    launch_ntt_forward(tb, fp, LD_DIGIT, ST_PK, (uint32_t)(npolys * n_digits), 0);  // warm
+    HIP_OK(hipEventRecord(e[0], 0));
+    for (int i = 0; i < iters; i++) launch_ntt_forward(tb, fp, LD_DIGIT, ST_PK, (uint32_t)(npolys * n_digits), 0);
+    HIP_OK(hipEventRecord(e[1], 0));
+    HIP_OK(hipEventSynchronize(e[1]));
+    HIP_OK(hipEventElapsedTime(ms, e[0], e[1]));
+    *ms /= iters;
+    for (auto& x : e) (void)hipEventDestroy(x);
+    return 0;
+}
+
 int spiral_gpu_multiply(uint64_t* out, const uint64_t* a, const uint64_t* b, size_t rs, size_t ms, size_t cs) {
     Scratch sc;
     uint64_t* da = upload_pk(sc, a, rs * ms);

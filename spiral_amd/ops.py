@@ -16,7 +16,7 @@ Q = P * B
 __all__ = [
     "N", "P", "B", "Q", "make_params", "get_shape", "get_tables", "ntt_forward", "ntt_inverse", "to_ntt", "to_ntt_no_reduce", "from_ntt",
     "multiply", "add", "mul_by_const", "automorph", "invert", "gadget_invert", "getRescaled", "multiplyQueryByDatabase", "split_and_crt",
-    "foldOneFurtherDimension", "expandImproved", "scalToMat", "regevToGSW", "time_ntt", "response_wire_bytes", "response_from_wire",
+    "foldOneFurtherDimension", "expandImproved", "scalToMat", "regevToGSW", "time_ntt", "time_ntt_digits", "response_wire_bytes", "response_from_wire",
 ]
 
 
@@ -189,3 +189,10 @@ def time_ntt(npolys: int, iters: int = 10):
     f, i = C.c_float(), C.c_float()
     check(lib().spiral_gpu_time_ntt(npolys, iters, C.byref(f), C.byref(i)))
     return f.value, i.value
+
+
+def time_ntt_digits(npolys: int, n_digits: int, iters: int = 10) -> float:
+    """ms per launch of npolys * n_digits gadget-digit transforms (the launch the conversion / expansion stages are made of)"""
+    ms = C.c_float()
+    check(lib().spiral_gpu_time_ntt_digits(npolys, n_digits, iters, C.byref(ms)))
+    return ms.value
