@@ -237,7 +237,7 @@ def main():
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     ap.add_argument("--overlap", type=int, default=0, help="1: Regev->GSW conversion on a side stream under the sweep (measured slower: the sweep loses "
                     "more to the contention, 349 -> 422 us, than the 30 us of conversion it hides); 0: everything in order on one stream")
-    ap.add_argument("--event-every", type=int, default=4, help="bracket the stages with HIP events on every n-th timed step only (1 = every step)")
+    ap.add_argument("--event-every", type=int, default=5, help="bracket the stages with HIP events on every n-th timed step only (1 = every step)")
     ap.add_argument("--root-fold", action="store_true", help="N > 1: plain reduce to rank 0, which lifts and folds alone")
     ap.add_argument("--lanes", type=int, default=3, help="N = 1: queries in flight in the extra throughput leg (`pipelined` in the JSON line; 1 = skip it)")
     ap.add_argument("--comm-overlap", action="store_true", help="N > 1 with the sharded expansion: overlap the all-gather of the GSW bits with ScalToMat + sweep and the "
