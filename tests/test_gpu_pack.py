@@ -183,7 +183,10 @@ def _random_pack_sets(count, seed):
     return out
 
 
-@pytest.mark.parametrize("nu1,nu2,out_n,kw", _random_pack_sets(12, 7), ids=[f"set{i}" for i in range(12)])
+_N_FUZZ = int(__import__("os").environ.get("SPIRAL_FUZZ_SETS", "12"))  # a soak run sets it to hundreds
+
+
+@pytest.mark.parametrize("nu1,nu2,out_n,kw", _random_pack_sets(_N_FUZZ, 7), ids=[f"set{i}" for i in range(_N_FUZZ)])
 def test_random_pack_sets_bit_exact(sa, oracle, nu1, nu2, out_n, kw):
     """a seeded draw of SpiralPack / SpiralStreamPack parameter sets (odd gadget dimensions and output sizes, every q' width):
     packed ciphertext and switched response == the oracle's, word for word"""

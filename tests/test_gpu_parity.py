@@ -410,7 +410,10 @@ def _random_parameter_sets(count, seed):
     return out
 
 
-@pytest.mark.parametrize("nu1,nu2,kw", _random_parameter_sets(16, 2024), ids=[f"set{i}" for i in range(16)])
+_N_FUZZ = int(__import__("os").environ.get("SPIRAL_FUZZ_SETS", "16"))  # a soak run sets it to hundreds
+
+
+@pytest.mark.parametrize("nu1,nu2,kw", _random_parameter_sets(_N_FUZZ, 2024), ids=[f"set{i}" for i in range(_N_FUZZ)])
 def test_random_parameter_sets_bit_exact(sa, oracle, nu1, nu2, kw):
     """a seeded draw of parameter sets: the folded ciphertext of the eager stages and of the whole-query graph == the oracle's, word for
     word (whether such a set decodes is the noise model's business, not the server's)"""
