@@ -805,6 +805,7 @@ int spiral_gpu_server_share_db(spiral_gpu_server* S, spiral_gpu_server* owner) {
     if (!owner->have_db) return fail("the owner has no database loaded");
     HIP_OK(hipSetDevice(S->device));
     HIP_OK(hipStreamSynchronize(S->stream));
+    srv_drop_graphs(S);  // captured sweeps hold the old image's address
     if (!S->db_shared) S->db.release();
     S->db.p = owner->db.p;
     S->db.words = owner->db.words;

@@ -457,6 +457,14 @@ def test_two_query_lanes_share_one_database(sa, oracle):
     db = O.gen_db(po, 31)
     owner, lane = sa.Server(pg), sa.Server(pg)
     owner.gen_db(31)
+    # the lane first answers from an image of its own through captured graphs: share_db must not leave them pointing at it
+    warm = O.Client(po, seed=9)
+    lane.gen_db(99)
+    lane.set_pub_params(*warm.pub_params())
+    lane.use_graphs(True)
+    lane.set_query(warm.query(1))
+    lane.run_query()
+    lane.sync()
     lane.share_db(owner)
     with pytest.raises(RuntimeError):
         lane.gen_db(5)
