@@ -86,3 +86,23 @@ def test_product_never_imports_the_oracle():
                     if re.search(r"liboracle|pyoracle|spiral_oracle|orc_", txt):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_wire_form_host_functions_reject_bad_arguments():
+    """the host halves of the response wire form need no device: sizes for valid parameters, 0 / an error for invalid ones"""
+    import ctypes as C
+
+    import numpy as np
+
+    import spiral_amd as sa
+
+    p = sa.make_params(8, 7)
+    assert sa.response_wire_bytes(p) == 20480 and sa.response_wire_bytes(p, 4) == (4 * 2048 * 20 + 16 * 2048 * 10) // 8
+    assert sa.response_wire_bytes(p, 0) == 0 and sa.response_wire_bytes(p, 17) == 0
+    bad = sa.make_params(8, 7, qprime_bits=37)
+    assert sa.response_wire_bytes(bad) == 0
+    with pytest.raises(RuntimeError):
+        sa.response_from_wire(bad, np.zeros(20480 + 8, dtype=np.uint8))
+    out = np.zeros((3, 2, 2048), dtype=np.uint64)
+    assert sa.lib().spiral_gpu_response_from_wire(C.byref(p), 2, None, out.ctypes.data_as(C.POINTER(C.c_uint64))) != 0
+    assert b"null" in sa.lib().spiral_gpu_last_error()
