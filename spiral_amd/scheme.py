@@ -584,6 +584,7 @@ def main(argv=None):
     ap.add_argument("--variant", default="spiral", choices=["spiral", "spiralstream", "spiral-pack", "spiralstream-pack"],
                     help="--select: query compression (spiral) or direct upload (spiralstream), each with or without response packing")
     ap.add_argument("--run", action="store_true", help="--select: also run the chosen set through ./spiral and report the measured times")
+    ap.add_argument("--analyze-deviation", action="store_true", help="--select --run: predicted against measured stage times (select_params.py --analyze-deviation)")
     ap.add_argument("--top", type=int, default=5, help="--select: how many of the cheapest sets to list")
     ap.add_argument("--optimize-for", default="cost", choices=["cost", "tput", "rate"], help="--select: USD per query (default), server time, or response size")
     ap.add_argument("--one-gpu", action="store_true", help="--select: only sets whose database image(s) fit one MI355X (256 GiB of its 288 GB)")
@@ -626,7 +627,22 @@ def main(argv=None):
             best = {k: v for k, v in ranked[0][4].items() if k != "s_e"}
             runs = [run_once(best, ranked[0][3], not a.random_data, a.seed) for _ in range(max(1, a.trials))]
             out["measured"] = summarize(runs, best, item_size, ranked[0][3])
+            if a.analyze_deviation:  # select_params.py:589-616: the model's stage times against the measured ones
+                fac, pred, meas = ranked[0][3], predict_times(model, ranked[0][4]), out["measured"]
+                keys = ["exp_us", "conv_us"] + (["pack_us"] if is_pack(best) else []) + ["fdim_us", "fold_us"]
+                predicted = [pred[k] * (1 if k in ("exp_us", "conv_us") else fac) for k in keys]
+                actual = [meas[k] for k in keys]
+                predicted.append(sum(predicted))
+                actual.append(meas["total_us"])
+                out["deviation"] = {"factor": fac, "name": keys + ["total_us"], "predicted_times": predicted, "actual_times": actual,
+                                    "abs_err": [abs(x - y) for x, y in zip(predicted, actual)],
+                                    "rel_err": [abs(x - y) / x if x else 0 for x, y in zip(predicted, actual)]}
         print(json.dumps(out))
+        if "deviation" in out:  # the reference's table, after the JSON line
+            d = out["deviation"]
+            print("factor", d["factor"])
+            for row in ("name", "predicted_times", "actual_times", "abs_err", "rel_err"):
+                print(" ".join([row] + [str(round(v, 3)) if isinstance(v, float) else str(v) for v in d[row]]) if row != "name" else " ".join(["name"] + d["name"]))
         return 0
     if a.set:
         work, _, variant = a.set.partition(":")
