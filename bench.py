@@ -224,7 +224,7 @@ def bench_pack(args):
         print(json.dumps(out), flush=True)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -240,54 +240,120 @@ def main():
     ap.add_argument("--event-every", type=int, default=5, help="bracket the stages with HIP events on every n-th timed step only (1 = every step)")
     ap.add_argument("--root-fold", action="store_true", help="N > 1: plain reduce to rank 0, which lifts and folds alone")
     ap.add_argument("--lanes", type=int, default=3, help="N = 1: queries in flight in the extra throughput leg (`pipelined` in the JSON line; 1 = skip it)")
-    ap.add_argument("--comm-overlap", action="store_true", help="N > 1 with the sharded expansion: overlap the all-gather of the GSW bits with ScalToMat + sweep and the "
-                    "Regev->GSW conversion with the reduce-scatter (async collectives; one more graph launch and two more stream joins per query: "
-                    "+20..50 us at world size 1, where there is nothing to hide, so it is opt-in until measured on N > 1)")
+    ap.add_argument("--schedule", default="both", choices=["both", "in-order", "comm-overlap"], help="N > 1 with the sharded expansion and the distributed fold: "
+                    "in-order = every collective where its result is needed; comm-overlap = the all-gather of the GSW bits under ScalToMat + sweep and the "
+                    "Regev->GSW conversion under the reduce-scatter (async collectives); both (default) = each timed over the K steps, `value` is the "
+                    "faster one and `schedules` holds both")
+    ap.add_argument("--comm-overlap", action="store_true", help="same as --schedule comm-overlap")
     ap.add_argument("--replicated-expansion", action="store_true", help="N > 1: every rank runs the whole query expansion (default: each rank expands its own "
                     "first-dimension subtree and every N-th GSW bit, one all-gather of the GSW bits)")
+    ap.add_argument("--no-config3", action="store_true", help="skip the secondary leg (`also.config3`: BASELINE.json configs[2]'s 2^24 x 256 B geometry, the one whose "
+                    "sweep is most of the query, timed after the headline workload in the same invocation so that the N = 1, 2, 4, 8 runs give its curve too)")
+    ap.add_argument("--config3-steps", type=int, default=10)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the one-GPU self-test)")
     ap.add_argument("--shared-device", action="store_true", help="self-test: all ranks use device 0")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the reduce even with one rank (self-test)")
-    args = ap.parse_args()
-    if args.workload == "pack":
-        return bench_pack(args)
+    args = ap.parse_args(argv)
+    if args.comm_overlap:
+        args.schedule = "comm-overlap"
+    return args
 
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher in the environment: start the N ranks as fresh child processes
+    (torch.distributed.run, one per GPU, rendezvous on 127.0.0.1) BEFORE this process imports torch or touches a GPU, pass
+    their output through (rank 0 prints the JSON line) and return their exit code.  Nothing is exec'd from a process that has
+    initialised the GPU: this parent never does."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print(f"bench.py: no WORLD_SIZE in the environment, launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
+class Ctx:
+    """what every leg of one invocation shares: the rank layout and the (once-initialised) process group"""
+
+    def __init__(self, args):
+        import torch
+
+        self.torch = torch
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+        if args.shared_device:  # self-test of the N > 1 flow on a one-GPU box: every rank on device 0 (use with --backend gloo)
+            self.local_rank = 0
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        self.use_dist = self.world > 1 or args.force_dist
+        self.dist = None
+        self.rccl = None
+        if self.use_dist:
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            if args.backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(backend=args.backend)
+            self.dist = dist
+            # what the communicator actually saw (not what the command line asked for): every rank's device, gathered
+            mine = {"rank": dist.get_rank(), "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device": torch.cuda.current_device(),
+                    "name": torch.cuda.get_device_name(self.dev), "pid": os.getpid()}
+            seen = [None] * dist.get_world_size()
+            dist.all_gather_object(seen, mine)
+            self.rccl = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_seen": seen,
+                         "distinct_devices": len({(r["device"]) for r in seen}), "nccl_version": list(torch.cuda.nccl.version()) if args.backend == "nccl" else None}
+
+    def fence(self):
+        if self.use_dist:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, dt):
+        if not self.use_dist:
+            return dt
+        t = self.torch.tensor([dt], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.use_dist:
+            self.dist.destroy_process_group()
+
+
+def bench_base(args, ctx, workload, steps, warmup, primary):
+    """one leg: `steps` timed queries of `workload` through the base server on ctx.world ranks.  primary: the headline leg, which
+    also carries the throughput leg, the transform roofline and the reference-bucket detail."""
     import numpy as np
-    import torch
 
     import spiral_amd as sa
     from spiral_amd import dist as sdist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    if args.shared_device:  # self-test of the N > 1 flow on a one-GPU box: every rank on device 0 (use with --backend gloo)
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or args.force_dist
-    if use_dist:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend=args.backend)
-
-    params_kw = dict(WORKLOADS[args.workload])
+    torch, dist = ctx.torch, ctx.dist
+    world, rank, local_rank, dev, use_dist = ctx.world, ctx.rank, ctx.local_rank, ctx.dev, ctx.use_dist
+    params_kw = dict(WORKLOADS[workload])
     label = params_kw.pop("label")
-    if args.nu1 is not None: params_kw["nu1"] = args.nu1
-    if args.nu2 is not None: params_kw["nu2"] = args.nu2
-    if (args.nu1, args.nu2) != (None, None): label += f" with nu1={params_kw['nu1']}, nu2={params_kw['nu2']}"
-    args.nu1, args.nu2 = params_kw["nu1"], params_kw["nu2"]
+    if primary:
+        if args.nu1 is not None: params_kw["nu1"] = args.nu1
+        if args.nu2 is not None: params_kw["nu2"] = args.nu2
+        if (args.nu1, args.nu2) != (None, None): label += f" with nu1={params_kw['nu1']}, nu2={params_kw['nu2']}"
+    nu1, nu2 = params_kw["nu1"], params_kw["nu2"]
     pg = sa.make_params(**params_kw)
     shp = sa.get_shape(pg)
     j0, j1 = sdist.shard_range(rank, world, shp.dim0)
@@ -322,19 +388,26 @@ def main():
         srv.set_expand_shard(rank, world)
         bits = torch.zeros(srv.gsw_bits_words(), dtype=torch.int64, device=dev)
         bits_all = torch.zeros(world * bits.numel(), dtype=torch.int64, device=dev)
-    overlap_comm = shard_expand and sharded_fold and args.comm_overlap
+    can_overlap = shard_expand and sharded_fold
+    if not can_overlap:
+        schedules = ["in-order"]
+    elif args.schedule == "both":  # at world size 1 there is nothing to hide: the comparison is for real multi-rank runs (and the self-tests)
+        schedules = ["in-order", "comm-overlap"] if (world > 1 or args.force_dist) else ["in-order"]
+    else:
+        schedules = [args.schedule]
     srv.use_graphs(not args.no_graphs)  # expand+convert and lift+fold+finish replay as two hipGraphs
     srv.set_overlap(bool(args.overlap))
 
     # HIP events bracket the stages (and give the sweep's launch duration for the roofline) on every event_every-th timed
     # step; an event record costs the stream ~6 us, so the other steps replay the whole query (one GPU) or everything before
-    # the collective (N GPUs) as one graph
-    sampled = [k for k in range(args.steps) if k % max(1, args.event_every) == 0]
-    ev = {k: [torch.cuda.Event(enable_timing=True) for _ in range(4)] for k in sampled}
+    # the collective (N GPUs) as one graph.  On those steps every collective is bracketed too (`collectives_us`).
+    sampled = [k for k in range(steps) if k % max(1, args.event_every) == 0]
+    new_events = lambda: [torch.cuda.Event(enable_timing=True) for _ in range(10)]
+    ev = {k: new_events() for k in sampled}
 
     whole = world == 1 and not use_dist and not args.no_graphs and not args.overlap and args.event_every > 1
 
-    def step(e=None):
+    def step(e=None, overlap_comm=False):
         # one query: [expand, convert] -> sweep -> [reduce over ranks] -> [lift, fold, response switch]
         if e is None and whole:
             srv.run_query()  # the same kernels as below, replayed as ONE hipGraph: no event / launch seams around the sweep
@@ -343,7 +416,9 @@ def main():
             e[0].record(stream)
             if shard_expand:
                 srv.run_expand_pack(bits.data_ptr())
+                e[4].record(stream)
                 sdist.all_gather_gsw_bits(bits_all, bits)
+                e[5].record(stream)
                 srv.gsw_bits_unpack(bits_all.data_ptr())
                 srv.convert()
             else:
@@ -373,48 +448,53 @@ def main():
         else:
             srv.run_pre_sweep()  # one graph for everything before the collective
         if sharded_fold:
+            if e: e[6].record(stream)
             sdist.reduce_scatter_accumulators(chunk, acc)
+            if e: e[7].record(stream)
             srv.fold_local(chunk.data_ptr(), ct.data_ptr())
+            if e: e[8].record(stream)
             sdist.all_gather_cts(gathered, ct)
+            if e: e[9].record(stream)
             if rank == 0:
                 srv.fold_root(gathered.data_ptr())
         else:
             if use_dist:
+                if e: e[6].record(stream)
                 sdist.reduce_accumulators(acc, dst=0)
+                if e: e[7].record(stream)
             if rank == 0:
                 srv.run_post(reduce_first=use_dist)
         if e: e[3].record(stream)
 
-    def fence():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    timed = {}
     with torch.cuda.stream(stream):
         if not args.no_graphs:  # priming, not a step of the run: each step flavour once, so that no hipGraph is captured later
-            step([torch.cuda.Event(enable_timing=True) for _ in range(4)])
-            step(None)
-        for i in range(args.warmup):
-            step(None)
-        fence()
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            step(ev[k] if k in sampled else None)
-        fence()
-        dt = time.perf_counter() - t0
-        if use_dist:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            step(new_events())
+            for sch in schedules:
+                step(None, sch == "comm-overlap")
+        for sch in schedules:
+            ov = sch == "comm-overlap"
+            for i in range(warmup):
+                step(None, ov)
+            ctx.fence()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                # the stage events belong to the in-order flavour (with comm-overlap the stages interleave); every schedule still runs exactly `steps` steps
+                step(ev[k] if (k in sampled and not ov) else None, ov)
+            ctx.fence()
+            timed[sch] = ctx.max_over_ranks(time.perf_counter() - t0) * 1e3 / steps
+        if "in-order" not in timed:  # --schedule comm-overlap: the stage split still comes from a few in-order steps, outside the timed region
+            for k in sampled:
+                step(ev[k])
+            ctx.fence()
         # throughput leg (outside the timed region, reported beside `value`, never as it): `lanes` queries in flight on one database
         # image, one server handle and one stream per lane, each replaying the whole-query graph
         pipelined = None
-        if whole and args.lanes > 1:
+        if primary and whole and args.lanes > 1:
             lanes = [(srv, stream)]
             for _ in range(args.lanes - 1):
-                lane, lane_stream = sa.Server(pg, local_rank, j0, j1), torch.cuda.Stream(device=dev)
+                lane, lane_stream = sa.Server(pg, local_rank, j0, j1, share_db_of=srv), torch.cuda.Stream(device=dev)
                 lane.set_stream(lane_stream.cuda_stream)
-                lane.share_db(srv)
                 lane.set_pub_params(*pub)
                 lane.set_query(query)
                 lane.use_graphs(True)
@@ -422,7 +502,7 @@ def main():
             for lane, _ in lanes:
                 lane.run_query()  # graph capture, untimed
             torch.cuda.synchronize()
-            n_q = max(args.steps, 100) // args.lanes * args.lanes
+            n_q = max(steps, 100) // args.lanes * args.lanes
             t1 = time.perf_counter()
             for k in range(n_q):
                 lanes[k % args.lanes][0].run_query()
@@ -435,26 +515,31 @@ def main():
                 lane.close()
         # untimed: the reference's stage buckets (src/spiral.cpp:246-257) from one eager pass with HIP events
         detail = None
-        if world == 1:
+        if primary and world == 1:
             srv.set_overlap(False)
             srv.use_graphs(False)
             detail = srv.answer_resident()
             detail = srv.answer_resident()
 
-    ms_per_step = dt * 1e3 / args.steps
+    best = min(timed, key=timed.get)
+    ms_per_step = timed[best]
     names = ["expand_convert", "sweep", "reduce_lift_fold_switch"]  # the last bucket includes the collective(s)
     stages = {n: sum(ev[k][i].elapsed_time(ev[k][i + 1]) for k in sampled) / len(sampled) * 1e3 for i, n in enumerate(names)}
+    coll = {}
+    if use_dist:
+        pairs = ([("all_gather_gsw_bits", 4, 5)] if shard_expand else []) + ([("reduce_scatter_accumulators", 6, 7), ("all_gather_folded_cts", 8, 9)] if sharded_fold else [("reduce_accumulators", 6, 7)])
+        coll = {n: round(sum(ev[k][a].elapsed_time(ev[k][b]) for k in sampled) / len(sampled) * 1e3, 1) for n, a, b in pairs}
     sweep_ms = stages["sweep"] / 1e3
     bytes_sweep = srv.sweep_bytes()
     achieved = bytes_sweep / (sweep_ms * 1e-3) / 1e9
-    traffic, traffic_src = pmc_traffic(world, args.nu1, args.nu2)
+    traffic, traffic_src = pmc_traffic(world, nu1, nu2)
     out = {
-        "metric": "server ms/query + DB GB/s vs HBM roofline" + (", 2^20 x 256B" if args.workload == "config2" else f" ({args.workload})"),
+        "metric": "server ms/query + DB GB/s vs HBM roofline" + (", 2^20 x 256B" if workload == "config2" else f" ({workload})"),
         "value": round(ms_per_step, 4),
         "unit": "ms/query",
         "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
+        "steps": steps,
+        "warmup": warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": False,
         "scaling": "strong",
@@ -465,7 +550,7 @@ def main():
                    "db_bytes_ntt_form": int(shp.dim0) * int(shp.num_per) * 4 * sa.N * 8, "schedule": "GSW conversion overlapped with the sweep (side stream)" if args.overlap else "in order, one stream",
                    "parallelism": (f"j-shard x{world}, reduce-scatter + distributed fold + all-gather" if sharded_fold else f"j-shard x{world} + 1 reduce")
                                   + (", sharded expansion + all-gather of the GSW bits" if shard_expand else "")
-                                  + (" (overlapped with ScalToMat + sweep)" if overlap_comm else "")},
+                                  + (" (overlapped with ScalToMat + sweep)" if best == "comm-overlap" else "")},
         "queries_per_s": round(1e3 / ms_per_step, 2),
         "stages_us": {k: round(v, 1) for k, v in stages.items()},
         "reference_buckets_us_eager": ({k: round(v, 1) for k, v in detail.items() if k != "scaltomat_us"} if detail else None),
@@ -473,30 +558,60 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "frac_device_bytes": round(srv.sweep_device_bytes() / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(bytes_sweep),
                      "avg_launch_ms": round(sweep_ms, 4),
                      "device_bytes_per_launch": int(srv.sweep_device_bytes()), "achieved_device_bytes": round(srv.sweep_device_bytes() / (sweep_ms * 1e-3) / 1e9, 1),
-                     "note": "achieved / frac = SURVEY 8d algorithmic bytes (8 B per database word) / launch time; the device keeps a word's two 28-bit residues in 7 bytes, so a launch physically moves device_bytes_per_launch: achieved_device_bytes / frac_device_bytes are the HBM utilisation in physical bytes (traffic = the PMC measurement of them)", "launches_timed": len(sampled), "shard": f"j in [{j0},{j1}) on rank 0"},
+                     "note": "achieved / frac = SURVEY 8d algorithmic bytes (8 B per database word) / launch time measured in THIS run with HIP events on the launch stream; "
+                             "the device keeps a word's two 28-bit residues in 7 bytes, so a launch physically moves device_bytes_per_launch: achieved_device_bytes / "
+                             "frac_device_bytes are the HBM utilisation in physical bytes.  `traffic` is NOT measured in this run: it is the rocprofv3 PMC figure "
+                             "(FETCH_SIZE / WRITE_SIZE passes) read from the committed file named in traffic_source, valid for configs[1] on one GPU only (null otherwise)",
+                     "launches_timed": len(sampled), "shard": f"j in [{j0},{j1}) on rank 0"},
     }
+    if use_dist:
+        out["schedules"] = {"ms_per_query": {k: round(v, 4) for k, v in timed.items()}, "chosen": best,
+                            "note": "each schedule timed over the same K steps after W warm-up steps, max over ranks; value = the faster one"}
+        out["collectives_us"] = coll
+        out["rccl"] = ctx.rccl
     # the transform kernels against their VALU bound (they are the rest of the query: ~29 k limb-pair transforms at config 2).
     # Bound: the bare Harvey / Shoup butterfly = 3 integer multiplies (4.45 cycles each per wave instruction per SIMD, measured,
     # profiles/r02_ubench_valu.txt) + 4 add / sub (2.9) = 25 cycles x 88 limb-butterflies per thread, 4 waves per polynomial on
     # 4 SIMDs: 2200 cycles per polynomial per CU = 3.6 ns per polynomial over 256 CUs at 2.4 GHz.
-    roofline_ntt = None
-    if rank == 0 and world == 1:
+    if primary and rank == 0 and world == 1:
         fwd_ms, inv_ms = sa.time_ntt(16384, 10)
         ns_f, ns_i = fwd_ms * 1e6 / 16384, inv_ms * 1e6 / 16384
         ns_d = sa.time_ntt_digits(2048, 8, 10) * 1e6 / 16384
-        roofline_ntt = {"bound": "valu", "unit": "ns per limb-pair transform (2048 points x 2 primes)", "peak": 3.6,
-                        "forward_to_ntt": round(ns_f, 2), "inverse_from_ntt": round(ns_i, 2), "forward_digits": round(ns_d, 2),
-                        "frac_forward": round(3.6 / ns_f, 3), "frac_inverse": round(3.6 / ns_i, 3), "frac_forward_digits": round(3.6 / ns_d, 3),
-                        "batch": 16384, "note": "standalone launches of 16384 transforms, HIP events: to_ntt (reduce mod p, b + forward) and from_ntt (inverse + CRT lift) "
-                                                "each read and write 16 KiB of HBM per transform; forward_digits is the launch the stages are built from (8 gadget digits "
-                                                "of each of 2048 polynomials: the source is re-read from cache, every transform writes its 16 KiB)"}
+        out["roofline_ntt"] = {"bound": "valu", "unit": "ns per limb-pair transform (2048 points x 2 primes)", "peak": 3.6,
+                               "forward_to_ntt": round(ns_f, 2), "inverse_from_ntt": round(ns_i, 2), "forward_digits": round(ns_d, 2),
+                               "frac_forward": round(3.6 / ns_f, 3), "frac_inverse": round(3.6 / ns_i, 3), "frac_forward_digits": round(3.6 / ns_d, 3),
+                               "batch": 16384, "note": "standalone launches of 16384 transforms, HIP events: to_ntt (reduce mod p, b + forward) and from_ntt (inverse + CRT lift) "
+                                                       "each read and write 16 KiB of HBM per transform; forward_digits is the launch the stages are built from (8 gadget digits "
+                                                       "of each of 2048 polynomials: the source is re-read from cache, every transform writes its 16 KiB)"}
+    if pipelined: out["pipelined"] = pipelined
     srv.close()
-    if use_dist:
-        dist.destroy_process_group()
-    if rank == 0:
-        if roofline_ntt: out["roofline_ntt"] = roofline_ntt
-        if pipelined: out["pipelined"] = pipelined
-        if world == 1 and not args.no_cpu_baseline and args.workload == "config2":  # (the larger workloads' 32 / 64 GiB host databases are not built for a baseline)
+    del acc
+    torch.cuda.empty_cache()
+    return out, params_kw
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args, argv))
+    if args.workload == "pack":
+        return bench_pack(args)
+
+    import numpy as np
+
+    ctx = Ctx(args)
+    out, params_kw = bench_base(args, ctx, args.workload, args.steps, args.warmup, primary=True)
+    if args.workload == "config2" and not args.no_config3 and (args.nu1, args.nu2) == (None, None):
+        # secondary leg: configs[2]'s geometry, where the sweep is ~70 % of the query and the j-shard scales; the headline stays configs[1]
+        o3, _ = bench_base(args, ctx, "config3", args.config3_steps, min(args.warmup, 2), primary=False)
+        out["also"] = {"config3": {k: o3[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "stages_us", "queries_per_s", "schedules", "collectives_us") if k in o3}}
+        out["also"]["config3"]["workload"] = o3["config"]["workload"]
+        out["also"]["config3"]["parallelism"] = o3["config"]["parallelism"]
+        out["also"]["config3"]["roofline"] = {k: o3["roofline"][k] for k in ("achieved", "frac", "frac_device_bytes", "avg_launch_ms", "algorithmic_bytes_per_launch", "shard")}
+    ctx.close()
+    if ctx.rank == 0:
+        if ctx.world == 1 and not args.no_cpu_baseline and args.workload == "config2":  # (the larger workloads' 32 / 64 GiB host databases are not built for a baseline)
             out["cpu_baseline"] = cpu_baseline(params_kw, np, args.workload)
         import ctypes
 

@@ -137,8 +137,8 @@ int spiral_gpu_regev_to_gsw(uint64_t *out, const uint64_t *cv_v, const uint64_t 
  * Resident server: do_test's server half (src/spiral.cpp:2337-2406, 1584-1629) with the database,
  * public parameters and all intermediates in HBM.
  * ------------------------------------------------------------------------------------------------ */
-/* The server holds first-dimension indices j in [j_begin, j_end) of the database (the whole range
- * for a single GPU).  Shards are summed by the caller between first_dim and lift (see
+/* The server holds first-dimension indices j in [j_begin, j_end) of the database; (j_begin, j_end) = (0, 0) means the
+ * whole first dimension [0, 2^nu1) (a single GPU).  Shards are summed by the caller between first_dim and lift (see
  * spiral_gpu_server_acc). */
 int spiral_gpu_server_create(const spiral_gpu_params *p, int device, uint32_t j_begin, uint32_t j_end,
                              spiral_gpu_server **out);
@@ -167,12 +167,20 @@ int spiral_gpu_server_load_db_items(spiral_gpu_server *s, const void *items, uin
  * word (z, ii, c, j, m) at ((((z - z_begin)*num_per + ii)*n2 + c)*(j_end - j_begin) + (j - j_begin))*n0 + m */
 int spiral_gpu_server_read_db_item(spiral_gpu_server *s, uint64_t item, uint64_t *out);
 int spiral_gpu_server_read_db_slots(spiral_gpu_server *s, uint32_t z_begin, uint32_t nz, uint64_t *out);
+/* the same for ALL 2048 slots but only the plaintext columns ii in [ii_begin, ii_begin + n_ii): load_db's layout of a database
+ * with num_per = n_ii, i.e. exactly what multiplyQueryByDatabase (src/spiral.cpp:628) needs to produce the full output
+ * polynomials of those ciphertexts (2048 * n_ii * n2 * (j_end - j_begin) * n0 words; tests at sizes whose whole image
+ * does not fit a host-side reference) */
+int spiral_gpu_server_read_db_columns(spiral_gpu_server *s, uint32_t ii_begin, uint32_t n_ii, uint64_t *out);
 /* --random-data analogue: arbitrary valid NTT-form words, timing only */
 int spiral_gpu_server_fill_db_random(spiral_gpu_server *s, uint64_t seed);
 /* a second in-flight query on one database: `s` releases its own image and sweeps `owner`'s (same parameters, shard and device;
  * the owner outlives `s` and does not reload while `s` answers; loads through `s` fail).  One handle per query lane, each on
  * its own stream: the latency-bound expansion / folding of one query runs under the HBM-bound sweep of another. */
 int spiral_gpu_server_share_db(spiral_gpu_server *s, spiral_gpu_server *owner);
+/* the same in one step and without ever allocating a second image: a new server with `owner`'s parameters, device and shard
+ * whose database IS the owner's (a query lane).  Works for images larger than half of HBM, where create + share_db cannot. */
+int spiral_gpu_server_create_lane(spiral_gpu_server *owner, spiral_gpu_server **out);
 
 /* public parameters (NTT form): W_exp_left g x (n0 x t_exp), W_exp_right n_right x (n0 x t_exp_right),
  * W n1 x (n0*t_conv), V n1 x (2*t_conv)   (src/spiral.cpp:2091-2092, 2216-2227, 2279-2296) */
@@ -261,8 +269,10 @@ enum spiral_gpu_buffer {
 int spiral_gpu_server_keep_cts(spiral_gpu_server *s, int on);
 size_t spiral_gpu_server_buffer_words(spiral_gpu_server *s, int which);
 int spiral_gpu_server_read(spiral_gpu_server *s, int which, uint64_t *out);
-/* overwrite the lifted ciphertexts (raw [num_per][n1][n2][N]) -- lets a test drive fold() alone */
+/* the last answer's response in its wire form (see spiral_gpu_response_wire_bytes above): packed on the device, downloaded
+ * into `out` (capacity in bytes; fails when it is smaller than the wire form) */
 int spiral_gpu_server_read_response_wire(spiral_gpu_server *s, void *out, size_t capacity);
+/* overwrite the lifted ciphertexts (raw [num_per][n1][n2][N]) -- lets a test drive fold() alone */
 int spiral_gpu_server_write_raw(spiral_gpu_server *s, const uint64_t *raw_cts);
 
 /* measurement helper: average duration (ms) of the sweep kernel alone over `iters` launches, timed
@@ -330,9 +340,10 @@ int spiral_gpu_pack_server_set_pub_params(spiral_gpu_pack_server *s, const uint6
  * (out_n^2 sweeps + lift) [3] folding [4] packing + modulus switch [5] the sweep kernels alone [6] total. */
 int spiral_gpu_pack_server_answer(spiral_gpu_pack_server *s, const uint64_t *query, uint64_t *response, uint64_t *packed_ct,
                                   double stage_us[8]);
+/* the last answer's response in its wire form ((out_n+1) x out_n, spiral_gpu_response_wire_bytes(p, out_n) bytes) */
+int spiral_gpu_pack_server_read_response_wire(spiral_gpu_pack_server *s, void *out, size_t capacity);
 /* the first-dimension accumulators of one trial of the last answer (fastMultiplyQueryByDatabaseDim1's output, :1050):
  * num_per ciphertexts base_dim x 1, NTT form (tests) */
-int spiral_gpu_pack_server_read_response_wire(spiral_gpu_pack_server *s, void *out, size_t capacity);
 int spiral_gpu_pack_server_read_acc(spiral_gpu_pack_server *s, uint32_t trial, uint64_t *out);
 uint64_t spiral_gpu_pack_server_sweep_bytes(spiral_gpu_pack_server *s); /* algorithmic bytes of ONE trial's sweep */
 

@@ -15,7 +15,7 @@ inline IndexMap identity_map() { return IndexMap{1u, 1u, 0u}; }
 
 struct DeviceTables {
     uint4* fwd = nullptr;      // [2048] forward twiddles {W_p, W'_p, W_b, W'_b}
-    uint4* inv = nullptr;      // [2048] inverse twiddles (1/2 folded in)
+    uint4* inv = nullptr;      // [2048] inverse twiddles psi^-i (row 1 times N^-1, row 0 = N^-1: the stages are unscaled, tables.cpp)
     uint64_t* neg1 = nullptr;  // [11][2048] PK: NTT(-x^(N-2^r))   (src/spiral.cpp:171-190)
     uint64_t* neg1s = nullptr; // the same words' Shoup companions floor(w * 2^32 / m), PK
 };
@@ -250,7 +250,9 @@ void launch_fill_db_random(uint64_t* db_dev, uint32_t num_per, uint32_t dim0_sha
 // (j local to the shard) as n0 x n2 reference NTT-form polynomials, or nz slabs z0.. of load_db's layout restricted to
 // the shard's j-range (z in the reference's slot order)
 void launch_db_read_item(const uint64_t* db_dev, uint64_t* out_ref, uint32_t num_per, uint32_t dim0_shard, uint32_t j_local, uint32_t ii, hipStream_t s);
-void launch_db_read_slots(const uint64_t* db_dev, uint64_t* out, uint32_t num_per, uint32_t dim0_shard, uint32_t z0, uint32_t nz, hipStream_t s);
+// (restricted to the n_ii plaintext columns ii0 .. ii0 + n_ii - 1: the same layout with num_per = n_ii)
+void launch_db_read_slots(const uint64_t* db_dev, uint64_t* out, uint32_t num_per, uint32_t dim0_shard, uint32_t z0, uint32_t nz, uint32_t ii0, uint32_t n_ii,
+                          hipStream_t s);
 void launch_fill_db1_random(uint64_t* db_dev, uint32_t num_per, uint32_t dim0, uint64_t seed, hipStream_t s);
 // the GSW-bit ciphertexts (odd slots 2 i + 1 of cv, i < n_bits) a rank of a G-rank answer expanded itself (i = a G + rank) <->
 // its block of the all-gather buffer [rank][a < n_max][2 polynomials]; pack: cv -> this rank's block, unpack: all blocks -> cv

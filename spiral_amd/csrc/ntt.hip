@@ -407,7 +407,8 @@ __global__ __launch_bounds__(256) void ntt_inverse_kernel(Tables t, InvParams p)
             hi[r] %= kB;
         }
     }
-    ntt_inverse_block(lo, hi, sh, t.inv, tid);
+    constexpr bool kLift = EXPAND || STORE == IST_CRT;  // the CRT lift takes the transform's lazy outputs (crt_compose_lazy)
+    ntt_inverse_block<!kLift>(lo, hi, sh, t.inv, tid);
     if constexpr (EXPAND) {
         // store the automorphed polynomial a(x^t) (scatter form of src/poly.cpp:240-261: coefficient i goes to i*t mod N,
         // negated as Q - a when i*t mod 2N >= N), so that the t_exp .. t_exp_right digit transforms that follow read it
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(256) void ntt_inverse_kernel(Tables t, InvParams p)
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const uint32_t e = (ix_a(tid, r) * p.auto_t) & (2u * kN - 1u);
-            const uint64_t v = crt_compose(lo[r], hi[r]);
+            const uint64_t v = crt_compose_lazy(csub_min(lo[r], kP), hi[r]);
             sh[lds_ix(e & (kN - 1u))] = (e & kN) ? kQ - v : v;
         }
         __syncthreads();
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(256) void ntt_inverse_kernel(Tables t, InvParams p)
     } else if constexpr (STORE == IST_CRT) {
         uint64_t* dst = p.dst + (size_t)p.dst_map(b) * kN;
 #pragma unroll
-        for (int r = 0; r < 8; r++) dst[ix_a(tid, r)] = crt_compose(lo[r], hi[r]);
+        for (int r = 0; r < 8; r++) dst[ix_a(tid, r)] = crt_compose_lazy(csub_min(lo[r], kP), hi[r]);
     } else {
         uint64_t* dst = p.dst + (size_t)p.dst_map(b) * (2 * kN);
 #pragma unroll
@@ -459,10 +460,9 @@ __global__ __launch_bounds__(256) void fold_chain_kernel(Tables t, FoldChainPara
         const size_t sp = p.pack ? ((size_t)pt * p.src_stride + pip) * 2u + prow : (size_t)s;
         pk_load8_sum(p.src + sp * kN, p.src_parts, p.src_part_stride, p.pre_reduce != 0, tid, lo, hi);
     }
-    ntt_inverse_block(lo, hi, sh, t.inv, tid);
+    ntt_inverse_block<false>(lo, hi, sh, t.inv, tid);
     uint64_t v[8];
-#pragma unroll
-    for (int r = 0; r < 8; r++) v[r] = crt_compose(lo[r], hi[r]);
+    crt_lift8(lo, hi, v);
     // source s = (ct i', r, c) over [2*np][3][2]; operand layout D[i' % np][(i' / np)*m2 + r + 3k][c]  (as LD_SDIGIT)
     const uint32_t ct = s / 6u, rc = s - ct * 6u, row = rc >> 1, c = rc & 1u;
     const uint32_t m2 = 3u * p.ell, hi_half = ct / p.fold_np, i = ct - hi_half * p.fold_np;
@@ -504,10 +504,9 @@ __global__ __launch_bounds__(256, 3) void fold_fused_kernel(Tables t, FoldFusedP
     const uint32_t s = b / cpp, chunk = b - s * cpp, k0 = chunk * p.dpb, k1 = min(k0 + p.dpb, p.ell);
     uint32_t lo[8], hi[8];
     pk_load8_sum(p.src + (size_t)s * kN, p.src_parts, p.src_part_stride, p.pre_reduce != 0, tid, lo, hi);
-    ntt_inverse_block(lo, hi, sh, t.inv, tid);
+    ntt_inverse_block<false>(lo, hi, sh, t.inv, tid);
     uint64_t v[8];
-#pragma unroll
-    for (int r = 0; r < 8; r++) v[r] = crt_compose(lo[r], hi[r]);
+    crt_lift8(lo, hi, v);
     // source s = (ct i', row, c) over [2*np'][3][2]; its digit k is column mm = half * m2 + row + 3k of the key (as LD_SDIGIT's D)
     const uint32_t ct = s / 6u, rc = s - ct * 6u, row = rc >> 1, c = rc & 1u;
     const uint32_t m2 = 3u * p.ell, half = ct / p.fold_np, i = ct - half * p.fold_np;

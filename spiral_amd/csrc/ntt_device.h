@@ -46,7 +46,7 @@ namespace spiral {
 
 struct Tables {
     const uint4* fwd;  // [2048] {W_p, W'_p, W_b, W'_b} indexed like the reference's forward rows (m + i)
-    const uint4* inv;  // [2048] same for the inverse rows (h + i), 1/2 folded in
+    const uint4* inv;  // [2048] inverse rows (h + i): psi^-i unscaled, row 1 times N^-1, row 0 = N^-1 (tables.cpp)
 };
 
 // ---- butterflies --------------------------------------------------------------------------------
@@ -74,27 +74,44 @@ __device__ __forceinline__ void ct_bfly(uint32_t& x, uint32_t& y, uint32_t w, ui
     x = x0 + t;
     y = x0 + 2 * m - t;
 }
-// inverse (Gentleman-Sande, 1/2 folded per stage, src/core.cpp:445-472): the sum side grows by m/2 per stage,
-// the product side is always < 2m.  8m - v keeps the difference positive (v < 8m) and, 8m being even and m odd,
-// u + 8m - v has the parity of u + v, which is what the exact halving needs.
+// inverse (Gentleman-Sande).  The reference halves in every stage (u' = (u + v)/2, twiddles carrying the 1/2,
+// src/core.cpp:445-472); the 11 halvings are one multiplication by N^-1, which is exact modular arithmetic either way, so
+// here the stages are unscaled -- u' = u + v, v' = (u - v) w with w = psi^-i -- and the LAST stage multiplies both outputs by
+// N^-1 (the difference side through its twiddle, the sum side by the constant kept in row 0 of the table).  That removes
+// the parity test, select, add and shift of every butterfly (4 of its 10 instructions); the price is that the sum side
+// doubles per stage instead of growing by m/2, so the sum-side registers are range-reduced once per pass (see
+// ntt_inverse_block).  VB: the difference is taken as u + VB m - v, VB m being at least the bound of v.
+template <uint32_t VB>
 __device__ __forceinline__ void gs_bfly(uint32_t& u, uint32_t& v, uint32_t w, uint32_t ws, uint32_t m) {
-    const uint32_t t = u + 8 * m - v;
-    const uint32_t s = u + v;
-    u = (s + ((s & 1u) ? m : 0u)) >> 1;
+    const uint32_t t = u + VB * m - v;
+    u = u + v;
 #ifdef NTT_ABLATE_ALU
     v = t ^ w;
 #else
     v = shoup(t, w, ws, m);
 #endif
 }
+// last stage: both outputs scaled by N^-1 (n = {N^-1 mod p, its Shoup companion, N^-1 mod b, companion}; w already carries it)
+template <uint32_t VB>
+__device__ __forceinline__ void gs_bfly_last(uint32_t& u, uint32_t& v, uint32_t w, uint32_t ws, uint32_t n, uint32_t ns, uint32_t m) {
+    const uint32_t t = u + VB * m - v;
+    u = shoup(u + v, n, ns, m);
+    v = shoup(t, w, ws, m);
+}
 
 __device__ __forceinline__ void ct2(uint32_t* lo, uint32_t* hi, int a, int b, uint4 tw) {
     ct_bfly(lo[a], lo[b], tw.x, tw.y, kP);
     ct_bfly(hi[a], hi[b], tw.z, tw.w, kB);
 }
+template <uint32_t VB>
 __device__ __forceinline__ void gs2(uint32_t* lo, uint32_t* hi, int a, int b, uint4 tw) {
-    gs_bfly(lo[a], lo[b], tw.x, tw.y, kP);
-    gs_bfly(hi[a], hi[b], tw.z, tw.w, kB);
+    gs_bfly<VB>(lo[a], lo[b], tw.x, tw.y, kP);
+    gs_bfly<VB>(hi[a], hi[b], tw.z, tw.w, kB);
+}
+template <uint32_t VB>
+__device__ __forceinline__ void gs2_last(uint32_t* lo, uint32_t* hi, int a, int b, uint4 tw, uint4 n) {
+    gs_bfly_last<VB>(lo[a], lo[b], tw.x, tw.y, n.x, n.y, kP);
+    gs_bfly_last<VB>(hi[a], hi[b], tw.z, tw.w, n.z, n.w, kB);
 }
 
 // three forward stages on 8 register-resident coefficients whose indices differ in the 3 bits the
@@ -122,31 +139,6 @@ __device__ __forceinline__ void ct_radix4x2(uint32_t* lo, uint32_t* hi, const TW
 #pragma unroll
     for (int q = 0; q < 4; q++) ct2(lo, hi, 2 * q, 2 * q + 1, tw[TWI(b2 + q)]);
 }
-// inverse order: distance 1, 2, 4
-template <class TW>
-__device__ __forceinline__ void gs_radix8(uint32_t* lo, uint32_t* hi, const TW& tw, uint32_t b0, uint32_t b1, uint32_t b2) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) gs2(lo, hi, 2 * q, 2 * q + 1, tw[TWI(b2 + q)]);
-    uint4 t1a = tw[TWI(b1)], t1b = tw[TWI(b1 + 1)];
-    gs2(lo, hi, 0, 2, t1a);
-    gs2(lo, hi, 1, 3, t1a);
-    gs2(lo, hi, 4, 6, t1b);
-    gs2(lo, hi, 5, 7, t1b);
-    uint4 t0 = tw[TWI(b0)];
-#pragma unroll
-    for (int k = 0; k < 4; k++) gs2(lo, hi, k, k + 4, t0);
-}
-template <class TW>
-__device__ __forceinline__ void gs_radix4x2(uint32_t* lo, uint32_t* hi, const TW& tw, uint32_t b1, uint32_t b2) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) gs2(lo, hi, 2 * q, 2 * q + 1, tw[TWI(b2 + q)]);
-    uint4 t1a = tw[TWI(b1)], t1b = tw[TWI(b1 + 1)];
-    gs2(lo, hi, 0, 2, t1a);
-    gs2(lo, hi, 1, 3, t1a);
-    gs2(lo, hi, 4, 6, t1b);
-    gs2(lo, hi, 5, 7, t1b);
-}
-
 // the 7 twiddles of a radix-8 pass (6 of a radix-4x2 pass), loaded ahead of the pass so that their latency hides
 // behind the previous pass's arithmetic and the LDS exchange
 struct Tw7 {
@@ -191,23 +183,54 @@ __device__ __forceinline__ void ct_radix4x2_pre(uint32_t* lo, uint32_t* hi, cons
     for (int q = 0; q < 4; q++) ct2(lo, hi, 2 * q, 2 * q + 1, w.t[3 + q]);
 }
 
+// inverse passes (stage distances 1, 2, 4 in register numbering), inputs < 2m.  Bounds in units of m after each stage:
+//   distance 1: sums (0,2,4,6) < 4, products (1,3,5,7) < 2
+//   distance 2: (0,4) < 8, (1,5) < 4, (2,3,6,7) < 2
+//   distance 4: 0 < 16, 1 < 8, (2,3) < 4, (4..7) < 2            -- 16 m < 2^32 for both primes
+__device__ __forceinline__ void gs_stage12(uint32_t* lo, uint32_t* hi, const Tw7& w) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) gs2<2>(lo, hi, 2 * q, 2 * q + 1, w.t[3 + q]);
+    gs2<4>(lo, hi, 0, 2, w.t[1]);
+    gs2<2>(lo, hi, 1, 3, w.t[1]);
+    gs2<4>(lo, hi, 4, 6, w.t[2]);
+    gs2<2>(lo, hi, 5, 7, w.t[2]);
+}
+// [0, 16m) -> [0, 2m): lazy_reduce alone leaves up to 2.13 m for inputs beyond 14 m (prime b)
+__device__ __forceinline__ uint32_t lazy_reduce16(uint32_t x, uint32_t m) {
+    const uint32_t r = lazy_reduce(x, m);
+    return min(r, r - 2 * m);
+}
 __device__ __forceinline__ void gs_radix8_pre(uint32_t* lo, uint32_t* hi, const Tw7& w) {
+    gs_stage12(lo, hi, w);
+    gs2<8>(lo, hi, 0, 4, w.t[0]);
+    gs2<4>(lo, hi, 1, 5, w.t[0]);
+    gs2<2>(lo, hi, 2, 6, w.t[0]);
+    gs2<2>(lo, hi, 3, 7, w.t[0]);
+    lo[0] = lazy_reduce16(lo[0], kP);
+    hi[0] = lazy_reduce16(hi[0], kB);
 #pragma unroll
-    for (int q = 0; q < 4; q++) gs2(lo, hi, 2 * q, 2 * q + 1, w.t[3 + q]);
-    gs2(lo, hi, 0, 2, w.t[1]);
-    gs2(lo, hi, 1, 3, w.t[1]);
-    gs2(lo, hi, 4, 6, w.t[2]);
-    gs2(lo, hi, 5, 7, w.t[2]);
-#pragma unroll
-    for (int k = 0; k < 4; k++) gs2(lo, hi, k, k + 4, w.t[0]);
+    for (int k = 1; k < 4; k++) {
+        lo[k] = lazy_reduce(lo[k], kP);
+        hi[k] = lazy_reduce(hi[k], kB);
+    }
+}
+// the last pass: its distance-4 stage applies N^-1 (n = row 0 of the table); every output is a Shoup product, < 2m
+__device__ __forceinline__ void gs_radix8_last(uint32_t* lo, uint32_t* hi, const Tw7& w, uint4 n) {
+    gs_stage12(lo, hi, w);
+    gs2_last<8>(lo, hi, 0, 4, w.t[0], n);
+    gs2_last<4>(lo, hi, 1, 5, w.t[0], n);
+    gs2_last<2>(lo, hi, 2, 6, w.t[0], n);
+    gs2_last<2>(lo, hi, 3, 7, w.t[0], n);
 }
 __device__ __forceinline__ void gs_radix4x2_pre(uint32_t* lo, uint32_t* hi, const Tw7& w) {
+    gs_stage12(lo, hi, w);
 #pragma unroll
-    for (int q = 0; q < 4; q++) gs2(lo, hi, 2 * q, 2 * q + 1, w.t[3 + q]);
-    gs2(lo, hi, 0, 2, w.t[1]);
-    gs2(lo, hi, 1, 3, w.t[1]);
-    gs2(lo, hi, 4, 6, w.t[2]);
-    gs2(lo, hi, 5, 7, w.t[2]);
+    for (int k = 0; k < 8; k += 4) {  // registers 0, 4 < 8m and 1, 5 < 4m
+        lo[k] = lazy_reduce(lo[k], kP);
+        hi[k] = lazy_reduce(hi[k], kB);
+        lo[k + 1] = lazy_reduce(lo[k + 1], kP);
+        hi[k + 1] = lazy_reduce(hi[k + 1], kB);
+    }
 }
 
 // ---- LDS tile -----------------------------------------------------------------------------------
@@ -341,8 +364,10 @@ __device__ __forceinline__ void ntt_forward_block(uint32_t* lo, uint32_t* hi, ui
 }
 
 // Inverse transform: in (lo,hi)[k] <-> slot ix_d(tid,k), values in [0, 2m);
-// out (lo,hi)[k] <-> coefficient ix_a(tid,k) = tid + 256k, canonical in [0, m).
-// Bounds: sum side < 2m + 11 * m/2 = 7.5m, product side < 2m: every t = u + 8m - v is in (0, 15.5m).
+// out (lo,hi)[k] <-> coefficient ix_a(tid,k) = tid + 256k, in [0, 2m) (CANONICAL: [0, m)).
+// `tw` is the device inverse table (tables.cpp): row 0 = N^-1, row 1 = psi^-(N/2) N^-1, rows >= 2 = psi^-i (no halving).
+// Every pass starts from values < 2m and range-reduces its sum-side registers before the exchange (gs_radix*_pre).
+template <bool CANONICAL = true>
 __device__ __forceinline__ void ntt_inverse_block(uint32_t* lo, uint32_t* hi, uint64_t* sh, const uint4* tw, uint32_t tid) {
     // as in the forward transform: the next pass's twiddles are in flight during the current pass
     const TwTable tb(tw);
@@ -361,6 +386,7 @@ __device__ __forceinline__ void ntt_inverse_block(uint32_t* lo, uint32_t* hi, ui
     __syncthreads();
     lds_get<ix_b>(sh, tid, lo, hi);
     Tw7 wa = tw_load8(tw, 1, 2, 4);
+    const uint4 ninv = tw[0];
     NTT_PRIO_LO();
     gs_radix8_pre(lo, hi, wb);
     NTT_PRIO_HI();
@@ -368,12 +394,23 @@ __device__ __forceinline__ void ntt_inverse_block(uint32_t* lo, uint32_t* hi, ui
     __syncthreads();
     lds_get<ix_a>(sh, tid, lo, hi);
     NTT_PRIO_LO();
-    gs_radix8_pre(lo, hi, wa);
+    gs_radix8_last(lo, hi, wa, ninv);
+    if constexpr (CANONICAL) canonicalize8(lo, hi);
+}
+
+// CRT lift of a coefficient whose residues are (x mod p canonical, y mod b in [0, 2b)) to [0, Q): Garner form as
+// common.h crt_compose (src/poly.cpp:344-353), the product by p^-1 mod b as a Shoup product so that it takes three
+// multiplies instead of a 64-bit remainder, and the b-side consumed lazily.
+constexpr uint32_t kPinvBShoup = 1676084570u;  // floor(kPinvB * 2^32 / kB)
+__device__ __forceinline__ uint64_t crt_compose_lazy(uint32_t x, uint32_t y2) {
+    const uint32_t d = y2 + 2 * kB - x;  // == y - x (mod b), positive: x < p < 2b
+    const uint32_t k = csub_min(shoup(d, kPinvB, kPinvBShoup, kB), kB);
+    return (uint64_t)x + (uint64_t)kP * k;
+}
+// the inverse transform's lazy outputs -> CRT-lifted coefficients
+__device__ __forceinline__ void crt_lift8(const uint32_t* lo, const uint32_t* hi, uint64_t (&v)[8]) {
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        lo[k] = csub_min(lazy_reduce(lo[k], kP), kP);
-        hi[k] = csub_min(lazy_reduce(hi[k], kB), kB);
-    }
+    for (int r = 0; r < 8; r++) v[r] = crt_compose_lazy(csub_min(lo[r], kP), hi[r]);
 }
 
 }  // namespace spiral

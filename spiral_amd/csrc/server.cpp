@@ -71,11 +71,18 @@ uint32_t fold_dpb(const spiral_gpu_server* S, uint32_t n_src) {
     return dpb;
 }
 
-int srv_alloc(spiral_gpu_server* S) {
+int srv_alloc(spiral_gpu_server* S, const spiral_gpu_server* db_owner) {
     const spiral_gpu_params& p = S->p;
     const spiral_gpu_shape& s = S->s;
     const size_t nic = 2 * (size_t)s.num_per;
-    if (S->db.alloc(db_device_words((uint32_t)nic, S->dim0_shard))) return -1;
+    if (db_owner) {  // a query lane: the owner's image, never written or freed here
+        S->db.p = db_owner->db.p;
+        S->db.words = db_owner->db.words;
+        S->db_shared = true;
+        S->have_db = true;
+    } else if (S->db.alloc(db_device_words((uint32_t)nic, S->dim0_shard))) {
+        return -1;
+    }
     if (S->w_left.alloc((size_t)s.n_left * 2 * p.t_exp * kN)) return -1;
     if (S->w_right.alloc((size_t)s.n_right * 2 * p.t_exp_right * kN)) return -1;
     if (S->w.alloc((size_t)3 * 2 * p.t_conv * kN)) return -1;
@@ -584,7 +591,7 @@ int spiral_gpu_regev_to_gsw(uint64_t* out, const uint64_t* cv_v, const uint64_t*
 // ------------------------------------------------------------------------------------------------
 // resident server
 // ------------------------------------------------------------------------------------------------
-int spiral_gpu_server_create(const spiral_gpu_params* p, int device, uint32_t j_begin, uint32_t j_end, spiral_gpu_server** out) {
+static int srv_create(const spiral_gpu_params* p, int device, uint32_t j_begin, uint32_t j_end, const spiral_gpu_server* db_owner, spiral_gpu_server** out) {
     if (!p || !out) return fail("null argument");
     spiral_gpu_shape s;
     if (shape_of(p, &s)) return -1;
@@ -635,13 +642,24 @@ int spiral_gpu_server_create(const spiral_gpu_params* p, int device, uint32_t j_
             delete S;
             return fail("hipEventCreate failed");
         }
-    if (srv_alloc(S)) {
+    if (srv_alloc(S, db_owner)) {
         srv_free(S);
         delete S;
         return -1;
     }
     *out = S;
     return 0;
+}
+
+int spiral_gpu_server_create(const spiral_gpu_params* p, int device, uint32_t j_begin, uint32_t j_end, spiral_gpu_server** out) {
+    return srv_create(p, device, j_begin, j_end, nullptr, out);
+}
+
+int spiral_gpu_server_create_lane(spiral_gpu_server* owner, spiral_gpu_server** out) {
+    if (!owner || !out) return fail("null argument");
+    if (owner->db_shared) return fail("the owner does not own its database image");
+    if (!owner->have_db) return fail("the owner has no database loaded");
+    return srv_create(&owner->p, owner->device, owner->j0, owner->j1, owner, out);
 }
 
 void spiral_gpu_server_destroy(spiral_gpu_server* S) {
@@ -762,24 +780,32 @@ int spiral_gpu_server_read_db_item(spiral_gpu_server* S, uint64_t item, uint64_t
     return 0;
 }
 
-int spiral_gpu_server_read_db_slots(spiral_gpu_server* S, uint32_t z_begin, uint32_t nz, uint64_t* out) {
+static int read_db_region(spiral_gpu_server* S, uint32_t z_begin, uint32_t nz, uint32_t ii0, uint32_t n_ii, uint64_t* out) {
     if (!S || !out) return fail("null argument");
     HIP_OK(hipSetDevice(S->device));
     if (z_begin >= kN || nz == 0 || nz > kN - z_begin) return fail("slot range out of bounds");
-    const size_t per_z = (size_t)S->s.num_per * 2 * S->dim0_shard * 2;
+    if (n_ii == 0 || ii0 >= S->s.num_per || n_ii > S->s.num_per - ii0) return fail("column range out of bounds");
+    const size_t per_z = (size_t)n_ii * 2 * S->dim0_shard * 2;
     const uint32_t zchunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(nz, ((size_t)256 << 20) / (per_z * sizeof(uint64_t))));
     DevBuf st;
     if (st.alloc(per_z * zchunk)) return -1;
     hipError_t e = hipSuccess;
     for (uint32_t z = 0; z < nz && e == hipSuccess; z += zchunk) {
         const uint32_t n = std::min(zchunk, nz - z);
-        launch_db_read_slots(S->db.p, st.p, S->s.num_per, S->dim0_shard, z_begin + z, n, S->stream);
+        launch_db_read_slots(S->db.p, st.p, S->s.num_per, S->dim0_shard, z_begin + z, n, ii0, n_ii, S->stream);
         e = hipMemcpyAsync(out + (size_t)z * per_z, st.p, (size_t)n * per_z * sizeof(uint64_t), hipMemcpyDeviceToHost, S->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(S->stream);
     }
     st.release();
     if (e != hipSuccess) return fail("database read-back failed: %s", hipGetErrorString(e));
     return 0;
+}
+int spiral_gpu_server_read_db_slots(spiral_gpu_server* S, uint32_t z_begin, uint32_t nz, uint64_t* out) {
+    if (!S) return fail("null argument");
+    return read_db_region(S, z_begin, nz, 0, S->s.num_per, out);
+}
+int spiral_gpu_server_read_db_columns(spiral_gpu_server* S, uint32_t ii_begin, uint32_t n_ii, uint64_t* out) {
+    return read_db_region(S, 0, kN, ii_begin, n_ii, out);
 }
 
 int spiral_gpu_server_fill_db_random(spiral_gpu_server* S, uint64_t seed) {
@@ -802,6 +828,9 @@ int spiral_gpu_server_share_db(spiral_gpu_server* S, spiral_gpu_server* owner) {
     if (S->device != owner->device || S->j0 != owner->j0 || S->dim0_shard != owner->dim0_shard || S->p.nu1 != owner->p.nu1 || S->p.nu2 != owner->p.nu2 ||
         S->s.num_per != owner->s.num_per)
         return fail("share_db: the servers differ in device, shard or database geometry");
+    // the image encodes plaintexts mod p_db (centred lift) and the lane's response switch uses ITS p_db: they must agree
+    if (S->p.p_db != owner->p.p_db || S->p.direct_upload != owner->p.direct_upload)
+        return fail("share_db: the servers differ in plaintext modulus or query form");
     if (!owner->have_db) return fail("the owner has no database loaded");
     HIP_OK(hipSetDevice(S->device));
     HIP_OK(hipStreamSynchronize(S->stream));

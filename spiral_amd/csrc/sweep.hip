@@ -272,21 +272,22 @@ void launch_db_read_item(const uint64_t* db_dev, uint64_t* out_ref, uint32_t num
     hipLaunchKernelGGL(db_read_item_kernel, dim3(kN / 256, 4), dim3(256), 0, s, db_dev, out_ref, num_per, dim0_shard, j_local, ii);
 }
 __global__ __launch_bounds__(256) void db_read_slots_kernel(const uint64_t* __restrict__ dev, uint64_t* __restrict__ out, uint32_t num_per, uint32_t dim0_shard,
-                                                            uint32_t z0, uint32_t nz) {
-    const size_t o = (size_t)blockIdx.x * 256u + threadIdx.x, per_z = (size_t)num_per * 2u * dim0_shard * 2u;
+                                                            uint32_t z0, uint32_t nz, uint32_t ii0, uint32_t n_ii) {
+    const size_t o = (size_t)blockIdx.x * 256u + threadIdx.x, per_z = (size_t)n_ii * 2u * dim0_shard * 2u;
     const uint32_t zl = (uint32_t)(o / per_z);
     if (zl >= nz) return;
-    size_t rem = o - (size_t)zl * per_z;  // ii*(2*dim0*2) + c*(dim0*2) + j*2 + m
+    size_t rem = o - (size_t)zl * per_z;  // (ii - ii0)*(2*dim0*2) + c*(dim0*2) + j*2 + m
     const uint32_t m = (uint32_t)(rem & 1u);
     rem >>= 1;
     const uint32_t jl = (uint32_t)(rem % dim0_shard);
     rem /= dim0_shard;
-    const uint32_t c = (uint32_t)(rem & 1u), ii = (uint32_t)(rem >> 1);
+    const uint32_t c = (uint32_t)(rem & 1u), ii = ii0 + (uint32_t)(rem >> 1);
     out[o] = db_get_word(dev, pk_pos(z0 + zl), jl, ii * 2u + c, m, 2u * num_per, dim0_shard);
 }
-void launch_db_read_slots(const uint64_t* db_dev, uint64_t* out, uint32_t num_per, uint32_t dim0_shard, uint32_t z0, uint32_t nz, hipStream_t s) {
-    const size_t words = (size_t)nz * num_per * 2u * dim0_shard * 2u;
-    hipLaunchKernelGGL(db_read_slots_kernel, dim3((uint32_t)((words + 255) / 256)), dim3(256), 0, s, db_dev, out, num_per, dim0_shard, z0, nz);
+void launch_db_read_slots(const uint64_t* db_dev, uint64_t* out, uint32_t num_per, uint32_t dim0_shard, uint32_t z0, uint32_t nz, uint32_t ii0, uint32_t n_ii,
+                          hipStream_t s) {
+    const size_t words = (size_t)nz * n_ii * 2u * dim0_shard * 2u;
+    hipLaunchKernelGGL(db_read_slots_kernel, dim3((uint32_t)((words + 255) / 256)), dim3(256), 0, s, db_dev, out, num_per, dim0_shard, z0, nz, ii0, n_ii);
 }
 
 // reference reorientCiphertexts layout (src/spiral.cpp:410-433): z*(dim0*2*4) + j*8 + m*4 + r

@@ -1,6 +1,6 @@
 // Twiddle tables for the two CRT primes, regenerated from the minimal primitive 4096-th roots of unity
 // (psi_p = 66687, psi_b = 158221) instead of copying the reference's 436 KB blob (src/constants.cpp:16).
-// Layout and scaling follow src/core.cpp:6-17: fwd[bitrev11(i)] = psi^i, inv[bitrev11(i)] = psi^-i / 2,
+// Layout and scaling of the host rows follow src/core.cpp:6-17: fwd[bitrev11(i)] = psi^i, inv[bitrev11(i)] = psi^-i / 2,
 // scaled companion W' = floor(W * 2^32 / m).  tests/test_oracle_tables.py + test_capi_cpu.py pin the
 // result to the reference's data via tests/golden/ntt_tables.json.
 #include <mutex>
@@ -57,7 +57,22 @@ int tables_get(int device, DeviceTables* out) {
         std::vector<uint4> fwd(kN), inv(kN);
         for (uint32_t i = 0; i < kN; i++) {
             fwd[i] = make_uint4((uint32_t)rows[4 * kN + i], (uint32_t)rows[5 * kN + i], (uint32_t)rows[6 * kN + i], (uint32_t)rows[7 * kN + i]);
-            inv[i] = make_uint4((uint32_t)rows[0 * kN + i], (uint32_t)rows[1 * kN + i], (uint32_t)rows[2 * kN + i], (uint32_t)rows[3 * kN + i]);
+        }
+        // Device inverse table (ntt_device.h ntt_inverse_block): the reference's rows carry the 1/2 of its per-stage halving
+        // (src/core.cpp:6-17, 445-472); the kernels run the stages unscaled and apply N^-1 once, in the last stage, so here
+        // rows >= 2 are 2 * (reference row) = psi^-i, row 1 (the last stage's only twiddle) is psi^-(N/2) * N^-1 and the
+        // unused row 0 holds N^-1 itself.  spiral_gpu_get_tables still returns the reference's rows (tables_host_rows).
+        {
+            const uint64_t mods[2] = {kP, kB};
+            uint32_t w[2][kN];
+            for (int n = 0; n < 2; n++) {
+                const uint64_t m = mods[n], ninv = powmod(kN, m - 2, m);
+                for (uint32_t i = 0; i < kN; i++) w[n][i] = (uint32_t)(rows[(0 + 2 * n) * kN + i] * 2 % m);
+                w[n][1] = (uint32_t)((unsigned __int128)w[n][1] * ninv % m);
+                w[n][0] = (uint32_t)ninv;
+            }
+            for (uint32_t i = 0; i < kN; i++)
+                inv[i] = make_uint4(w[0][i], (uint32_t)(((uint64_t)w[0][i] << 32) / kP), w[1][i], (uint32_t)(((uint64_t)w[1][i] << 32) / kB));
         }
         DeviceTables t;
         if (hipSetDevice(device) != hipSuccess) return -1;

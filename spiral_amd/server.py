@@ -20,12 +20,18 @@ def _p(a: np.ndarray):
 
 
 class Server:
-    def __init__(self, params: Params, device: int = 0, j_begin: int = 0, j_end: int = 0):
+    def __init__(self, params: Params, device: int = 0, j_begin: int = 0, j_end: int = 0, share_db_of: "Server | None" = None):
+        """share_db_of: make this server a query lane of that one -- same parameters, device and shard, sweeping ITS database
+        image (no second image is ever allocated)"""
         self.params = params
         self.shape = Shape()
         check(lib().spiral_gpu_get_shape(C.byref(params), C.byref(self.shape)))
         h = C.c_void_p()
-        check(lib().spiral_gpu_server_create(C.byref(params), device, j_begin, j_end, C.byref(h)))
+        if share_db_of is not None:
+            check(lib().spiral_gpu_server_create_lane(share_db_of.h, C.byref(h)))
+            self._db_owner = share_db_of  # keeps the owner alive
+        else:
+            check(lib().spiral_gpu_server_create(C.byref(params), device, j_begin, j_end, C.byref(h)))
         self.h = h
         self.dim0_shard = (j_end - j_begin) if (j_begin or j_end) else self.shape.dim0
 
@@ -66,6 +72,12 @@ class Server:
         """load_db's layout restricted to this server's j-range: [nz][num_per][n2][j][n0] packed words"""
         out = np.zeros((nz, self.shape.num_per, 2, self.dim0_shard, 2), dtype=np.uint64)
         check(lib().spiral_gpu_server_read_db_slots(self.h, z_begin, nz, _p(out)))
+        return out
+
+    def read_db_columns(self, ii_begin: int, n_ii: int = 1) -> np.ndarray:
+        """all 2048 slots of the plaintext columns ii_begin .. ii_begin + n_ii - 1: [2048][n_ii][n2][j][n0] packed words"""
+        out = np.zeros((N, n_ii, 2, self.dim0_shard, 2), dtype=np.uint64)
+        check(lib().spiral_gpu_server_read_db_columns(self.h, ii_begin, n_ii, _p(out)))
         return out
 
     def fill_db_random(self, seed: int):

@@ -48,12 +48,19 @@ def sha(a):
 
 
 def host_gib_available():
-    import psutil
+    for line in open("/proc/meminfo"):
+        if line.startswith("MemAvailable:"):
+            return int(line.split()[1]) / 2**20
+    return 0.0
 
-    return psutil.virtual_memory().available / 2**30
+
+def record(request, line):
+    """print, and keep for the terminal summary (tests/conftest.py) so that the line survives `pytest -q`"""
+    print(line)
+    request.config._spiral_evidence.append(line)
 
 
-def test_config2_every_stage_bit_exact(sa, oracle_mt):
+def test_config2_every_stage_bit_exact(sa, oracle_mt, request):
     """configs[1] (= configs[0]'s geometry): the whole path at 2^20 x 256 B against the oracle, stage by stage"""
     M = oracle_mt
     from spiral_amd import server as SV
@@ -71,7 +78,7 @@ def test_config2_every_stage_bit_exact(sa, oracle_mt):
     raw = M.from_ntt(acc)
     fin = M.stage_fold(po, raw, gsw)
     resp = M.stage_rescale(po, fin)
-    print(f"config 2 oracle ({M.n_threads} threads): sha256 sweep output {sha(acc)} response {sha(resp)}")
+    record(request, f"config 2 oracle ({M.n_threads} threads): sha256 sweep output {sha(acc)} response {sha(resp)}")
 
     srv = sa.Server(pg)
     srv.keep_cts(True)
@@ -93,7 +100,7 @@ def test_config2_every_stage_bit_exact(sa, oracle_mt):
     srv.finish()
     got_resp = srv.read(SV.BUF_RESPONSE)
     assert_eq(got_resp, resp, "response")
-    print(f"config 2 device: sha256 sweep output {sha(got_acc)} response {sha(got_resp)}")
+    record(request, f"config 2 device: sha256 sweep output {sha(got_acc)} response {sha(got_resp)} (all 24 MiB of accumulators, every stage buffer, answer(), run_query graph: bit-exact)")
     assert_eq(cl.decode(got_resp), M.db_item(po, 1234, idx), "decoded plaintext")
 
     # answer() in one call, and the whole query replayed as one hipGraph, for other indices too
@@ -130,7 +137,7 @@ def test_config2_every_stage_bit_exact(sa, oracle_mt):
     srv.close()
 
 
-def sampled_checks(sa, M, po, pg, seed, idx, cl, label, n_slots=6, n_items=12):
+def sampled_checks(sa, M, po, pg, seed, idx, cl, label, request, n_slots=6, n_items=12):
     """the size-independent checks for a database too large for a host-side reference: see the module docstring"""
     from spiral_amd import server as SV
 
@@ -161,25 +168,34 @@ def sampled_checks(sa, M, po, pg, seed, idx, cl, label, n_slots=6, n_items=12):
     slabs = np.concatenate([srv.read_db_slots(z, 1) for z in zs]).reshape(len(zs), -1)
     want = M.multiply_query_by_database_slots(re[zs], slabs, s.dim0, s.num_per)
     assert_eq(got_acc[..., zs], want, f"{label}: first-dimension accumulators on slots {zs}")
+    # slot-complete: the FULL output polynomials (all 2048 slots, so every z-tile of the sweep and every XCD the tile map
+    # deals them to) of the first, the last and one random plaintext column -- the device's database words of those columns
+    # (dim0 x 2 x 2 x 2048 each) read back, multiplyQueryByDatabase (src/spiral.cpp:628-999) restated on them
+    cols = sorted({0, s.num_per - 1, int(rng.integers(1, max(2, s.num_per - 1)))})
+    for ii in cols:
+        sub = srv.read_db_columns(ii, 1)  # load_db's layout with num_per = 1
+        want_ii = M.multiply_query_by_database(re, sub, s.dim0, 1)
+        assert_eq(got_acc[ii:ii + 1], want_ii, f"{label}: all 2048 slots of output ciphertext {ii}")
+    record(request, f"{label}: sweep slot-complete on output ciphertexts {cols} (all 2048 slots x 6 polynomials each), on slots {zs} for all {s.num_per} ciphertexts; sha256 of those columns {sha(got_acc[cols])}")
     # and everything after the sweep from the device's full accumulators
     raw = M.from_ntt(got_acc)
     want_fin = M.stage_fold(po, raw, gsw)
     assert_eq(fin, want_fin, f"{label}: folded ciphertext (from the device's accumulators)")
     assert_eq(resp, M.stage_rescale(po, want_fin), f"{label}: response")
     gbps = srv.sweep_bytes() / us["sweep_kernel_us"] / 1e3
-    print(f"{label}: stage us {({k: round(x) for k, x in us.items()})}, sweep {gbps:.0f} GB/s of algorithmic bytes = {gbps / 80:.1f} % of the 8 TB/s HBM peak")
+    record(request, f"{label}: stage us {({k: round(x) for k, x in us.items()})}, sweep {gbps:.0f} GB/s of algorithmic bytes = {gbps / 80:.1f} % of the 8 TB/s HBM peak")
     srv.close()
 
 
-def test_config3_geometry_sampled_slots(sa, oracle_mt):
+def test_config3_geometry_sampled_slots(sa, oracle_mt, request):
     """configs[2]'s geometry on one MI355X: 2^24 x 256 B, nu1=9, nu2=10, t_GSW=10, q'=2^22, 32 GiB"""
     M = oracle_mt
     kw = dict(t_gsw=10, t_conv=4, t_exp=8, t_exp_right=56, qprime_bits=22, p_db=256)
     po, pg = M.make_params(9, 10, **kw), sa.make_params(9, 10, **kw)
-    sampled_checks(sa, M, po, pg, 99, 424242 % (1 << 19), M.Client(po, seed=6), "config 3 geometry (32 GiB)")
+    sampled_checks(sa, M, po, pg, 99, 424242 % (1 << 19), M.Client(po, seed=6), "config 3 geometry (32 GiB)", request)
 
 
-def test_configs3_spiralstream_2_20_x_100KB(sa, oracle_mt):
+def test_configs3_spiralstream_2_20_x_100KB(sa, oracle_mt, request):
     """configs[3]: SpiralStream (--direct-upload), 2^20 x 100 KB -- the published "Streaming 20/spiralstream" set
     (all_parameter_choices.txt:1149-1163: nu1=11, nu2=9, p=32768, q'=27 bits, t_GSW=4, t_conv=56, t_exp=2; direct upload =
     QNUMFIRST 2^nu1, QNUMREST t_GSW*nu2, src/spiral.cpp:2060-2061): 2048 + 36 uploaded ciphertexts, no expansion, one
@@ -189,10 +205,10 @@ def test_configs3_spiralstream_2_20_x_100KB(sa, oracle_mt):
     po, pg = M.make_params(11, 9, **kw), sa.make_params(11, 9, **kw)
     s = M.shape_of(po)
     assert (s.n_query_cts, s.dim0, s.num_per) == (2048 + 36, 2048, 512)
-    sampled_checks(sa, M, po, pg, 777, 31337 % (1 << 20), M.Client(po, seed=4), "configs[3] SpiralStream 2^20 x 100KB (64 GiB)", n_slots=4, n_items=8)
+    sampled_checks(sa, M, po, pg, 777, 31337 % (1 << 20), M.Client(po, seed=4), "configs[3] SpiralStream 2^20 x 100KB (64 GiB)", request, n_slots=4, n_items=8)
 
 
-def test_config5_pack_bit_exact(sa, oracle_mt):
+def test_config5_pack_bit_exact(sa, oracle_mt, request):
     """configs[4]: SpiralPack 2^18 x 30 KB (all_parameter_choices.txt:610-624: nu1=10, nu2=8, n=4, p=256, q'=2^20, t_GSW=8,
     t_conv=4, t_exp=16), 16 trial databases of 4 GiB"""
     M = oracle_mt
@@ -214,17 +230,24 @@ def test_config5_pack_bit_exact(sa, oracle_mt):
     cv[0] = q.reshape(2, 2, N)
     cv = M.expand_improved(cv, s.g, po.t_exp, wl, po.t_exp_right, wr, s.n_right, s.ell * po.nu2, s.stopround)
     re = M.reorient_dim1(cv, s.dim0, 2)
-    db0 = M.pack_gen_db_trial(po, out_n, seed, 0)
-    assert_eq(srv.read_acc(0), M.sweep_dim1(db0, re, s.dim0, s.num_per), "config 5, trial 0: first-dimension accumulators")
-    del db0
-    if host_gib_available() > 160:  # all 16 trials (64 GiB of reference-layout database on the host)
+    # a fixed subset of the trials, whatever the box's memory: each trial's FULL sweep output (all slots, all ciphertexts)
+    # against the oracle's sweep of that trial's 4 GiB database, one database on the host at a time
+    shas = []
+    for t in (0, 7, 15):
+        db_t = M.pack_gen_db_trial(po, out_n, seed, t)
+        got_t = srv.read_acc(t)
+        assert_eq(got_t, M.sweep_dim1(db_t, re, s.dim0, s.num_per), f"config 5, trial {t}: first-dimension accumulators")
+        shas.append(f"{t}:{sha(got_t)}")
+        del db_t
+    record(request, f"config 5: first-dimension accumulators of trials 0, 7, 15 bit-exact in full (sha256 {' '.join(shas)})")
+    if host_gib_available() > 160:  # all 16 trials at once (64 GiB of reference-layout database on the host): packed ciphertext + response
         db = np.empty((s.trials, s.dim0 * s.num_per * N), dtype=np.uint64)
         for t in range(s.trials):
             db[t] = M.pack_gen_db_trial(po, out_n, seed, t)
         want_resp, want_packed = M.pack_answer(po, out_n, q, wl, wr, v, vw, db)
         assert_eq(packed, want_packed, "config 5: packed ciphertext")
         assert_eq(resp, want_resp, "config 5: response")
-        print(f"config 5: packed ciphertext and response bit-exact over all {s.trials} trials; sha256 response {sha(resp)}")
+        record(request, f"config 5: all-trials: yes -- packed ciphertext and response bit-exact over all {s.trials} trials; sha256 response {sha(resp)}")
     else:
-        print("config 5: < 160 GiB of host memory available, the all-trials comparison was skipped (trial 0 compared)")
+        record(request, f"config 5: all-trials: no ({host_gib_available():.0f} GiB of host memory available, 160 needed); trials 0, 7, 15 compared in full, response decodes")
     srv.close()
