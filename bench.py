@@ -52,6 +52,19 @@ def cpu_model():
     return "unknown"
 
 
+def cpu_quota_cores():
+    """CPUs this process may actually use: the cgroup quota (cpu.max) when there is one, else the affinity mask.  A GPU box reports
+    256 logical CPUs but a 1-GPU slice of it is capped (16 CPUs on this pool): threads beyond the cap only time-slice."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(params_kw, np, workload):
     """the oracle (CPU restatement of the reference's algorithm, kind "port") timed on this box's host cores on ONE full
     query of the same workload, twice: on 1 thread -- the reference is single-threaded (src/spiral.cpp:1231, no -fopenmp in
@@ -83,32 +96,53 @@ def cpu_baseline(params_kw, np, workload):
     w, v = mk((3, 2 * po.t_conv)), mk((3, 2 * po.t_conv))
     q = mk((s.n_query_cts, 2))
 
-    def timed(threads):
-        got = O.set_threads(threads)
-        t0 = time.perf_counter()
-        O.answer(po, q, wl, wr, w, v, db)
-        return got, (time.perf_counter() - t0) * 1e3
+    sweep_bytes = O.db_words(po) * 8  # the NTT-form database the loop streams, 8 B per word as SURVEY.md 8d counts it
 
-    _, ms1 = timed(1)
+    def timed(threads, reps=1):
+        """best of `reps` passes of the four stages (expansion, conversion, first dimension = reorient + sweep + lift, folding):
+        (threads, total ms, first-dimension ms, sweep-loop ms)"""
+        got, best = O.set_threads(threads), None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            cv = O.stage_expand(po, q, wl, wr)
+            cts, gsw = O.stage_convert(po, cv, w, v)
+            t1 = time.perf_counter()
+            re = O.reorient_ciphertexts(cts)
+            t2 = time.perf_counter()
+            acc = O.multiply_query_by_database(re, db, s.dim0, s.num_per)
+            t3 = time.perf_counter()
+            raw = O.from_ntt(acc)
+            t4 = time.perf_counter()
+            O.stage_rescale(po, O.stage_fold(po, raw, gsw))
+            t5 = time.perf_counter()
+            cur = ((t5 - t0) * 1e3, (t4 - t1) * 1e3, (t3 - t2) * 1e3)
+            if best is None or cur[0] < best[0]:
+                best = cur
+        return (got,) + best
+
+    _, ms1, fd1, sw1 = timed(1)
     out = {"value": round(ms1, 1), "unit": "ms/query", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
+           "first_dim_ms": round(fd1, 1), "sweep_loop_ms": round(sw1, 1), "sweep_gbps": round(sweep_bytes / sw1 / 1e6, 2), "sweep_isa": O.sweep_isa(),
            "build": "gcc -O3 -march=native -fopenmp on this box" if native else "prebuilt gcc -O3 -march=x86-64-v3",
-           "sample": f"1 full query of {workload} ({O.db_words(po) * 8 / 2**30:.0f} GiB NTT-form database of arbitrary valid words), oracle/ restatement"}
+           "sample": f"1 full query of {workload} ({O.db_words(po) * 8 / 2**30:.0f} GiB NTT-form database of arbitrary valid words), oracle/ restatement; "
+                     "the first-dimension loop is the reference's vectorised form (src/spiral.cpp:640-886, _mm512_mul_epu32 / _mm256_mul_epu32, partial "
+                     "reduction every 64 terms); sweep_gbps = NTT-form database bytes / sweep_loop_ms, comparable with roofline.achieved"}
     if native:
-        # all cores: this restatement (per-call scratch allocation like the reference's MatPoly, many small parallel regions)
-        # stops scaling well before a 2 x 64-core box is full, so the thread count is swept and the best one reported
-        ncpu = os.cpu_count() or 1
-        O.set_threads(min(ncpu, 16))
+        # all cores: a thread ladder, best of two passes each (the second is warm), the best count reported
+        ncpu, quota = os.cpu_count() or 1, cpu_quota_cores()
+        O.set_threads(min(quota, 16))
         db = O.fill_db_random(99, O.db_words(po))  # first touch spread over the threads' NUMA nodes
-        timed(min(ncpu, 16))  # thread pool start-up
         ladder, best = {}, None
-        for th in sorted({t for t in (8, 16, 32, 64, 128, ncpu) if t <= ncpu}):
-            got, ms = timed(th)
+        for th in sorted({t for t in (8, 16, 32, 64, 128, quota, 2 * quota) if t <= min(ncpu, 2 * quota)}):
+            got, ms, fd, sw = timed(th, reps=2)
             ladder[str(got)] = round(ms, 1)
             if best is None or ms < best[1]:
-                best = (got, ms)
+                best = (got, ms, fd, sw)
             elif ms > 3 * best[1]:
                 break
-        out["all_cores"] = {"value": round(best[1], 1), "unit": "ms/query", "cores": best[0], "logical_cpus": ncpu, "ms_by_threads": ladder}
+        out["all_cores"] = {"value": round(best[1], 1), "unit": "ms/query", "cores": best[0], "logical_cpus": ncpu, "usable_cpus": quota, "first_dim_ms": round(best[2], 1),
+                            "sweep_loop_ms": round(best[3], 1), "sweep_gbps": round(sweep_bytes / best[3] / 1e6, 2), "ms_by_threads": ladder,
+                            "note": "usable_cpus = the cgroup CPU quota of this box (cpu.max) or the affinity mask: the thread ladder stops at twice that"}
     shutil.rmtree(d, ignore_errors=True)
     return out
 

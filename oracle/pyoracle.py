@@ -253,6 +253,19 @@ def multiply_query_by_database(reoriented, db, dim0, num_per):
     return out
 
 
+def multiply_query_by_database_scalar(reoriented, db, dim0, num_per):
+    """the scalar cell only (the default entry point uses the reference's AVX-512 / AVX2 form where the build has it)"""
+    out = u64(num_per, 3, 2, 2, N)
+    lib().orc_multiply_query_by_database_scalar(_p(out), _p(reoriented), _p(db), C.c_size_t(dim0), C.c_size_t(num_per))
+    return out
+
+
+def sweep_isa():
+    f = lib().orc_sweep_isa
+    f.restype = C.c_char_p
+    return f().decode()
+
+
 def multiply_query_by_database_slots(reoriented_slabs, db_slabs, dim0, num_per):
     """the sweep on a subset of NTT slots: reoriented_slabs [nz][dim0][2][4], db_slabs [nz][num_per*2*dim0*2] -> [num_per][3][2][2][nz]"""
     nz = reoriented_slabs.shape[0]

@@ -1,6 +1,7 @@
 /*
  * spiral_oracle.c -- CPU restatement of the Spiral server-answer path.  TEST INFRASTRUCTURE ONLY.
- * See spiral_oracle.h for the pinning statement.  Scalar C, no SIMD; semantics are the reference's
+ * See spiral_oracle.h for the pinning statement.  Scalar C (one exception: the first-dimension cell also exists in the
+ * reference's AVX-512 / AVX2 form, proven equal to the scalar one by tests/test_oracle.py); semantics are the reference's
  * scalar paths ("mathematical sum mod m", SURVEY.md section 8c hazard 4).  All NTT-domain outputs are
  * canonical residues in [0,m) (the reference's AVX2 tail may leave m instead of 0,
  * src/core.cpp:308,342,347 -- compare NTT-domain buffers mod m).
@@ -462,8 +463,104 @@ void orc_multiply_query_by_database_slots(uint64_t *out, const uint64_t *cts, co
                                           uint32_t nz) {
     sweep_slabs(out, cts, db, dim0, num_per, nz, nz);
 }
-static void sweep_slabs(uint64_t *out, const uint64_t *cts, const uint64_t *db, size_t dim0, size_t num_per, uint32_t nz, size_t N_out) {
-    const size_t NTTP_out = 2 * N_out;
+/* one (z, i, c) cell: the six sums over jm < 2 dim0 of a[jm][r] * b[jm], per CRT limb, reduced.  Scalar form (:932-998). */
+static inline void sweep_cell_scalar(const uint64_t *a, const uint64_t *b, size_t jm_total, uint64_t s0_out[3], uint64_t s1_out[3]) {
+    u128 s0[3] = {0, 0, 0}, s1[3] = {0, 0, 0};
+    for (size_t jm = 0; jm < jm_total; jm++) {
+        uint64_t bw = b[jm], blo = (uint32_t)bw, bhi = bw >> 32;
+        for (uint32_t r = 0; r < 3; r++) {
+            uint64_t aw = a[jm * 4 + r];
+            s0[r] += (uint64_t)(uint32_t)aw * blo;
+            s1[r] += (aw >> 32) * bhi;
+        }
+    }
+    for (uint32_t r = 0; r < 3; r++) {
+        s0_out[r] = (uint64_t)(s0[r] % ORC_P);
+        s1_out[r] = (uint64_t)(s1[r] % ORC_B);
+    }
+}
+/* The reference's vectorised forms of the same cell, so that the CPU baseline bench.py times is the loop the reference
+ * runs on such a host rather than gcc's reading of the scalar one: AVX-512 src/spiral.cpp:640-745 (two jm per 512-bit
+ * vector: lanes 0..3 = rows of jm, 4..7 = rows of jm + 1, _mm512_mul_epu32 on the low and on the shifted-down high halves,
+ * a partial reduction every max_summed_pa_or_b_in_u64 = 64 terms, include/values.h:56), AVX2 :746-886 (one jm per 256-bit
+ * vector).  Operands must be reduced residues (< 2^28 here), as the reference's are.  tests/test_oracle.py proves these
+ * equal to the scalar cell, extremes included. */
+#if defined(__AVX512F__)
+#include <immintrin.h>
+#define ORC_SWEEP_ISA "avx512"
+static inline void sweep_cell_simd(const uint64_t *a, const uint64_t *b, size_t jm_total, uint64_t s0_out[3], uint64_t s1_out[3]) {
+    size_t inner = 64, outer = jm_total / inner;
+    if (jm_total < 64) {
+        inner = jm_total;
+        outer = 1;
+    }
+    uint64_t acc0[3] = {0, 0, 0}, acc1[3] = {0, 0, 0};
+    for (size_t o = 0; o < outer; o++) {
+        __m512i n0 = _mm512_setzero_si512(), n2 = _mm512_setzero_si512();
+#pragma GCC unroll 16
+        for (size_t k = 0; k < inner / 2; k++) {
+            const size_t jm = o * inner + 2 * k;
+            const __m512i bv = _mm512_mask_blend_epi64(0xF0, _mm512_set1_epi64((long long)b[jm]), _mm512_set1_epi64((long long)b[jm + 1]));
+            const __m512i av = _mm512_loadu_si512((const void *)(a + jm * 4));
+            n0 = _mm512_add_epi64(n0, _mm512_mul_epu32(av, bv));
+            n2 = _mm512_add_epi64(n2, _mm512_mul_epu32(_mm512_srli_epi64(av, 32), _mm512_srli_epi64(bv, 32)));
+        }
+        uint64_t t0[8], t2[8];
+        _mm512_storeu_si512((void *)t0, n0);
+        _mm512_storeu_si512((void *)t2, n2);
+        for (int r = 0; r < 3; r++) {
+            acc0[r] = (acc0[r] + t0[r] + t0[4 + r]) % ORC_P;
+            acc1[r] = (acc1[r] + t2[r] + t2[4 + r]) % ORC_B;
+        }
+    }
+    for (int r = 0; r < 3; r++) {
+        s0_out[r] = acc0[r];
+        s1_out[r] = acc1[r];
+    }
+}
+#elif defined(__AVX2__)
+#include <immintrin.h>
+#define ORC_SWEEP_ISA "avx2"
+static inline void sweep_cell_simd(const uint64_t *a, const uint64_t *b, size_t jm_total, uint64_t s0_out[3], uint64_t s1_out[3]) {
+    size_t inner = 64, outer = jm_total / inner;
+    if (jm_total < 64) {
+        inner = jm_total;
+        outer = 1;
+    }
+    uint64_t acc0[3] = {0, 0, 0}, acc1[3] = {0, 0, 0};
+    for (size_t o = 0; o < outer; o++) {
+        __m256i n0 = _mm256_setzero_si256(), n2 = _mm256_setzero_si256();
+#pragma GCC unroll 16
+        for (size_t k = 0; k < inner; k++) {
+            const size_t jm = o * inner + k;
+            const __m256i bv = _mm256_set1_epi64x((long long)b[jm]);
+            const __m256i av = _mm256_loadu_si256((const __m256i *)(a + jm * 4));
+            n0 = _mm256_add_epi64(n0, _mm256_mul_epu32(av, bv));
+            n2 = _mm256_add_epi64(n2, _mm256_mul_epu32(_mm256_srli_epi64(av, 32), _mm256_srli_epi64(bv, 32)));
+        }
+        uint64_t t0[4], t2[4];
+        _mm256_storeu_si256((__m256i *)t0, n0);
+        _mm256_storeu_si256((__m256i *)t2, n2);
+        for (int r = 0; r < 3; r++) {
+            acc0[r] = (acc0[r] + t0[r]) % ORC_P;
+            acc1[r] = (acc1[r] + t2[r]) % ORC_B;
+        }
+    }
+    for (int r = 0; r < 3; r++) {
+        s0_out[r] = acc0[r];
+        s1_out[r] = acc1[r];
+    }
+}
+#else
+#define ORC_SWEEP_ISA "scalar"
+#define sweep_cell_simd sweep_cell_scalar
+#endif
+const char *orc_sweep_isa(void) { return ORC_SWEEP_ISA; }
+
+static void sweep_slabs_impl(uint64_t *out, const uint64_t *cts, const uint64_t *db, size_t dim0, size_t num_per, uint32_t nz, size_t N_out, int scalar) {
+    const size_t NTTP_out = 2 * N_out, jm_total = dim0 * 2;
+    /* the vector cells step through jm in blocks of 64 (2 for the AVX-512 pairing): other lengths take the scalar cell */
+    const int simd_ok = !scalar && (jm_total % 64 == 0 || (jm_total < 64 && jm_total % 2 == 0));
 #pragma omp parallel for if (g_threads > 1)
     for (uint32_t z = 0; z < nz; z++) {
         const uint64_t *a = cts + (size_t)z * (dim0 * 2 * 4);
@@ -471,22 +568,25 @@ static void sweep_slabs(uint64_t *out, const uint64_t *cts, const uint64_t *db, 
         for (size_t i = 0; i < num_per; i++)
             for (uint32_t c = 0; c < N2; c++) {
                 const uint64_t *b = bz + (i * N2 + c) * (dim0 * N0);
-                u128 s0[3] = {0, 0, 0}, s1[3] = {0, 0, 0};
-                for (size_t jm = 0; jm < dim0 * 2; jm++) {
-                    uint64_t bw = b[jm], blo = (uint32_t)bw, bhi = bw >> 32;
-                    for (uint32_t r = 0; r < 3; r++) {
-                        uint64_t aw = a[jm * 4 + r];
-                        s0[r] += (uint64_t)(uint32_t)aw * blo;
-                        s1[r] += (aw >> 32) * bhi;
-                    }
-                }
+                uint64_t s0[3], s1[3];
+                if (simd_ok)
+                    sweep_cell_simd(a, b, jm_total, s0, s1);
+                else
+                    sweep_cell_scalar(a, b, jm_total, s0, s1);
                 for (uint32_t r = 0; r < 3; r++) {
                     uint64_t *o = out + ((i * N1 + r) * N2 + c) * NTTP_out;
-                    o[z] = (uint64_t)(s0[r] % ORC_P);
-                    o[N_out + z] = (uint64_t)(s1[r] % ORC_B);
+                    o[z] = s0[r];
+                    o[N_out + z] = s1[r];
                 }
             }
     }
+}
+static void sweep_slabs(uint64_t *out, const uint64_t *cts, const uint64_t *db, size_t dim0, size_t num_per, uint32_t nz, size_t N_out) {
+    sweep_slabs_impl(out, cts, db, dim0, num_per, nz, N_out, 0);
+}
+/* the scalar cell only (tests: the vectorised cells against it) */
+void orc_multiply_query_by_database_scalar(uint64_t *out, const uint64_t *cts, const uint64_t *db, size_t dim0, size_t num_per) {
+    sweep_slabs_impl(out, cts, db, dim0, num_per, N, N, 1);
 }
 
 /* src/spiral.cpp:464-582: Cn[i][r][c][n][z] = (sum_m Q[z][r][m].n * C[z][i][c][m].n) mod m_n, u64 sums */

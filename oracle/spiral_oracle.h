@@ -149,6 +149,9 @@ void orc_encode_item(const orc_params *p, const uint64_t *pt, uint64_t *enc /* [
 /* the sweep on nz chosen NTT slots only: cts / db hold those slots' slabs, out is [num_per][n1][n2][2][nz] */
 void orc_multiply_query_by_database_slots(uint64_t *out, const uint64_t *reoriented_cts, const uint64_t *db, size_t dim0,
                                           size_t num_per, uint32_t nz);
+/* the scalar cell only, and which vector form this build's orc_multiply_query_by_database uses ("avx512" | "avx2" | "scalar") */
+void orc_multiply_query_by_database_scalar(uint64_t *out, const uint64_t *cts, const uint64_t *db, size_t dim0, size_t num_per);
+const char *orc_sweep_isa(void);
 /* threads for the `native` (-fopenmp) build used by bench.py's all-cores CPU baseline; a no-op returning 1 otherwise */
 int orc_set_threads(int n);
 void orc_db_item(const orc_params *p, uint64_t seed, uint64_t item, uint64_t *pt /* raw [2][2][N] */);

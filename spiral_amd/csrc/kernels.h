@@ -106,8 +106,6 @@ struct InvParams {
     uint32_t src_ref;     // 1: source is reference layout [2][N] u64 instead of PK
     uint32_t split;       // > 0: blocks b >= split take their source from src_map2(b - split) (two source regions, one launch)
     IndexMap src_map2;
-    uint32_t n_parts;     // > 1: the source polynomial is the sum of n_parts PK partial sums, part_stride polynomials apart (fold_fused_kernel's output)
-    uint32_t part_stride;
     // expansion round (launch_ntt_inverse_expand): block b = (active ct a, row); a < cnt_e -> i = 2a, else
     // i = 2(a - cnt_e) + 1; a ct with i >= num_in is first created as neg1 * cv[i - num_in] (src/spiral.cpp:1709)
     // Row 0 is transformed to dst[2a]; row 1 is not: its automorphed image, a slot permutation, goes to dst[2a + 1] in PK.
@@ -132,29 +130,11 @@ struct FoldChainParams {
     uint32_t pre_reduce;  // 1: fields are lazy sums (< 2^32), reduce mod m first
     uint32_t dpb;         // digits per block, 1 .. ell
     uint32_t lazy_out;    // 1: digit transforms left in [0, 2m) (the product kernel sums 6 * ell < 128 terms of < 2^57)
-    uint32_t src_parts, src_part_stride;  // > 1: a source polynomial is the sum of that many partial sums (a fused round's output), stride in polynomials
     // SpiralPack fold (foldCiphertextsDim1): sources are [trial][2*np][2] 2 x 1 ciphertexts with a trial stride of src_stride
     // ciphertexts, unsigned digits, operand layout as LD_PDIGIT / PM_FOLD
     uint32_t pack, src_stride;
 };
 void launch_fold_chain(const DeviceTables& t, const FoldChainParams& p, uint32_t n_src, hipStream_t s);
-
-// One whole folding round in one kernel (ntt.hip fold_fused_kernel): foldOneFurtherDimension's lift, balanced digits, forward
-// transforms AND the product with the round's key (src/spiral.cpp:1349-1410), so the digit polynomials -- 2*m2 per output
-// ciphertext, 96 MiB in round 0 of config 2 -- never exist in memory.  A workgroup takes one source polynomial (ct i' < 2 np',
-// row r, column c) and `dpb` of its digits, accumulates key[r'][mm] * NTT(digit) for the three output rows r' in registers and
-// writes its three partial sums; the 6 * ceil(ell / dpb) partial sums of an output polynomial (2 halves x 3 rows x chunks)
-// are added by whoever reads it next: the next round's loader, or the final lift (InvParams::n_parts).
-struct FoldFusedParams {
-    const uint64_t* src;   // PK partial sums of the 2*np' source cts: part q, polynomial s at src + (q * src_part_stride + s) * N
-    uint32_t src_parts;    // partial sums to add on load (1: plain PK polynomials, e.g. the sweep's accumulators)
-    uint32_t src_part_stride;  // in polynomials
-    const uint64_t* key;   // [3][2*m2] PK: [Q_neg | Q] of this round's dimension
-    uint64_t* dst;         // partial sums out: part q = (half * 3 + r) * cpp + chunk, polynomial (q * np' + i) * 6 + r' * 2 + c
-    uint32_t ell, bits, fold_np, pre_reduce, dpb;
-};
-inline uint32_t fold_fused_parts(uint32_t ell, uint32_t dpb) { return 6u * ((ell + dpb - 1u) / dpb); }
-void launch_fold_fused(const DeviceTables& t, const FoldFusedParams& p, hipStream_t s);
 
 // ---- layout conversion at the C-ABI boundary -------------------------------------------------------
 // reference polynomial b <-> packed polynomial pk_map(b)

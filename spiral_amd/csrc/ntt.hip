@@ -98,45 +98,23 @@ __device__ __forceinline__ void sdigit_of(uint64_t v, const SDigit& d, uint32_t&
     }
 }
 
-// a thread's 8 slots of the PK polynomial that is the sum of n_parts partial sums `stride` polynomials apart (fields < m
-// each); reduce: also when n_parts == 1 the fields may be lazy sums (< 2^32).  Returns canonical residues.
-__device__ __forceinline__ void pk_load8_sum(const uint64_t* first, uint32_t n_parts, size_t stride, bool reduce, uint32_t tid, uint32_t* lo, uint32_t* hi) {
+// a thread's 8 slots of a PK polynomial as residues; reduce: the fields may be lazy sums (< 2^32: the output of a reduce over
+// ranks), otherwise they are canonical already
+__device__ __forceinline__ void pk_load8_red(const uint64_t* poly, bool reduce, uint32_t tid, uint32_t* lo, uint32_t* hi) {
     uint64_t x[8];
-    pk_load8(first, tid, x);
-    if (n_parts <= 1) {
-        pk_unpack8(x, lo, hi);
-        if (reduce) {
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                lo[r] %= kP;
-                hi[r] %= kB;
-            }
-        }
-        return;
-    }
-    uint64_t sl[8], sh[8];
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        sl[r] = lo32(x[r]);
-        sh[r] = hi32(x[r]);
-    }
-    for (uint32_t q = 1; q < n_parts; q++) {
-        pk_load8(first + (size_t)q * stride * kN, tid, x);
+    pk_load8(poly, tid, x);
+    pk_unpack8(x, lo, hi);
+    if (reduce) {
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            sl[r] += lo32(x[r]);
-            sh[r] += hi32(x[r]);
+            lo[r] %= kP;
+            hi[r] %= kB;
         }
-    }
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        lo[r] = mod_p(sl[r]);
-        hi[r] = mod_b(sh[r]);
     }
 }
 
 template <uint32_t LOAD, uint32_t STORE>
-__global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p) {
+__global__ __launch_bounds__(256, 8) void ntt_forward_kernel(Tables t, FwdParams p) {
     __shared__ uint64_t sh[kLdsWords];
     const uint32_t tid = threadIdx.x, b = blockIdx.x;
     uint32_t s = b / p.n_digits, k = b - s * p.n_digits;
@@ -198,10 +176,13 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
         }
         const uint64_t* src = p.src + (size_t)sp * kN;
         const uint64_t mask = (1ull << p.bits) - 1;
+        uint64_t raw[8];  // all eight requested before the digit-width branch (inside it, the compiler waits for the first alone)
+#pragma unroll
+        for (int r = 0; r < 8; r++) raw[r] = src[ix_a(tid, r)];
         auto body = [&](auto small) {
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                uint32_t d = (uint32_t)digit_of(src[ix_a(tid, r)], k, p.bits, mask);
+                uint32_t d = (uint32_t)digit_of(raw[r], k, p.bits, mask);
                 lo[r] = digit_residue<decltype(small)::value>(d, kP);
                 hi[r] = digit_residue<decltype(small)::value>(d, kB);
             }
@@ -223,12 +204,15 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
             a += p.cnt_e;
         }
         const uint64_t* src = p.src + (size_t)a * 2u * kN;
+        uint64_t raw[8];  // requested before anything else is computed (see LD_PDIGIT)
+#pragma unroll
+        for (int r = 0; r < 8; r++) raw[r] = src[ix_a(tid, r)];
         const uint32_t bits = get_bits_per(tdim);
         const uint64_t mask = (1ull << bits) - 1;
         auto body = [&](auto small) {
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                const uint32_t d = (uint32_t)digit_of(src[ix_a(tid, r)], k, bits, mask);  // already automorphed by the inverse pass
+                const uint32_t d = (uint32_t)digit_of(raw[r], k, bits, mask);  // already automorphed by the inverse pass
                 lo[r] = digit_residue<decltype(small)::value>(d, kP);
                 hi[r] = digit_residue<decltype(small)::value>(d, kB);
             }
@@ -246,13 +230,15 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
     } else {
         const uint64_t* src = p.src + (size_t)p.src_map(s) * kN;
         const uint64_t mask = (1ull << p.bits) - 1;
+        uint64_t raw[8];  // requested before anything else is computed (see LD_PDIGIT)
+#pragma unroll
+        for (int r = 0; r < 8; r++) raw[r] = load_raw(src, ix_a(tid, r), p.tinv);
         SDigit sd{};
         if constexpr (LOAD == LD_SDIGIT) sd = sdigit_setup(k, p.bits, p.ell);
         auto body = [&](auto small) {
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                uint32_t idx = ix_a(tid, r);
-                uint64_t v = load_raw(src, idx, p.tinv);
+                uint64_t v = raw[r];
                 if constexpr (LOAD == LD_RAW) {
                     lo[r] = mod_p(v);
                     hi[r] = mod_b(v);
@@ -330,8 +316,9 @@ __global__ __launch_bounds__(256) void ntt_forward_kernel(Tables t, FwdParams p)
     }
 }
 
+// (8 workgroups per CU: the second launch bound keeps the kernel at 64 VGPRs, where the compiler's own choice was 65)
 template <uint32_t STORE, bool EXPAND = false>
-__global__ __launch_bounds__(256) void ntt_inverse_kernel(Tables t, InvParams p) {
+__global__ __launch_bounds__(256, 8) void ntt_inverse_kernel(Tables t, InvParams p) {
     __shared__ uint64_t sh[kLdsWords];
     const uint32_t tid = threadIdx.x, b = blockIdx.x;
     uint32_t lo[8], hi[8];
@@ -398,7 +385,7 @@ __global__ __launch_bounds__(256) void ntt_inverse_kernel(Tables t, InvParams p)
         }
     } else {
         const uint32_t sp = (p.split && b >= p.split) ? p.src_map2(b - p.split) : p.src_map(b);
-        pk_load8_sum(p.src + (size_t)sp * kN, p.n_parts, p.part_stride, false, tid, lo, hi);
+        pk_load8_red(p.src + (size_t)sp * kN, false, tid, lo, hi);
     }
     if (p.pre_reduce) {
 #pragma unroll
@@ -448,6 +435,8 @@ __global__ __launch_bounds__(256) void ntt_inverse_kernel(Tables t, InvParams p)
 // dpb = ell: one workgroup per polynomial, no redundant work (rounds that fill the chip); dpb = 1: one workgroup per
 // (polynomial, digit), every digit job repeating the inverse transform (the last rounds, which are latency-bound); the host
 // picks dpb per round so that a round is about as many blocks as the chip holds.
+// (register budget: 103 VGPRs = 4 workgroups per CU.  Forcing 5 or 6 through the launch bound spills 24 / 84 bytes per thread and
+// measured 0 / +30 us on the fold, profiles/r03_variants.txt; holding one twiddle row set instead of two does not lower the count.)
 __global__ __launch_bounds__(256) void fold_chain_kernel(Tables t, FoldChainParams p) {
     __shared__ uint64_t sh[kLdsWords];
     const uint32_t tid = threadIdx.x, b = blockIdx.x;
@@ -458,7 +447,7 @@ __global__ __launch_bounds__(256) void fold_chain_kernel(Tables t, FoldChainPara
     const uint32_t per_t = 4u * p.fold_np, pt = s / per_t, prem = s - pt * per_t, pip = prem >> 1, prow = prem & 1u;
     {
         const size_t sp = p.pack ? ((size_t)pt * p.src_stride + pip) * 2u + prow : (size_t)s;
-        pk_load8_sum(p.src + sp * kN, p.src_parts, p.src_part_stride, p.pre_reduce != 0, tid, lo, hi);
+        pk_load8_red(p.src + sp * kN, p.pre_reduce != 0, tid, lo, hi);
     }
     ntt_inverse_block<false>(lo, hi, sh, t.inv, tid);
     uint64_t v[8];
@@ -493,65 +482,6 @@ __global__ __launch_bounds__(256) void fold_chain_kernel(Tables t, FoldChainPara
         pk_pack8(lo, hi, x);
         pk_store8(p.dst + di * kN, tid, x);
     }
-}
-
-// One folding round fused (kernels.h FoldFusedParams): lift + balanced digits + forward transforms as fold_chain_kernel, and
-// each digit's transform is multiplied into the three output rows straight from the registers it was computed in.
-__global__ __launch_bounds__(256, 3) void fold_fused_kernel(Tables t, FoldFusedParams p) {
-    __shared__ uint64_t sh[kLdsWords];
-    const uint32_t tid = threadIdx.x, b = blockIdx.x;
-    const uint32_t cpp = (p.ell + p.dpb - 1u) / p.dpb;  // chunks per polynomial
-    const uint32_t s = b / cpp, chunk = b - s * cpp, k0 = chunk * p.dpb, k1 = min(k0 + p.dpb, p.ell);
-    uint32_t lo[8], hi[8];
-    pk_load8_sum(p.src + (size_t)s * kN, p.src_parts, p.src_part_stride, p.pre_reduce != 0, tid, lo, hi);
-    ntt_inverse_block<false>(lo, hi, sh, t.inv, tid);
-    uint64_t v[8];
-    crt_lift8(lo, hi, v);
-    // source s = (ct i', row, c) over [2*np'][3][2]; its digit k is column mm = half * m2 + row + 3k of the key (as LD_SDIGIT's D)
-    const uint32_t ct = s / 6u, rc = s - ct * 6u, row = rc >> 1, c = rc & 1u;
-    const uint32_t m2 = 3u * p.ell, half = ct / p.fold_np, i = ct - half * p.fold_np;
-    uint64_t alo[3][8], ahi[3][8];
-#pragma unroll
-    for (int rr = 0; rr < 3; rr++)
-#pragma unroll
-        for (int r = 0; r < 8; r++) alo[rr][r] = ahi[rr][r] = 0;
-    for (uint32_t k = k0; k < k1; k++) {
-        const SDigit sd = sdigit_setup(k, p.bits, p.ell);
-        auto digits = [&](auto small) {
-#pragma unroll
-            for (int r = 0; r < 8; r++) sdigit_of<decltype(small)::value>(v[r], sd, lo[r], hi[r]);
-        };
-        DIGIT_WIDTH_DISPATCH(p.bits, digits);
-        const uint32_t mm = half * m2 + row + 3u * k;  // this digit's column of the key
-        if (k > k0) __syncthreads();  // the previous transform's last LDS reads
-        ntt_forward_block(lo, hi, sh, t.fwd, tid);
-        // (the key words are fetched a row at a time after the transform: 96 accumulator registers leave no room to hold
-        // them across it; the other resident workgroups cover the latency)
-#pragma unroll
-        for (int rr = 0; rr < 3; rr++) {
-            uint64_t kw[8];
-            pk_load8(p.key + ((size_t)rr * 2u * m2 + mm) * kN, tid, kw);
-#pragma unroll
-            for (int r = 0; r < 8; r++) {  // at most ell <= 28 products of < 2^56 per accumulator
-                alo[rr][r] += (uint64_t)lo32(kw[r]) * lo[r];
-                ahi[rr][r] += (uint64_t)hi32(kw[r]) * hi[r];
-            }
-        }
-    }
-    const uint32_t part = (half * 3u + row) * cpp + chunk;
-#pragma unroll
-    for (int rr = 0; rr < 3; rr++) {
-        uint64_t x[8];
-#pragma unroll
-        for (int r = 0; r < 8; r++) x[r] = pack(mod_p(alo[rr][r]), mod_b(ahi[rr][r]));
-        pk_store8(p.dst + (((size_t)part * p.fold_np + i) * 6u + (uint32_t)rr * 2u + c) * kN, tid, x);
-    }
-}
-void launch_fold_fused(const DeviceTables& t, const FoldFusedParams& p, hipStream_t s) {
-    const uint32_t n_src = 2u * p.fold_np * 6u, cpp = (p.ell + p.dpb - 1u) / p.dpb;
-    if (n_src == 0) return;
-    Tables tb{t.fwd, t.inv};
-    hipLaunchKernelGGL(fold_fused_kernel, dim3(n_src * cpp), dim3(256), 0, s, tb, p);
 }
 
 __global__ __launch_bounds__(256) void ref_to_pk_kernel(const uint64_t* ref, uint64_t* pk, IndexMap pk_map) {

@@ -229,6 +229,14 @@ __global__ __launch_bounds__(kTpb) void expand_mac_round_kernel(ExpandMacParams 
         nw = p.neg1n[z];
         nws = p.neg1ns[z];
     }
+    // so are the words the finishing wave adds to the product: requested now, they arrive under the MAC loop
+    uint64_t* c = p.cv + (size_t)i * 2 * kN + z;
+    uint64_t old0 = 0, old1 = 0, a1v = 0;
+    if (kg == 0) {
+        old0 = c[0];
+        old1 = c[kN];
+        a1v = p.a1[((size_t)a * 2u + 1u) * kN + z];
+    }
     Acc2 acc0, acc1;
 #pragma unroll 7
     for (uint32_t k = kg; k < tdim; k += 4) {
@@ -255,9 +263,8 @@ __global__ __launch_bounds__(kTpb) void expand_mac_round_kernel(ExpandMacParams 
             acc1.lo += sh[q][zz][2];
             acc1.hi += sh[q][zz][3];
         }
-        uint64_t* c = p.cv + (size_t)i * 2 * kN + z;
-        const uint64_t c0 = add_pk(c[0], acc0.reduced());
-        const uint64_t c1 = add_pk(add_pk(c[kN], acc1.reduced()), p.a1[((size_t)a * 2u + 1u) * kN + z]);
+        const uint64_t c0 = add_pk(old0, acc0.reduced());
+        const uint64_t c1 = add_pk(add_pk(old1, acc1.reduced()), a1v);
         c[0] = c0;
         c[kN] = c1;
         if (make_next) {
@@ -284,6 +291,13 @@ __global__ __launch_bounds__(kTpb) void expand_mac_round_wide_kernel(ExpandMacPa
         nw = *reinterpret_cast<const u64x2_t*>(p.neg1n + z);
         nws = *reinterpret_cast<const u64x2_t*>(p.neg1ns + z);
     }
+    uint64_t* c = p.cv + (size_t)i * 2 * kN + z;
+    u64x2_t old0 = {0, 0}, old1 = {0, 0}, a1v = {0, 0};
+    if (kg == 0) {  // the finishing wave's addends, in flight under the MAC loop
+        old0 = *reinterpret_cast<const u64x2_t*>(c);
+        old1 = *reinterpret_cast<const u64x2_t*>(c + kN);
+        a1v = *reinterpret_cast<const u64x2_t*>(p.a1 + ((size_t)a * 2u + 1u) * kN + z);
+    }
     Acc2 acc0[2], acc1[2];
 #pragma unroll 7
     for (uint32_t k = kg; k < tdim; k += 4) {
@@ -306,9 +320,6 @@ __global__ __launch_bounds__(kTpb) void expand_mac_round_wide_kernel(ExpandMacPa
     __syncthreads();
     if (kg == 0) {
         uint64_t c0[2], c1[2];
-        uint64_t* c = p.cv + (size_t)i * 2 * kN + z;
-        const u64x2_t old0 = *reinterpret_cast<const u64x2_t*>(c), old1 = *reinterpret_cast<const u64x2_t*>(c + kN);
-        const u64x2_t a1v = *reinterpret_cast<const u64x2_t*>(p.a1 + ((size_t)a * 2u + 1u) * kN + z);
 #pragma unroll
         for (int h = 0; h < 2; h++) {
 #pragma unroll
@@ -352,6 +363,23 @@ __global__ __launch_bounds__(kTpb) void expand_mac_round_batch_kernel(ExpandMacP
     const size_t gbase = odd ? (size_t)p.cnt_e * p.t_e + (size_t)(a0 - p.cnt_e) * p.t_o : (size_t)a0 * p.t_e;
     const uint64_t* w = (odd ? p.w_o : p.w_e) + z;
     const uint64_t* gp = p.g + gbase * kN + z;
+    // wave kg finishes ciphertext kg of the group (CT <= 4): what it adds to the product -- the old ciphertext, NTT(automorph(c_1)),
+    // the next round's neg1 words -- is requested now and arrives under the MAC loop
+    static_assert(CT <= 4, "one ciphertext per finishing wave");
+    const bool fin = kg < (uint32_t)CT && kg < n;
+    const uint32_t fa = a0 + kg, fi = p.act.index(fin ? fa : a0, p.cnt_e);
+    const bool make_next = fin && p.neg1n != nullptr && (!odd || (fi >> 1) + (p.next_num_in >> 1) < p.next_cnt_o);
+    uint64_t* cp = p.cv + (size_t)fi * 2 * kN + z;
+    u64x2_t old0 = {0, 0}, old1 = {0, 0}, a1v = {0, 0}, nw = {0, 0}, nws = {0, 0};
+    if (fin) {
+        old0 = *reinterpret_cast<const u64x2_t*>(cp);
+        old1 = *reinterpret_cast<const u64x2_t*>(cp + kN);
+        a1v = *reinterpret_cast<const u64x2_t*>(p.a1 + ((size_t)fa * 2u + 1u) * kN + z);
+    }
+    if (make_next) {
+        nw = *reinterpret_cast<const u64x2_t*>(p.neg1n + z);
+        nws = *reinterpret_cast<const u64x2_t*>(p.neg1ns + z);
+    }
     Acc2 acc[CT][2][2];  // [ciphertext][output row][slot of the pair]
 #pragma unroll 2
     for (uint32_t k = kg; k < tdim; k += 4) {
@@ -380,17 +408,8 @@ __global__ __launch_bounds__(kTpb) void expand_mac_round_batch_kernel(ExpandMacP
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < CT; c++) {
-        if ((uint32_t)(c & 3) != kg || (uint32_t)c >= n) continue;
-        const uint32_t a = a0 + c, i = p.act.index(a, p.cnt_e);
-        const bool make_next = p.neg1n != nullptr && (!odd || (i >> 1) + (p.next_num_in >> 1) < p.next_cnt_o);
-        uint64_t* cp = p.cv + (size_t)i * 2 * kN + z;
-        const u64x2_t old0 = *reinterpret_cast<const u64x2_t*>(cp), old1 = *reinterpret_cast<const u64x2_t*>(cp + kN);
-        const u64x2_t a1v = *reinterpret_cast<const u64x2_t*>(p.a1 + ((size_t)a * 2u + 1u) * kN + z);
-        u64x2_t nw = {0, 0}, nws = {0, 0};
-        if (make_next) {
-            nw = *reinterpret_cast<const u64x2_t*>(p.neg1n + z);
-            nws = *reinterpret_cast<const u64x2_t*>(p.neg1ns + z);
-        }
+        if ((uint32_t)c != kg || !fin) continue;
+        const uint32_t i = fi;
 #pragma unroll
         for (int q = 0; q < 4; q++)  // <= 56 terms of < 2^56 in total: no overflow
             if ((uint32_t)q != kg) {

@@ -28,14 +28,7 @@ struct spiral_gpu_server {
     DevBuf db, w_left, w_right, w, v, query, cv, ex_raw, ex_g;
     DevBuf cv_raw, cv_g, gsw, key, cts_keep;
     uint64_t *gs_raw_p = nullptr, *gs_chat_p = nullptr;  // the Regev->GSW halves of cv_raw / cv_g
-    DevBuf qs, acc_own, raw, fold_d, fold_c, fold_p[2], resp, stage;
-    // Fused fold rounds (fold_fused_kernel: lift + digits + transforms + key product in one kernel, outputs as partial sums) are
-    // implemented, parity-tested and OFF by default: measured on config 2 round 0 (768 workgroups x 9 transforms) 84-86 us
-    // against 64 + 19 us for the chain + product kernels -- the 96 accumulator registers of the three output rows cap the
-    // kernel at 3 waves per SIMD and it loses as much in the transforms as the 192 MiB of digit traffic it removes cost;
-    // later rounds lose outright to reading 12-48 partial sums per polynomial.  SPIRAL_FOLD_FUSED=1: wide rounds, =2: all.
-    bool fold_fused_all = false;
-    bool fold_fused = false;
+    DevBuf qs, acc_own, raw, fold_d, fold_c, resp, stage;
     uint64_t* acc = nullptr;
     hipEvent_t ev[8] = {};
     // captured stage groups (hipGraph): [0] expand + convert, [1] lift + fold + finish, [2] the same with
@@ -111,12 +104,6 @@ int srv_alloc(spiral_gpu_server* S, const spiral_gpu_server* db_owner) {
     const size_t half = s.num_per > 1 ? s.num_per / 2 : 1;
     if (S->fold_d.alloc(half * 2 * s.m2 * 2 * kN)) return -1;
     if (S->fold_c.alloc(half * 6 * kN)) return -1;
-    {  // partial sums of the fused fold rounds: 6 * chunks parts of np' x 6 polynomials, two buffers (a round reads the previous one's)
-        size_t most = 6;
-        for (uint32_t np = s.num_per / 2; np >= 1; np /= 2) most = std::max(most, (size_t)fold_fused_parts(s.ell, fold_dpb(S, 2 * np * 6)) * np * 6);
-        for (auto& b : S->fold_p)
-            if (b.alloc(most * kN)) return -1;
-    }
     if (S->resp.alloc((size_t)6 * kN)) return -1;
     return 0;
 }
@@ -132,7 +119,7 @@ void srv_drop_graphs(spiral_gpu_server* S) {
 void srv_free(spiral_gpu_server* S) {
     srv_drop_graphs(S);
     DevBuf* all[] = {&S->db, &S->w_left, &S->w_right, &S->w, &S->v, &S->query, &S->cv, &S->ex_raw, &S->ex_g, &S->cv_raw,
-                     &S->cv_g, &S->gsw, &S->key, &S->cts_keep, &S->qs, &S->acc_own, &S->raw, &S->fold_d, &S->fold_c, &S->fold_p[0], &S->fold_p[1],
+                     &S->cv_g, &S->gsw, &S->key, &S->cts_keep, &S->qs, &S->acc_own, &S->raw, &S->fold_d, &S->fold_c,
                      &S->resp, &S->stage, &S->wire};
     if (S->db_shared) S->db.p = nullptr;
     for (DevBuf* b : all) b->release();
@@ -607,10 +594,6 @@ static int srv_create(const spiral_gpu_params* p, int device, uint32_t j_begin, 
     S->dim0_shard = j_end - j_begin;
     if (const char* e = getenv("SPIRAL_FOLD_CHAIN")) S->fold_chain = atoi(e) != 0;
     if (const char* e = getenv("SPIRAL_FOLD_BLOCKS")) S->fold_blocks = (uint32_t)strtoul(e, nullptr, 10);
-    if (const char* e = getenv("SPIRAL_FOLD_FUSED")) {
-        S->fold_fused = atoi(e) != 0;
-        S->fold_fused_all = atoi(e) == 2;
-    }
     if (p->direct_upload || s.stopround == 0) {
         S->pos_stride = 1;
         S->pos_first = 0;
@@ -1013,16 +996,12 @@ namespace {
 int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t rounds, const uint64_t* src_pk, bool pre_reduce, bool finish = false) {
     const spiral_gpu_shape& s = S->s;
     uint32_t np = np0;
-    uint32_t src_parts = 1, src_part_stride = 0;  // src_pk is the sum of that many partial sums (fused rounds)
-    int pbuf = 0;
     auto lift = [&](uint32_t npolys) {
         InvParams ip{};
         ip.src = src_pk;
         ip.dst = S->raw.p;
         ip.src_map = ip.dst_map = identity_map();
         ip.pre_reduce = pre_reduce ? 1 : 0;
-        ip.n_parts = src_parts;
-        ip.part_stride = src_part_stride;
         launch_ntt_inverse(S->tb, ip, IST_CRT, npolys, S->stream);
         src_pk = nullptr;
     };
@@ -1030,27 +1009,6 @@ int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t ro
         np /= 2;
         const uint32_t n_src = 2 * np * 6;
         const uint64_t* key = S->key.p + (size_t)d * 3 * 2 * s.m2 * kN;
-        // optional (see spiral_gpu_server::fold_fused): the whole round in one kernel, its output left as partial sums
-        if (src_pk && S->fold_chain && S->fold_fused && (fold_dpb(S, n_src) == s.ell || S->fold_fused_all)) {
-            FoldFusedParams fp{};
-            fp.src = src_pk;
-            fp.src_parts = src_parts;
-            fp.src_part_stride = src_part_stride;
-            fp.key = key;
-            fp.dst = S->fold_p[pbuf].p;
-            fp.ell = s.ell;
-            fp.bits = get_bits_per(s.ell);
-            fp.fold_np = np;
-            fp.pre_reduce = pre_reduce ? 1 : 0;
-            fp.dpb = fold_dpb(S, n_src);
-            launch_fold_fused(S->tb, fp, S->stream);
-            src_pk = fp.dst;
-            src_parts = fold_fused_parts(s.ell, fp.dpb);
-            src_part_stride = np * 6;
-            pbuf ^= 1;
-            pre_reduce = false;
-            continue;
-        }
         if (src_pk && S->fold_chain) {
             FoldChainParams cp{};
             cp.src = src_pk;
@@ -1061,8 +1019,6 @@ int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t ro
             cp.pre_reduce = pre_reduce ? 1 : 0;
             cp.dpb = fold_dpb(S, n_src);
             cp.lazy_out = 6 * s.ell < 128 ? 1 : 0;  // fold_mac sums 2 * m2 = 6 ell products per accumulator
-            cp.src_parts = src_parts;
-            cp.src_part_stride = src_part_stride;
             launch_fold_chain(S->tb, cp, n_src, S->stream);
         } else {
             if (src_pk) lift(n_src);
@@ -1078,7 +1034,6 @@ int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t ro
         }
         launch_fold_mac(key, S->fold_d.p, S->fold_c.p, 2 * s.m2, np, S->stream);
         src_pk = S->fold_c.p;
-        src_parts = 1;
         pre_reduce = false;
     }
     if (src_pk) lift(np * 6);

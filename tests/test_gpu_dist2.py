@@ -127,7 +127,7 @@ def test_bench_two_rank_flow_on_one_gpu():
     import subprocess
 
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--backend", "gloo", "--shared-device"]
+           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--backend", "gloo", "--shared-device", "--no-config3"]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
@@ -135,6 +135,27 @@ def test_bench_two_rank_flow_on_one_gpu():
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["value"] > 0 and out["scaling"] == "strong"
     assert out["roofline"]["bound"] == "hbm" and out["roofline"]["achieved"] > 0
     assert "reduce-scatter" in out["config"]["parallelism"] and "sharded expansion" in out["config"]["parallelism"]
+
+
+def test_bench_self_launch_without_launcher():
+    """plain `python bench.py --gpus 2` with no WORLD_SIZE in the environment: bench.py starts the two ranks itself (before it
+    touches the GPU), relays rank 0's JSON line and exits with the children's code.  The line is self-describing: what the
+    communicator saw, both collective schedules timed over the same steps, per-collective times, the configs[2] leg."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--backend", "gloo", "--shared-device", "--config3-steps", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["value"] > 0
+    assert out["rccl"]["world_size"] == 2 and [x["rank"] for x in out["rccl"]["ranks_seen"]] == [0, 1] and out["rccl"]["backend"] == "gloo"
+    assert set(out["schedules"]["ms_per_query"]) == {"in-order", "comm-overlap"} and out["schedules"]["chosen"] in out["schedules"]["ms_per_query"]
+    assert out["value"] == min(out["schedules"]["ms_per_query"].values())
+    assert set(out["collectives_us"]) == {"all_gather_gsw_bits", "reduce_scatter_accumulators", "all_gather_folded_cts"}
+    c3 = out["also"]["config3"]
+    assert c3["n_gpus"] == 2 and c3["value"] > 0 and c3["roofline"]["achieved"] > 0 and "2^24" in c3["workload"]
 
 
 @pytest.mark.parametrize("extra", [[], ["--root-fold"]])
@@ -147,7 +168,7 @@ def test_bench_rccl_world_size_one(extra):
     import subprocess
 
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--force-dist", "--backend", "nccl", "--no-cpu-baseline"] + extra
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--force-dist", "--backend", "nccl", "--no-cpu-baseline", "--no-config3"] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])

@@ -302,10 +302,6 @@ def test_load_db_in_several_staging_passes(sa, oracle, monkeypatch):
     {"SPIRAL_FOLD_BLOCKS": "0"},         # fold_chain_kernel, one block per polynomial (all digits) every round
     {"SPIRAL_FOLD_BLOCKS": "1000000"},   # fold_chain_kernel, one block per (polynomial, digit) every round
     {"SPIRAL_FOLD_BLOCKS": "300"},       # mixed chunk sizes
-    {"SPIRAL_FOLD_FUSED": "1"},          # the wide rounds fused (fold_fused_kernel), the narrow ones chain + product
-    {"SPIRAL_FOLD_FUSED": "2"},          # every round fused (fold_fused_kernel), outputs as partial sums of 6 .. 48 parts
-    {"SPIRAL_FOLD_FUSED": "2", "SPIRAL_FOLD_BLOCKS": "1000000"},  # ... one digit per workgroup
-    {"SPIRAL_FOLD_FUSED": "2", "SPIRAL_FOLD_BLOCKS": "0"},        # ... all digits per workgroup
 ])
 def test_fold_chain_schedules(sa, oracle, env, monkeypatch):
     """the fold's schedule variants (read from the environment when the server is created) all give the oracle's answer"""
@@ -492,6 +488,45 @@ def test_two_query_lanes_share_one_database(sa, oracle):
     lane.close()
     fin, resp, _ = owner.answer(clients[0].query(9))  # the owner is unaffected by the lane's release
     assert_eq(clients[0].decode(resp), O.db_item(po, 31, 9), "owner after the lane closed")
+    owner.close()
+
+
+def test_lane_created_on_the_owners_image(sa, oracle):
+    """create_lane (Server(share_db_of=...)): a query lane that never allocates an image of its own; a server with another
+    plaintext modulus cannot share (its response switch would use the wrong modulus); column read-back == slot read-back"""
+    O = oracle
+    from spiral_amd import server as SV
+
+    kw = dict(t_gsw=4)
+    po, pg = O.make_params(5, 3, **kw), sa.make_params(5, 3, **kw)
+    db = O.gen_db(po, 31)
+    owner = sa.Server(pg)
+    with pytest.raises(RuntimeError):
+        sa.Server(pg, share_db_of=owner)  # nothing loaded yet
+    owner.gen_db(31)
+    lane = sa.Server(pg, share_db_of=owner)
+    with pytest.raises(RuntimeError):
+        lane.gen_db(5)
+    with pytest.raises(RuntimeError):
+        sa.Server(pg, share_db_of=lane)  # a lane does not own the image
+    other = sa.Server(sa.make_params(5, 3, t_gsw=4, p_db=16))
+    with pytest.raises(RuntimeError):
+        other.share_db(owner)
+    other.close()
+    cl = O.Client(po, seed=8)
+    pp = cl.pub_params()
+    lane.set_pub_params(*pp)
+    for idx in (0, 77, 255):
+        q = cl.query(idx)
+        fin, resp, _ = lane.answer(q)
+        assert_eq(fin, O.answer(po, q, *pp, db), f"lane answer idx={idx}")
+        assert_eq(cl.decode(resp), O.db_item(po, 31, idx), "decoded plaintext")
+    slabs = owner.read_db_slots(0, N)  # [N][num_per][2][dim0][2]
+    for ii0, n in ((0, 1), (7, 1), (2, 3)):
+        assert_eq(owner.read_db_columns(ii0, n), slabs[:, ii0:ii0 + n], f"columns {ii0}..{ii0 + n - 1}")
+    with pytest.raises(RuntimeError):
+        owner.read_db_columns(7, 2)
+    lane.close()
     owner.close()
 
 

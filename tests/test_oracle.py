@@ -180,6 +180,33 @@ def test_staged_pipeline_equals_answer(oracle):
     assert (fin == O.answer(p, q, wl, wr, w, v, db)).all()
 
 
+@pytest.mark.parametrize("dim0", [1, 2, 16, 32, 64, 128])
+def test_vectorised_sweep_cell_equals_scalar(oracle, oracle_mt, dim0):
+    """the first-dimension cell in the reference's AVX2 (default build) and AVX-512 (native build, where the host has it) forms
+    (src/spiral.cpp:640-886: partial reduction every 64 terms) against the scalar u128 cell: random residues, all-maximal
+    residues (the largest sums) and zeros; dim0 = 1 takes the scalar cell in every build (odd pairing)"""
+    rng = np.random.default_rng(dim0)
+    num_per = 3
+    for O in (oracle, oracle_mt):
+        for fill in ("random", "max", "zero"):
+            def words(shape):
+                if fill == "random":
+                    lo, hi = rng.integers(0, O.P, size=shape, dtype=np.uint64), rng.integers(0, O.B, size=shape, dtype=np.uint64)
+                elif fill == "max":
+                    lo, hi = np.full(shape, O.P - 1, dtype=np.uint64), np.full(shape, O.B - 1, dtype=np.uint64)
+                else:
+                    lo = hi = np.zeros(shape, dtype=np.uint64)
+                return np.ascontiguousarray(lo | (hi << np.uint64(32)))
+            re = words((O.N, dim0, 2, 4))
+            db = words((O.N, num_per, 2, dim0, 2))
+            got = O.multiply_query_by_database(re, db, dim0, num_per)
+            want = O.multiply_query_by_database_scalar(re, db, dim0, num_per)
+            assert (got == want).all(), (O.sweep_isa(), fill, dim0)
+            if fill == "max" and dim0 >= 32:
+                assert int(want.max()) > 0
+    assert oracle.sweep_isa() in ("avx2", "avx512", "scalar") and oracle_mt.sweep_isa() in ("avx2", "avx512", "scalar")
+
+
 def test_threaded_native_build_gives_identical_results(oracle, oracle_mt):
     """the -fopenmp -march=native build on many threads (full-size parity tests, bench.py's all-cores baseline) must be
     the same function as the default single-threaded build: base path with expansion + stopround, and the pack path"""

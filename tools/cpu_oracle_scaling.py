@@ -16,11 +16,15 @@ db = O.fill_db_random(99, O.db_words(po))
 mk = lambda shape: np.ascontiguousarray(np.stack([rng.integers(0, m, size=shape + (O.N,), dtype=np.uint64) for m in (O.P, O.B)], axis=-2))
 wl, wr = mk((s.n_left, 2, po.t_exp)), mk((s.n_right, 2, po.t_exp_right))
 w, v = mk((3, 8)), mk((3, 8)); q = mk((1, 2))
+print("sweep cell:", O.sweep_isa(), "| OMP env:", {k: v for k, v in os.environ.items() if k.startswith(("OMP_", "GOMP_"))})
 for th in [int(x) for x in sys.argv[1:]]:
     O.set_threads(th)
-    for stage in range(1):
+    for rep in range(2):  # the second pass is the warm one (scratch blocks cached by malloc, threads started)
         t0 = time.perf_counter(); cv = O.stage_expand(po, q, wl, wr); t1 = time.perf_counter()
         cts, gsw = O.stage_convert(po, cv, w, v); t2 = time.perf_counter()
         raw = O.stage_first_dim(po, cts, db); t3 = time.perf_counter()
         fin = O.stage_fold(po, raw, gsw); t4 = time.perf_counter()
-    print(th, "threads: expand %.0f convert %.0f first_dim %.0f fold %.0f total %.0f ms" % ((t1-t0)*1e3, (t2-t1)*1e3, (t3-t2)*1e3, (t4-t3)*1e3, (t4-t0)*1e3))
+        re = O.reorient_ciphertexts(cts); t5 = time.perf_counter()
+        O.multiply_query_by_database(re, db, s.dim0, s.num_per); t6 = time.perf_counter()
+    print(th, "threads: expand %.0f convert %.0f first_dim %.0f (sweep loop alone %.0f = %.1f GB/s of NTT-form database) fold %.0f total %.0f ms" % (
+        (t1-t0)*1e3, (t2-t1)*1e3, (t3-t2)*1e3, (t6-t5)*1e3, O.db_words(po) * 8 / (t6-t5) / 1e9, (t4-t3)*1e3, (t4-t0)*1e3), flush=True)
