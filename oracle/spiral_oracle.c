@@ -659,7 +659,13 @@ void orc_expand_improved(uint64_t *cv, uint32_t g, uint32_t t_exp, const uint64_
         /* the reference creates cv[num_in + i] = neg1 * cv[i] at the top of iteration i < num_in (:1709), before that
          * iteration updates cv[i] and before iteration num_in + i reads it; done up front here so that the iterations of a
          * round are independent (same values) */
-        for (uint32_t i = 0; i < num_in; i++) orc_mul_by_const(cv + (size_t)(num_in + i) * CT, neg1, cv + (size_t)i * CT, N0);
+        for (uint32_t i = 0; i < num_in; i++) {
+            /* ... under the same skip predicate as the iteration itself (:1701-1702 come before :1709): an odd ciphertext the
+             * round skips creates nothing, so every cv slot holds what the reference leaves there */
+            if (stopround > 0 && r > stopround && (i & 1)) continue;
+            if (stopround > 0 && r == stopround && (i & 1) && i / 2 > max_bits_right) continue;
+            orc_mul_by_const(cv + (size_t)(num_in + i) * CT, neg1, cv + (size_t)i * CT, N0);
+        }
 #pragma omp parallel for schedule(dynamic, 1) if (g_threads > 1)
         for (uint32_t i = 0; i < num_out; i++) {
             int odd = i & 1;

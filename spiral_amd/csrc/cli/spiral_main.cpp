@@ -136,7 +136,7 @@ static int run_high_rate(spiral_gpu_params p, uint32_t out_n, uint64_t idx_targe
 
 int main(int argc, char** argv) {
     if (argc < 4) {
-        fprintf(stderr, "usage: %s <nu1> <nu2> <IDX_TARGET> [dbfile|a] [--random-data] [--direct-upload] [--nonoise] [--show-diff] [--seed N]\n", argv[0]);
+        fprintf(stderr, "usage: %s <nu1> <nu2> <IDX_TARGET> [dbfile|a] [--random-data] [--direct-upload] [--nonoise] [--show-diff] [--output-err F] [--seed N]\n", argv[0]);
         return 1;
     }
     const uint32_t nu1 = (uint32_t)strtol(argv[1], nullptr, 10), nu2 = (uint32_t)strtol(argv[2], nullptr, 10);
@@ -154,6 +154,10 @@ int main(int argc, char** argv) {
         if (!strcmp(argv[i], "--show-diff")) { cout << "Showing diff..." << endl; show_diff = true; }
         if (!strcmp(argv[i], "--direct-upload")) { cout << "Direct uploading of query (no compression)" << endl; direct_flag = true; }
         if (!strcmp(argv[i], "--seed") && i + 1 < argc) seed = strtoull(argv[++i], nullptr, 10);
+        // --output-err F (src/spiral.cpp:1287-1291) asks the reference to dump its empirical noise statistics (analyze_err.py's
+        // input): those are outside this path.  The flag and its file name are consumed so that a driver's
+        // command line parses the same way, and the file is not written.
+        if (!strcmp(argv[i], "--output-err") && i + 1 < argc) { cout << "--output-err " << argv[++i] << ": noise statistics are not produced by this build (ignored)" << endl; }
     }
     if (idx_target >= total_n) {
         fprintf(stderr, "spiral: IDX_TARGET %llu out of range (n = %llu)\n", (unsigned long long)idx_target, (unsigned long long)total_n);

@@ -24,6 +24,14 @@ int tables_get(int device, DeviceTables* out);
 // host copy of the reference-ordered rows (for the C-ABI's spiral_gpu_get_tables)
 void tables_host_rows(uint64_t* out8x2048);
 
+// Lazy digit transforms.  A forward transform of gadget digits may leave its outputs in [0, 2m) instead of [0, m) (FwdParams::lazy_out,
+// FoldChainParams::lazy_out, always for LD_EXPAND) ONLY when every reader is a u64 multiply-accumulate (poly.hip Acc2, pack.hip)
+// against canonical words summing at most `terms` products per accumulator: terms * (2m - 1) * (m - 1) must stay below 2^64.
+// Kernels that add or compare such words (add_pk, csub, canonical stores) need canonical operands and must not be fed lazy ones.
+// This is the one place the bound is decided; the hosts call it with the number of products their MAC kernel sums.
+constexpr bool lazy_ok(uint32_t terms) { return (unsigned __int128)terms * (2ull * kP - 1ull) * (kP - 1ull) < ((unsigned __int128)1 << 64); }
+static_assert(lazy_ok(56) && lazy_ok(2 * 56) && lazy_ok(128) && !lazy_ok(129), "u64 accumulators hold up to 128 lazy products");
+
 // ---- forward NTT ---------------------------------------------------------------------------------
 enum FwdLoad : uint32_t {
     LD_RAW = 0,     // raw u64 coefficient, reduced mod p / mod b        (to_ntt, src/poly.cpp:311)

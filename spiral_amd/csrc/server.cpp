@@ -893,7 +893,7 @@ int convert_part(spiral_gpu_server* S, uint32_t what, hipStream_t st, bool mark_
     fp.src_map = fp.dst_map = identity_map();
     fp.n_digits = p.t_conv;
     fp.bits = get_bits_per(p.t_conv);
-    fp.lazy_out = 1;  // read only by the conversion products (at most 2 * t_conv <= 112 terms per accumulator)
+    fp.lazy_out = lazy_ok(2 * p.t_conv) ? 1 : 0;  // read only by the conversion products, which sum at most 2 * t_conv terms per accumulator
     launch_ntt_forward(S->tb, fp, LD_DIGIT, ST_PK, (n1 + n2) * p.t_conv, st);
     Scal2MatParams sp{};
     sp.w = S->w.p;
@@ -1018,7 +1018,7 @@ int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t ro
             cp.fold_np = np;
             cp.pre_reduce = pre_reduce ? 1 : 0;
             cp.dpb = fold_dpb(S, n_src);
-            cp.lazy_out = 6 * s.ell < 128 ? 1 : 0;  // fold_mac sums 2 * m2 = 6 ell products per accumulator
+            cp.lazy_out = lazy_ok(6 * s.ell) ? 1 : 0;  // fold_mac sums 2 * m2 = 6 ell products per accumulator
             launch_fold_chain(S->tb, cp, n_src, S->stream);
         } else {
             if (src_pk) lift(n_src);

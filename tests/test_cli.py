@@ -39,6 +39,7 @@ def test_cli_refuses_to_run_without_gpu_or_args():
 @pytest.mark.gpu
 @pytest.mark.parametrize("args,env", [
     (["4", "2", "37", "a", "--seed", "3"], {"TGSW": "4"}),
+    (["4", "2", "21", "a", "--output-err", "/tmp/spiral_err_not_written.txt", "--seed", "9"], {"TGSW": "4"}),  # argv of src/spiral.cpp:1287-1291: consumed, ignored
     (["6", "2", "77", "a", "--random-data", "--seed", "4"], {}),
     (["5", "2", "7", "a", "--direct-upload", "--seed", "5"], {"TEXP": "2", "TGSW": "5", "QPBITS": "19"}),  # SURVEY 8c stream probe
 ])
@@ -51,6 +52,8 @@ def test_cli_end_to_end(args, env):
     missing = [k for k, m in got.items() if m is None]
     assert not missing, (missing, r.stdout)
     assert got["is_corr"].group(1) == "1"
+    if "--output-err" in args:
+        assert "noise statistics are not produced" in r.stdout and not os.path.exists(args[args.index("--output-err") + 1])
     assert int(got["resp_sz"].group(1)) == int((2 * 2 * 2048 * (8 + 2) + 2 * 2048 * int(env.get("QPBITS", 20))) / 8)
 
 
