@@ -273,6 +273,7 @@ def parse_args(argv=None):
                     "more to the contention, 349 -> 422 us, than the 30 us of conversion it hides); 0: everything in order on one stream")
     ap.add_argument("--event-every", type=int, default=5, help="bracket the stages with HIP events on every n-th timed step only (1 = every step)")
     ap.add_argument("--root-fold", action="store_true", help="N > 1: plain reduce to rank 0, which lifts and folds alone")
+    ap.add_argument("--no-batched-sweep", dest="batched_sweep", action="store_false", help="N = 1: skip the batched-sweep part of the throughput leg")
     ap.add_argument("--lanes", type=int, default=3, help="N = 1: queries in flight in the extra throughput leg (`pipelined` in the JSON line; 1 = skip it)")
     ap.add_argument("--schedule", default="both", choices=["both", "in-order", "comm-overlap"], help="N > 1 with the sharded expansion and the distributed fold: "
                     "in-order = every collective where its result is needed; comm-overlap = the all-gather of the GSW bits under ScalToMat + sweep and the "
@@ -524,9 +525,10 @@ def bench_base(args, ctx, workload, steps, warmup, primary):
         # throughput leg (outside the timed region, reported beside `value`, never as it): `lanes` queries in flight on one database
         # image, one server handle and one stream per lane, each replaying the whole-query graph
         pipelined = None
-        if primary and whole and args.lanes > 1:
+        if whole and args.lanes > 1:
+            n_lanes = max(args.lanes, 4 if args.batched_sweep else 0)
             lanes = [(srv, stream)]
-            for _ in range(args.lanes - 1):
+            for _ in range(n_lanes - 1):
                 lane, lane_stream = sa.Server(pg, local_rank, j0, j1, share_db_of=srv), torch.cuda.Stream(device=dev)
                 lane.set_stream(lane_stream.cuda_stream)
                 lane.set_pub_params(*pub)
@@ -536,15 +538,37 @@ def bench_base(args, ctx, workload, steps, warmup, primary):
             for lane, _ in lanes:
                 lane.run_query()  # graph capture, untimed
             torch.cuda.synchronize()
-            n_q = max(steps, 100) // args.lanes * args.lanes
+            n_q = max(steps, 100 if primary else 24) // args.lanes * args.lanes
             t1 = time.perf_counter()
             for k in range(n_q):
                 lanes[k % args.lanes][0].run_query()
             torch.cuda.synchronize()
             dt_p = time.perf_counter() - t1
             pipelined = {"lanes": args.lanes, "queries": n_q, "queries_per_s": round(n_q / dt_p, 1), "ms_per_query_amortised": round(dt_p * 1e3 / n_q, 4),
-                         "note": "throughput with several queries in flight (one handle + stream per lane sharing the database image, share_db); "
+                         "note": "throughput with several queries in flight (one handle + stream per lane sharing the database image, create_lane); "
                                  "each query's own latency is `value` or longer"}
+            if args.batched_sweep:
+                # the same lanes, but the B queries of a batch share ONE pass over the database (spiral_gpu_server_first_dim_batch):
+                # run_pre per lane on its stream, the batched sweep, run_post per lane
+                pipelined["batched_sweep"] = {}
+                for B in (2, 4):
+                    group = [ln for ln, _ in lanes[:B]]
+                    for _ in range(2):  # graph capture of run_pre / run_post, untimed
+                        for ln in group: ln.run_pre()
+                        sa.first_dim_batch(group)
+                        for ln in group: ln.run_post()
+                    torch.cuda.synchronize()
+                    n_b = max(n_q // B, 3)
+                    t1 = time.perf_counter()
+                    for _ in range(n_b):
+                        for ln in group: ln.run_pre()
+                        sa.first_dim_batch(group)
+                        for ln in group: ln.run_post()
+                    torch.cuda.synchronize()
+                    dt_b = time.perf_counter() - t1
+                    pipelined["batched_sweep"][str(B)] = {"queries": n_b * B, "queries_per_s": round(n_b * B / dt_b, 1), "ms_per_query_amortised": round(dt_b * 1e3 / (n_b * B), 4)}
+                pipelined["batched_sweep"]["note"] = ("B queries per pass over the database (sweep_kernel<0, B>: the 112-byte groups a lane fetches are multiplied into B "
+                                                      "accumulator sets); throughput only, every answer bit-identical to the single-query path")
             for lane, _ in lanes[1:]:
                 lane.close()
         # untimed: the reference's stage buckets (src/spiral.cpp:246-257) from one eager pass with HIP events
@@ -639,7 +663,7 @@ def main(argv=None):
     if args.workload == "config2" and not args.no_config3 and (args.nu1, args.nu2) == (None, None):
         # secondary leg: configs[2]'s geometry, where the sweep is ~70 % of the query and the j-shard scales; the headline stays configs[1]
         o3, _ = bench_base(args, ctx, "config3", args.config3_steps, min(args.warmup, 2), primary=False)
-        out["also"] = {"config3": {k: o3[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "stages_us", "queries_per_s", "schedules", "collectives_us") if k in o3}}
+        out["also"] = {"config3": {k: o3[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "stages_us", "queries_per_s", "schedules", "collectives_us", "pipelined") if k in o3}}
         out["also"]["config3"]["workload"] = o3["config"]["workload"]
         out["also"]["config3"]["parallelism"] = o3["config"]["parallelism"]
         out["also"]["config3"]["roofline"] = {k: o3["roofline"][k] for k in ("achieved", "frac", "frac_device_bytes", "avg_launch_ms", "algorithmic_bytes_per_launch", "shard")}

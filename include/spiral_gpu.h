@@ -194,6 +194,13 @@ int spiral_gpu_server_expand(spiral_gpu_server *s);    /* expandImproved + reord
 int spiral_gpu_server_convert(spiral_gpu_server *s);   /* scalToMat x dim0, regevToGSW x nu2, Q_neg   */
 int spiral_gpu_server_first_dim(spiral_gpu_server *s); /* multiplyQueryByDatabase on this shard       */
 int spiral_gpu_server_lift(spiral_gpu_server *s, int reduce_first); /* nttInvAndCrtLiftCiphertexts     */
+/* Throughput, beyond the reference (which answers one query at a time): multiplyQueryByDatabase for the queries of n <= 4
+ * servers that share one database image (an owner and its lanes, create_lane) in ONE pass over the database -- server b's
+ * converted query against the image into server b's accumulators, each bit-identical to its own first_dim().  Asynchronous:
+ * the launch runs on servers[0]'s stream and the other lanes' streams are ordered around it with events, so per lane the
+ * sequence run_pre(lane) ... first_dim_batch(all) ... run_post(lane, 0) needs no host synchronisation.  Pays where the sweep is
+ * most of a query (large databases); a single query's latency is first_dim(). */
+int spiral_gpu_server_first_dim_batch(spiral_gpu_server *const *servers, uint32_t n);
 int spiral_gpu_server_fold(spiral_gpu_server *s);      /* foldOneFurtherDimension x nu2               */
 int spiral_gpu_server_finish(spiral_gpu_server *s);    /* response modulus switch, :1441-1447         */
 int spiral_gpu_server_sync(spiral_gpu_server *s);

@@ -227,6 +227,12 @@ void launch_fold_key_from_reoriented(const uint64_t* q_re, const uint64_t* qneg_
 // acc[ii][r][c][z] PK (fields < m).
 // g_log: log2 of the number of ranks of a distributed fold (accumulators grouped by ii mod 2^g_log), 0 = natural order
 void launch_sweep(const uint64_t* db, const uint32_t* qs, uint64_t* acc, uint32_t num_per, uint32_t jm_total, uint32_t g_log, hipStream_t s);
+// n = 2 .. kSweepMaxBatch queries against one pass over the database (records qs[b] -> accumulators acc[b]); only where
+// sweep_batch_ok (the packed layout with at least 64 output columns: every published geometry but the smallest streaming ones)
+constexpr uint32_t kSweepMaxBatch = 4;
+bool sweep_batch_ok(uint32_t num_per, uint32_t jm_total);
+void launch_sweep_batch(const uint64_t* db, const uint32_t* const* qs, uint64_t* const* acc, uint32_t n, uint32_t num_per, uint32_t jm_total, uint32_t g_log,
+                        hipStream_t s);
 // reference DB layout (src/spiral.cpp:1139-1153) -> device layout, for the j-range [j0, j0 + dim0_shard): db_ref holds the nz
 // consecutive z slabs z0 .. z0+nz-1, db_dev is the base of the shard's device database
 void launch_db_relayout(const uint64_t* db_ref, uint64_t* db_dev, uint32_t num_per, uint32_t dim0, uint32_t j0, uint32_t dim0_shard, uint32_t z0,

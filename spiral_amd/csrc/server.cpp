@@ -43,6 +43,7 @@ struct spiral_gpu_server {
     bool overlap = false, side_pending = false;
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_batch = nullptr;  // first_dim_batch: this lane's records are ready / the shared sweep is done
     // fold chain (fold_chain_kernel): a block lifts one source polynomial and transforms dpb of its digits; dpb is halved
     // from ell until the round has at least fold_blocks blocks.  SPIRAL_FOLD_CHAIN=0 (separate lift + digit transforms) and
     // SPIRAL_FOLD_BLOCKS override (tuning / tests).
@@ -127,6 +128,7 @@ void srv_free(spiral_gpu_server* S) {
         if (e) (void)hipEventDestroy(e);
     if (S->ev_fork) (void)hipEventDestroy(S->ev_fork);
     if (S->ev_join) (void)hipEventDestroy(S->ev_join);
+    if (S->ev_batch) (void)hipEventDestroy(S->ev_batch);
     if (S->side_stream) (void)hipStreamDestroy(S->side_stream);
     if (S->own_stream) (void)hipStreamDestroy(S->own_stream);
 }
@@ -614,7 +616,8 @@ static int srv_create(const spiral_gpu_params* p, int device, uint32_t j_begin, 
     S->stream = S->own_stream;
     if (hipStreamCreateWithFlags(&S->side_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&S->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&S->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&S->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&S->ev_batch, hipEventDisableTiming) != hipSuccess) {
         srv_free(S);
         delete S;
         return fail("side stream setup failed");
@@ -970,6 +973,45 @@ int spiral_gpu_server_first_dim(spiral_gpu_server* S) {
     HIP_OK(hipSetDevice(S->device));
     if (!S->have_db) return fail("no database loaded");
     launch_sweep(S->db.p, (const uint32_t*)S->qs.p, S->acc, S->s.num_per, 2 * S->dim0_shard, S->fold_g_log, S->stream);
+    return 0;
+}
+
+// One pass over the database for the queries of n servers that sweep the SAME image (an owner and its lanes, create_lane /
+// share_db): server b's query records against the database into server b's accumulators.  The launch goes on servers[0]'s stream;
+// every other lane's stream is made to wait for it and it for theirs (events), so each lane's run_pre / run_post on its own stream
+// stay correctly ordered around it.  Geometries the batched kernel does not cover fall back to one sweep per lane.
+int spiral_gpu_server_first_dim_batch(spiral_gpu_server* const* servers, uint32_t n) {
+    if (!servers || n == 0) return fail("no servers");
+    for (uint32_t b = 0; b < n; b++)
+        if (!servers[b]) return fail("null server");
+    spiral_gpu_server* S0 = servers[0];
+    if (n == 1) return spiral_gpu_server_first_dim(S0);
+    if (n > kSweepMaxBatch) return fail("at most %u queries per batched sweep", kSweepMaxBatch);
+    HIP_OK(hipSetDevice(S0->device));
+    if (!S0->have_db) return fail("no database loaded");
+    const uint32_t* qs[kSweepMaxBatch];
+    uint64_t* acc[kSweepMaxBatch];
+    for (uint32_t b = 0; b < n; b++) {
+        spiral_gpu_server* S = servers[b];
+        if (S->db.p != S0->db.p || S->device != S0->device || S->dim0_shard != S0->dim0_shard || S->s.num_per != S0->s.num_per || S->fold_g_log != S0->fold_g_log)
+            return fail("first_dim_batch: server %u does not sweep the same database image with the same layout as server 0", b);
+        for (uint32_t c = 0; c < b; c++)
+            if (servers[c] == S) return fail("first_dim_batch: server %u listed twice", b);
+        qs[b] = (const uint32_t*)S->qs.p;
+        acc[b] = S->acc;
+    }
+    if (!sweep_batch_ok(S0->s.num_per, 2 * S0->dim0_shard)) {
+        for (uint32_t b = 0; b < n; b++)
+            if (spiral_gpu_server_first_dim(servers[b])) return -1;
+        return 0;
+    }
+    for (uint32_t b = 1; b < n; b++) {  // the lanes' records must be complete
+        HIP_OK(hipEventRecord(servers[b]->ev_batch, servers[b]->stream));
+        HIP_OK(hipStreamWaitEvent(S0->stream, servers[b]->ev_batch, 0));
+    }
+    launch_sweep_batch(S0->db.p, qs, acc, n, S0->s.num_per, 2 * S0->dim0_shard, S0->fold_g_log, S0->stream);
+    HIP_OK(hipEventRecord(S0->ev_batch, S0->stream));
+    for (uint32_t b = 1; b < n; b++) HIP_OK(hipStreamWaitEvent(servers[b]->stream, S0->ev_batch, 0));
     return 0;
 }
 

@@ -105,9 +105,19 @@ __device__ __forceinline__ void mac_packed_j(uint64_t (&a)[6], const uint4* q, c
 // same address).  MODE 2 (P <= 8): the wave stages the P x 8 records of a group in LDS with two coalesced loads and the
 // lanes read them from there, which takes three quarters of the requests off the vector memory pipe.
 constexpr uint32_t kQStage = 8 * 24;  // uint4 per wave: up to 8 slots x (8 j x 3)
-template <int MODE>
-__global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __restrict__ db, const uint32_t* __restrict__ qs, uint64_t* __restrict__ acc,
-                                                             uint32_t nic, uint32_t dim0, uint32_t g_log) {
+// NB > 1 (MODE 0 only): NB queries against ONE pass over the database -- every 112-byte group a lane fetches and unpacks is
+// multiplied into NB accumulator sets, each against its own query's records (all wave-uniform, scalar loads).  The sweep has the
+// VALU headroom (6 MADs per 7 bytes at 6.4 TB/s = 5.5 T MAD/s of ~31): for throughput at the database sizes where the sweep is
+// most of a query, the stream is paid once per NB queries (spiral_gpu_server_first_dim_batch).  Single-query latency is NB = 1.
+struct SweepBatch {
+    const uint32_t* qs[kSweepMaxBatch];
+    uint64_t* acc[kSweepMaxBatch];
+};
+template <int MODE, int NB = 1>
+__global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __restrict__ db, SweepBatch bt, uint32_t nic, uint32_t dim0, uint32_t g_log) {
+    static_assert(NB == 1 || MODE == 0, "batched sweeps use the wide geometry");
+    const uint32_t* __restrict__ qs = bt.qs[0];
+    uint64_t* __restrict__ acc = bt.acc[0];
     constexpr bool WIDE = MODE == 0;
     constexpr uint32_t kShWords = MODE == 2 ? (kSweepZ * kQStage * 2 > kSweepZ * kSweepRow ? kSweepZ * kQStage * 2 : kSweepZ * kSweepRow) : kSweepZ * kSweepRow;
     __shared__ __attribute__((aligned(16))) uint64_t sh[kShWords];  // results; MODE 2: first the record staging (aliased)
@@ -131,6 +141,7 @@ __global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __r
     const u32x4* dbp = reinterpret_cast<const u32x4*>(db) + (size_t)tile * groups * 7u * 64u + lane;
     const uint4* q = reinterpret_cast<const uint4*>(qs) + (size_t)z * dim0 * 3u;  // 3 x uint4 per j; wave-uniform when WIDE
     uint64_t a[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t ax[NB > 1 ? NB - 1 : 1][6] = {};  // queries 1 .. NB-1 of a batch
     for (uint32_t g0 = gfirst; g0 < glast; g0 += 16) {  // 16 groups = 128 j = 256 terms per accumulator between reductions
         const uint32_t gend = min(g0 + 16u, glast);
 #pragma unroll 2
@@ -166,10 +177,38 @@ __global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __r
             mac_packed_j<5>(a, qg + 15, d);
             mac_packed_j<6>(a, qg + 18, d);
             mac_packed_j<7>(a, qg + 21, d);
+            if constexpr (NB > 1) {
+#pragma unroll
+                for (int b = 1; b < NB; b++) {
+                    const uint4* qb = reinterpret_cast<const uint4*>(bt.qs[b]) + (size_t)z * dim0 * 3u + (size_t)g * 24u;
+                    mac_packed_j<0>(ax[b - 1], qb, d);
+                    mac_packed_j<1>(ax[b - 1], qb + 3, d);
+                    mac_packed_j<2>(ax[b - 1], qb + 6, d);
+                    mac_packed_j<3>(ax[b - 1], qb + 9, d);
+                    mac_packed_j<4>(ax[b - 1], qb + 12, d);
+                    mac_packed_j<5>(ax[b - 1], qb + 15, d);
+                    mac_packed_j<6>(ax[b - 1], qb + 18, d);
+                    mac_packed_j<7>(ax[b - 1], qb + 21, d);
+                }
+            }
         }
         reduce6(a);
+        if constexpr (NB > 1) {
+#pragma unroll
+            for (int b = 1; b < NB; b++) reduce6(ax[b - 1]);
+        }
     }
     if constexpr (MODE == 2) __syncthreads();  // every wave is done with its staging area before results overwrite it
+#pragma unroll
+    for (int b = 0; b < NB; b++) {  // one query's results at a time through the same LDS rows
+    if constexpr (NB > 1) {
+        if (b > 0) {
+            __syncthreads();  // the previous query's rows have been read
+            acc = bt.acc[b];
+#pragma unroll
+            for (int r = 0; r < 6; r++) a[r] = ax[b - 1][r];
+        }
+    }
 #pragma unroll
     for (uint32_t r = 0; r < 3; r++) sh[wv * kSweepRow + lane * 3u + r] = pack((uint32_t)a[r], (uint32_t)a[3 + r]);
     __syncthreads();
@@ -198,6 +237,7 @@ __global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __r
         const uint32_t ii = (i0 & ((1u << g_log) - 1u)) * (num_per >> g_log) + (i0 >> g_log);
         acc[((size_t)(6u * ii + 2u * r + c)) * kN + zg * pz + zz] = pack(mod_p(sp), mod_b(sb));
     }
+    }  // batch
 }
 
 // plain-layout path (dim0 < 8, test sizes only): one thread per (z, ic)
@@ -217,20 +257,40 @@ __global__ __launch_bounds__(256) void sweep_small_kernel(const uint64_t* __rest
     store_acc(acc, a, ic, z, nic >> 1, g_log);
 }
 
+bool sweep_batch_ok(uint32_t num_per, uint32_t jm_total) { return 2 * num_per >= 64 && db_packed(2 * num_per, jm_total / 2); }
+void launch_sweep_batch(const uint64_t* db, const uint32_t* const* qs, uint64_t* const* acc, uint32_t n, uint32_t num_per, uint32_t jm_total, uint32_t g_log,
+                        hipStream_t s) {
+    const uint32_t nic = 2 * num_per, dim0 = jm_total / 2;
+    SweepBatch bt{};
+    for (uint32_t b = 0; b < n; b++) {
+        bt.qs[b] = qs[b];
+        bt.acc[b] = acc[b];
+    }
+    const dim3 grid((kN / kSweepZ) * (nic >> 6)), block(kSweepZ * 64);
+    switch (n) {
+        case 2: hipLaunchKernelGGL((sweep_kernel<0, 2>), grid, block, 0, s, db, bt, nic, dim0, g_log); break;
+        case 3: hipLaunchKernelGGL((sweep_kernel<0, 3>), grid, block, 0, s, db, bt, nic, dim0, g_log); break;
+        case 4: hipLaunchKernelGGL((sweep_kernel<0, 4>), grid, block, 0, s, db, bt, nic, dim0, g_log); break;
+        default: abort();
+    }
+}
 void launch_sweep(const uint64_t* db, const uint32_t* qs, uint64_t* acc, uint32_t num_per, uint32_t jm_total, uint32_t g_log, hipStream_t s) {
     const uint32_t nic = 2 * num_per, dim0 = jm_total / 2;
     if (dim0 == 0) return;
+    SweepBatch bt{};
+    bt.qs[0] = qs;
+    bt.acc[0] = acc;
     if (db_packed(nic, dim0)) {
         static const bool stage = [] {
             const char* e = getenv("SPIRAL_SWEEP_STAGE");  // tuning only: 0 = narrow geometries load their records per lane
             return e ? atoi(e) != 0 : true;
         }();
         if (nic >= 64)
-            hipLaunchKernelGGL(sweep_kernel<0>, dim3((kN / kSweepZ) * (nic >> 6)), dim3(kSweepZ * 64), 0, s, db, qs, acc, nic, dim0, g_log);
+            hipLaunchKernelGGL(sweep_kernel<0>, dim3((kN / kSweepZ) * (nic >> 6)), dim3(kSweepZ * 64), 0, s, db, bt, nic, dim0, g_log);
         else if (nic >= 8 && stage)  // one workgroup per tile of 64/nic <= 8 slots, its waves split the j range; records staged in LDS
-            hipLaunchKernelGGL(sweep_kernel<2>, dim3(kN / (64 / nic)), dim3(kSweepZ * 64), 0, s, db, qs, acc, nic, dim0, g_log);
+            hipLaunchKernelGGL(sweep_kernel<2>, dim3(kN / (64 / nic)), dim3(kSweepZ * 64), 0, s, db, bt, nic, dim0, g_log);
         else
-            hipLaunchKernelGGL(sweep_kernel<1>, dim3(kN / (64 / nic)), dim3(kSweepZ * 64), 0, s, db, qs, acc, nic, dim0, g_log);
+            hipLaunchKernelGGL(sweep_kernel<1>, dim3(kN / (64 / nic)), dim3(kSweepZ * 64), 0, s, db, bt, nic, dim0, g_log);
     } else {
         const uint32_t threads = kN * nic;
         hipLaunchKernelGGL(sweep_small_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, db, qs, acc, nic, dim0, g_log);

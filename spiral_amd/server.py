@@ -19,6 +19,12 @@ def _p(a: np.ndarray):
     return a.ctypes.data_as(U64P)
 
 
+def first_dim_batch(servers):
+    """one pass over the database for the (converted) queries of up to four servers sharing one image; see include/spiral_gpu.h"""
+    arr = (C.c_void_p * len(servers))(*[s.h for s in servers])
+    check(lib().spiral_gpu_server_first_dim_batch(arr, len(servers)))
+
+
 class Server:
     def __init__(self, params: Params, device: int = 0, j_begin: int = 0, j_end: int = 0, share_db_of: "Server | None" = None):
         """share_db_of: make this server a query lane of that one -- same parameters, device and shard, sweeping ITS database

@@ -530,6 +530,61 @@ def test_lane_created_on_the_owners_image(sa, oracle):
     owner.close()
 
 
+@pytest.mark.parametrize("nu1,nu2,n", [(4, 5, 2), (3, 6, 3), (3, 5, 4), (5, 3, 3)])
+def test_batched_sweep_equals_single_sweeps(sa, oracle, nu1, nu2, n):
+    """first_dim_batch: the queries of n lanes against one pass over the shared database image; every lane's accumulators and
+    final answer equal its own first_dim() and the oracle.  (5, 3): fewer than 64 output columns, where the call falls back to
+    one sweep per lane.  Lanes run on their own streams with the whole-group graphs either side of the shared sweep."""
+    import torch
+
+    O = oracle
+    from spiral_amd import server as SV
+
+    kw = dict(t_gsw=8 if nu2 >= 5 else 4)  # (t_gsw = 4 is bit-exact too but too noisy to decode from nu2 = 5 up)
+    po, pg = O.make_params(nu1, nu2, **kw), sa.make_params(nu1, nu2, **kw)
+    s = O.shape_of(po)
+    db = O.gen_db(po, 77)
+    owner = sa.Server(pg)
+    owner.gen_db(77)
+    lanes = [owner] + [sa.Server(pg, share_db_of=owner) for _ in range(n - 1)]
+    clients = [O.Client(po, seed=40 + b) for b in range(n)]
+    pps = [cl.pub_params() for cl in clients]
+    streams = [torch.cuda.Stream() for _ in range(n)]
+    for srv, st, pp in zip(lanes, streams, pps):
+        srv.set_stream(st.cuda_stream)
+        srv.set_pub_params(*pp)
+        srv.use_graphs(True)
+    total = s.dim0 * s.num_per
+    for rnd in range(2):
+        idxs = [(17 * rnd + 5 * b) % total for b in range(n)]
+        qs = [cl.query(i) for cl, i in zip(clients, idxs)]
+        for srv, q in zip(lanes, qs):
+            srv.set_query(q)
+            srv.run_pre()
+        sa.first_dim_batch(lanes)
+        for srv in lanes:
+            srv.run_post()
+        for srv in lanes:
+            srv.sync()
+        for b, (srv, cl, pp, q, idx) in enumerate(zip(lanes, clients, pps, qs, idxs)):
+            cv = O.stage_expand(po, q, pp[0], pp[1])
+            cts, gsw = O.stage_convert(po, cv, pp[2], pp[3])
+            want_acc = O.multiply_query_by_database(O.reorient_ciphertexts(cts), db, s.dim0, s.num_per)
+            assert_eq(srv.read(SV.BUF_ACC), want_acc, f"round {rnd} lane {b}: accumulators of the batched sweep")
+            assert_eq(srv.read(SV.BUF_FINAL), O.stage_fold(po, O.from_ntt(want_acc), gsw), f"round {rnd} lane {b}: final ciphertext")
+            assert_eq(cl.decode(srv.read(SV.BUF_RESPONSE)), O.db_item(po, 77, idx), f"round {rnd} lane {b}: decoded plaintext")
+    with pytest.raises(RuntimeError):
+        sa.first_dim_batch([lanes[0], lanes[0]])
+    other = sa.Server(pg)
+    other.gen_db(77)  # same contents, another image
+    with pytest.raises(RuntimeError):
+        sa.first_dim_batch([lanes[0], other])
+    other.close()
+    for srv in lanes[1:]:
+        srv.close()
+    owner.close()
+
+
 def test_sharded_first_dim_sums_to_unsharded(sa, oracle):
     """two j-shards on one device: summing their accumulators (what the RCCL reduce does) == one server"""
     O = oracle
