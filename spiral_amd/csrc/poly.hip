@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kTpb) void expand_mac_round_kernel(ExpandMacParams 
         a1v = p.a1[((size_t)a * 2u + 1u) * kN + z];
     }
     Acc2 acc0, acc1;
-#pragma unroll 7
+#pragma unroll 14  // t = 56 is 14 terms per k-group: all of them in flight at once (this kernel serves the latency-bound rounds)
     for (uint32_t k = kg; k < tdim; k += 4) {
 #ifndef MAC_PLAIN_LOADS  // streamed operand: read once, must not push the shared W / key rows out of L2 (-17 us on expand + convert)
         const uint64_t gv = __builtin_nontemporal_load(&gp[(size_t)k * kN]);

@@ -10,12 +10,16 @@ seconds of host time.  What is compared bit for bit:
   reference's NTT layout, and ingested from raw plaintext bytes (SURVEY.md 8c asked for the SHA-256 of the sweep
   output and of the response: printed, and equal because the arrays are).
 * configs[2] geometry (nu1=9, nu2=10, 32 GiB) and configs[3] (SpiralStream nu1=11, nu2=9, 64 GiB): the database does not
-  fit a host-side reference computation, and the sweep is independent per NTT slot, so the device database is read
-  back for a sample of slots, the oracle runs the sweep on exactly those slots, and the accumulators must agree there;
-  sampled items of the device database must equal the oracle's encoding of the seeded plaintexts; everything
+  fit a host-side reference computation, and the sweep is independent per NTT slot and per output ciphertext, so the device
+  database is read back (a) for a sample of slots -- the oracle runs the sweep on exactly those slots for ALL output
+  ciphertexts -- and (b) for ALL 2048 slots of the first, the last and one random plaintext column -- the oracle runs the
+  full multiplyQueryByDatabase on them, every z-tile and XCD of the sweep's tile map included -- and the accumulators must
+  agree; sampled items of the device database must equal the oracle's encoding of the seeded plaintexts; everything
   database-independent (expansion, conversion) is compared in full; the response must decode to the item.
-* configs[4] (SpiralPack nu1=10, nu2=8, n=4, 64 GiB): trial 0's sweep accumulators against the oracle's sweep of that
-  trial's 4 GiB database; with enough host memory, all 16 trials, the packed ciphertext and the response.
+* configs[4] (SpiralPack nu1=10, nu2=8, n=4, 64 GiB): the full sweep accumulators of trials 0, 7 and 15 against the oracle's
+  sweep of each trial's 4 GiB database, unconditionally; with 160 GiB of host memory, all 16 trials at once, the packed
+  ciphertext and the response.
+The lines the tests record (SHA-256s, GB/s, which branches ran) are repeated in pytest's terminal summary (tests/conftest.py).
 """
 import hashlib
 
