@@ -57,6 +57,35 @@ __global__ __launch_bounds__(kTpb) void fold_mac_kernel(FoldMacParams p) {
     const uint64_t* dp = p.d + (size_t)i0 * p.K * 2 * kN + z;
     const uint64_t* kp = p.key + z;
     Acc2 acc[B][3][2];
+    if constexpr (B == 1) {
+        // The latency-bound rounds (np < 16): "request all 12 terms of the k-group (K = 6 t_GSW = 48), then multiply".  With the loads inside
+        // a loop whose every iteration may be the last, the compiler waits for each term before requesting the next -- 12 dependent
+        // round trips per thread.  Indices beyond K are clamped for the request and their products skipped.  7.0 / 6.3 / 6.3 / 6.2 ->
+        // 6.6 / 5.6 / 5.5 / 5.4 us for the four narrow rounds of config 2.  (The same rewrite of the bandwidth-bound B = 2 rounds and of
+        // the expansion's product kernels costs occupancy and measured 1-2 us SLOWER per launch: they keep the plain loop.)
+        constexpr uint32_t U = 12;
+        for (uint32_t m0 = kg; m0 < p.K; m0 += 4 * U) {
+            uint64_t kv[U][3], dv[U][2];
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                const uint32_t mm = min(m0 + 4 * u, p.K - 1);
+#pragma unroll
+                for (uint32_t r = 0; r < 3; r++) kv[u][r] = kp[((size_t)r * p.K + mm) * kN];
+                dv[u][0] = __builtin_nontemporal_load(&dp[(size_t)mm * 2 * kN]);
+                dv[u][1] = __builtin_nontemporal_load(&dp[((size_t)mm * 2 + 1) * kN]);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                if (m0 + 4 * u < p.K) {
+#pragma unroll
+                    for (uint32_t r = 0; r < 3; r++) {
+                        acc[0][r][0].mac(kv[u][r], dv[u][0]);
+                        acc[0][r][1].mac(kv[u][r], dv[u][1]);
+                    }
+                }
+            }
+        }
+    } else {
 #pragma unroll 4
     for (uint32_t mm = kg; mm < p.K; mm += 4) {
         uint64_t kv[3];
@@ -75,6 +104,7 @@ __global__ __launch_bounds__(kTpb) void fold_mac_kernel(FoldMacParams p) {
                 acc[b][r][1].mac(kv[r], d1);
             }
         }
+    }
     }
     if (kg > 0) {
 #pragma unroll
