@@ -106,3 +106,35 @@ def test_wire_form_host_functions_reject_bad_arguments():
     out = np.zeros((3, 2, 2048), dtype=np.uint64)
     assert sa.lib().spiral_gpu_response_from_wire(C.byref(p), 2, None, out.ctypes.data_as(C.POINTER(C.c_uint64))) != 0
     assert b"null" in sa.lib().spiral_gpu_last_error()
+
+
+def test_bench_self_launch_command_and_cpu_quota(monkeypatch):
+    """bench.py --gpus N without a launcher: the parent builds a torch.distributed.run command for N ranks on 127.0.0.1 with the
+    user's own flags and returns the children's exit code, without importing torch itself; the CPU-baseline
+    thread ladder is capped by the cgroup quota"""
+    import importlib
+    import subprocess
+    import sys
+
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None, cwd=None):
+        seen.update(cmd=cmd, env=env, cwd=cwd)
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    torch_loaded_before = "torch" in sys.modules
+    argv = ["--gpus", "4", "--steps", "5", "--workload", "config3"]
+    with pytest.raises(SystemExit) as e:
+        bench.main(argv)
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-len(argv):] == argv and cmd[-len(argv) - 1].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert ("torch" in sys.modules) == torch_loaded_before  # the parent never touches torch / the GPU
+    assert 1 <= bench.cpu_quota_cores() <= (os.cpu_count() or 1)
+    a = bench.parse_args(["--comm-overlap"])
+    assert a.schedule == "comm-overlap" and bench.parse_args([]).schedule == "both"
