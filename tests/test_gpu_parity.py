@@ -50,8 +50,17 @@ def test_ntt_forward_inverse(sa, oracle):
     x[2] *= 3  # lazy inputs < 4m are legal for ntt_forward (src/core.cpp:274)
     f = sa.ntt_forward(x)
     assert_eq(f, O.ntt_forward(x), "ntt_forward")
-    xi = rand_ntt(rng, O, (5,))
+    xi = rand_ntt(rng, O, (9,))
+    # the unscaled inverse stages double their sums per stage: the patterns that drive every register of every pass to its bound
+    top = np.array([O.P - 1, O.B - 1], dtype=np.uint64)[:, None]
+    xi[0] = top                                    # every sum maximal (16 m - 16 before a pass's reduction)
+    xi[1] = top * (np.arange(N) % 2 == 0)          # maximal differences in the first stage
+    xi[2] = top * (np.arange(N) % 2 == 1)
+    xi[3] = top * (np.arange(N) < N // 2)          # ... in the last
+    xi[4] = top * ((np.arange(N) // 8) % 2 == 0)   # ... across the first exchange
+    xi[5] = top * ((np.arange(N) // 64) % 2 == 1)
     assert_eq(sa.ntt_inverse(xi), O.ntt_inverse(xi), "ntt_inverse")
+    assert_eq(sa.from_ntt(xi), O.from_ntt(xi), "from_ntt on the extreme patterns (lazy CRT lift)")
     assert_eq(sa.ntt_inverse(f), canon(O, x), "inverse(forward)")
 
 
