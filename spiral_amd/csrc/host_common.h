@@ -154,17 +154,7 @@ inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_
                 const uint64_t* w_right, uint32_t max_bits_right, uint32_t stopround, const ExpandWork& wk, hipStream_t st,
                 const uint64_t* query = nullptr,  // query: the packed query ciphertext when cv[0] does not hold it yet
                 uint32_t r_begin = 0, uint32_t r_end = 0xffffffffu,  // rounds [r_begin, min(r_end, g))
-                const ExpandShard& shard = ExpandShard{},
-                // defer_last: if the last round is even-only, leave its product to the caller (returned), who gathers it into the
-                // conversion's lift (launch_expand_fused FUSED_LIFT) -- cv is then complete only after that launch
-                ExpandFusedParams* defer_last = nullptr) {
-    static const bool fuse_even = [] {
-        const char* e = getenv("SPIRAL_EXPAND_FUSE");  // tuning / tests: 0 = every round's product as its own launch
-        return e ? atoi(e) != 0 : true;
-    }();
-    bool pending = false;  // round r - 1 was even-only and left its product to this round's first launch
-    ExpandFusedParams fz{};
-    if (defer_last) defer_last->cnt = 0;
+                const ExpandShard& shard = ExpandShard{}) {
     // active odd-index ciphertexts of round r (:1701-1702); the even ones are all 2^r
     auto odd_count = [&](uint32_t r) {
         const uint32_t num_in = 1u << r;
@@ -193,15 +183,6 @@ inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_
         //    cts with i >= num_in are neg1 * cv[i - num_in] (:1709): created inside this kernel in round 0, by the
         //    previous round's MAC afterwards
         const uint32_t cnt = cnt_even + cnt_odd;
-        if (pending) {  // the previous (even-only) round's product, the creation of this round's new ciphertexts and this round's inverse pass
-            fz.dst = wk.raw;
-            fz.neg1n = tb.neg1 + (size_t)r * kN;
-            fz.neg1ns = tb.neg1s + (size_t)r * kN;
-            fz.next_num_in = num_in;
-            fz.auto_t = t;
-            launch_expand_fused(tb, fz, FUSED_NEXT_ROUND, st);
-            pending = false;
-        } else {
         InvParams ip{};
         ip.dst = wk.raw;
         ip.src_map = ip.dst_map = identity_map();
@@ -215,7 +196,6 @@ inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_
         ip.create_here = r == 0;
         ip.query = query;
         launch_ntt_inverse_expand(tb, ip, 2 * cnt, st);
-        }
         // 2) G^-1(automorph(c)[0]) digits (t_exp / t_exp_right per ct), one launch
         FwdParams fp{};
         fp.src = wk.raw;
@@ -227,24 +207,6 @@ inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_
         fp.t_o = t_exp_right;
         launch_ntt_forward(tb, fp, LD_EXPAND, ST_PK, cnt_even * t_exp + cnt_odd * t_exp_right, st);
         // 3) cv[i] += W * digits + (0, NTT(c'_1))
-        // Even-only rounds (beyond stopround; one GPU): K = t_exp terms per output, so the product is gathered by the workgroups of the
-        // NEXT launch that needs the ciphertext -- the next round's inverse pass, or (last round, defer_last) the conversion's lift
-        const bool last = r + 1 >= std::min(r_end, g);
-        if (fuse_even && cnt_odd == 0 && shard.g_log == 0 && r > 0 && (!last || (defer_last && r + 1 == g))) {
-            fz = ExpandFusedParams{};
-            fz.cv = cv;
-            fz.w = w_left + (size_t)r * 2 * t_exp * kN;
-            fz.g = wk.g;
-            fz.a1 = wk.raw;
-            fz.cnt = cnt_even;
-            fz.t = t_exp;
-            if (last) {
-                *defer_last = fz;
-                return;
-            }
-            pending = true;
-            continue;
-        }
         ExpandMacParams mp{};
         mp.cv = cv;
         mp.w_e = w_left + (size_t)r * 2 * t_exp * kN;

@@ -127,35 +127,6 @@ struct InvParams {
     const uint64_t* query;  // create_here only, optional: cv[0] is read from here (and written to cv) instead of from cv
 };
 void launch_ntt_inverse(const DeviceTables& t, const InvParams& p, uint32_t store, uint32_t nblocks, hipStream_t s);
-
-// Even-only expansion rounds (r > stopround: every active ciphertext takes W_left, K = t_exp terms): round r's product
-//     cv[2a] += W_left[r] * digits_r[a] + (0, NTT(automorph(c_1)))        (src/spiral.cpp:1720-1737)
-// is GATHERED by the workgroup that then runs the next step on that ciphertext, instead of being its own launch: one workgroup per
-// (source ciphertext a < cnt, row) reads the 2 t + 2 polynomials of its product (288 KiB at t = 8), stores the updated row, and
-//   next = NEXT_ROUND: creates the child cv[2a + next_num_in] = neg1 * cv[2a] (:1709) and does round r + 1's inverse pass for both
-//          children (row 0: INTT + CRT lift + automorphism into dst[2a'], row 1: the slot permutation into dst[2a' + 1], a' = a, a + cnt),
-//   next = LIFT: the conversion's lift of row 0 (INTT + CRT into lift_dst[a], coefficient order); blocks beyond 2 cnt are plain lifts
-//          of extra polynomials (the Regev->GSW sources), so that the conversion still needs one launch.
-// With K = 8 the gather is 3 us per workgroup and replaces a launch; with K = 48 / 56 (fold, odd ciphertexts) it loses.
-enum ExpandFusedNext : uint32_t { FUSED_NEXT_ROUND = 0, FUSED_LIFT = 1 };
-struct ExpandFusedParams {
-    uint64_t* cv;
-    const uint64_t* w;     // W_left[r]: [2][t] PK
-    const uint64_t* g;     // round r's digit transforms, t per source ciphertext, PK, in [0, 2m)
-    const uint64_t* a1;    // round r's work buffer: polynomial 2a + 1 = NTT(automorph(c_1)) of source ciphertext a
-    uint32_t cnt, t;
-    // NEXT_ROUND
-    uint64_t* dst;         // round r + 1's work buffer
-    const uint64_t* neg1n;
-    const uint64_t* neg1ns;
-    uint32_t next_num_in, auto_t;
-    // LIFT
-    uint64_t* lift_dst;    // row 0 of source ciphertext a, lifted, at polynomial a
-    const uint64_t* extra_src;  // n_extra more PK polynomials to lift (extra_map(e) -> polynomial index in extra_src) into lift_dst[cnt + e]
-    IndexMap extra_map;
-    uint32_t n_extra;
-};
-void launch_expand_fused(const DeviceTables& t, const ExpandFusedParams& p, uint32_t next, hipStream_t s);
 void launch_ntt_inverse_expand(const DeviceTables& t, const InvParams& p, uint32_t nblocks, hipStream_t s);
 
 // fold chain (ntt.hip): PK polynomials [2*np][3][2] -> inverse transform, CRT lift, balanced digits, forward transforms

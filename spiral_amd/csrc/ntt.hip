@@ -426,131 +426,6 @@ __global__ __launch_bounds__(256, 8) void ntt_inverse_kernel(Tables t, InvParams
     }
 }
 
-// Even-only expansion rounds: the product of round r gathered into the workgroup that runs the next step (kernels.h ExpandFusedParams).
-// Thread tid holds slots 8 tid .. 8 tid + 7 of its polynomial throughout (the PK layout's thread order = the inverse transform's input).
-template <uint32_t NEXT>
-__global__ __launch_bounds__(256) void expand_fused_kernel(Tables t, ExpandFusedParams p) {
-    __shared__ uint64_t sh[kLdsWords];
-    const uint32_t tid = threadIdx.x, b = blockIdx.x;
-    uint32_t lo[8], hi[8];
-    if constexpr (NEXT == FUSED_LIFT) {
-        if (b >= 2u * p.cnt) {  // a plain lift riding in the same launch
-            const uint32_t e = b - 2u * p.cnt;
-            pk_load8_red(p.extra_src + (size_t)p.extra_map(e) * kN, false, tid, lo, hi);
-            ntt_inverse_block<false>(lo, hi, sh, t.inv, tid);
-            uint64_t* dst = p.lift_dst + (size_t)(p.cnt + e) * kN;
-#pragma unroll
-            for (int r = 0; r < 8; r++) dst[ix_a(tid, r)] = crt_compose_lazy(csub_min(lo[r], kP), hi[r]);
-            return;
-        }
-    }
-    const uint32_t a = b >> 1, row = b & 1u;
-    // ---- the product: sum_k W[row][k] * g[a][k], request two terms ahead of their use
-    uint64_t alo[8] = {}, ahi[8] = {};
-    const uint64_t* wrow = p.w + (size_t)row * p.t * kN;
-    const uint64_t* grow = p.g + (size_t)a * p.t * kN;
-    uint64_t* cvp = p.cv + ((size_t)(2u * a) * 2u + row) * kN;
-    uint64_t old[8], add1[8];
-    pk_load8(cvp, tid, old);
-    if (row == 1) pk_load8(p.a1 + ((size_t)a * 2u + 1u) * kN, tid, add1);
-    for (uint32_t k0 = 0; k0 < p.t; k0 += 2) {
-        uint64_t wv[2][8], gv[2][8];
-#pragma unroll
-        for (uint32_t u = 0; u < 2; u++) {
-            const uint32_t k = min(k0 + u, p.t - 1);
-            pk_load8(wrow + (size_t)k * kN, tid, wv[u]);
-            pk_load8<true>(grow + (size_t)k * kN, tid, gv[u]);
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < 2; u++)
-            if (k0 + u < p.t) {
-#pragma unroll
-                for (int r = 0; r < 8; r++) {  // at most 56 products of a canonical word and a word < 2m: no overflow (lazy_ok)
-                    alo[r] += (uint64_t)lo32(wv[u][r]) * lo32(gv[u][r]);
-                    ahi[r] += (uint64_t)hi32(wv[u][r]) * hi32(gv[u][r]);
-                }
-            }
-    }
-    uint64_t x[8];
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        lo[r] = csub(lo32(old[r]) + mod_p(alo[r]), kP);
-        hi[r] = csub(hi32(old[r]) + mod_b(ahi[r]), kB);
-        if (row == 1) {
-            lo[r] = csub(lo[r] + lo32(add1[r]), kP);
-            hi[r] = csub(hi[r] + hi32(add1[r]), kB);
-        }
-        x[r] = pack(lo[r], hi[r]);
-    }
-    pk_store8(cvp, tid, x);
-    if constexpr (NEXT == FUSED_LIFT) {
-        if (row == 0) {
-            ntt_inverse_block<false>(lo, hi, sh, t.inv, tid);
-            uint64_t* dst = p.lift_dst + (size_t)a * kN;
-#pragma unroll
-            for (int r = 0; r < 8; r++) dst[ix_a(tid, r)] = crt_compose_lazy(csub_min(lo[r], kP), hi[r]);
-        }
-    } else {
-        // the child created for the next round: cv[2a + next_num_in] = neg1 * cv[2a]
-        uint64_t y[8];
-        {
-            uint64_t nw[8], nws[8];
-            pk_load8(p.neg1n, tid, nw);
-            pk_load8(p.neg1ns, tid, nws);
-#pragma unroll
-            for (int r = 0; r < 8; r++)
-                y[r] = pack(csub(shoup(lo[r], lo32(nw[r]), lo32(nws[r]), kP), kP), csub(shoup(hi[r], hi32(nw[r]), hi32(nws[r]), kB), kB));
-            pk_store8(p.cv + ((size_t)(2u * a + p.next_num_in) * 2u + row) * kN, tid, y);
-        }
-#pragma unroll 1
-        for (uint32_t child = 0; child < 2; child++) {
-            const uint32_t an = a + child * p.cnt;  // the child's position among the next round's active ciphertexts
-            if (child == 1) {
-                __syncthreads();  // the first child's last LDS reads
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    x[r] = y[r];
-                    lo[r] = lo32(y[r]);
-                    hi[r] = hi32(y[r]);
-                }
-            }
-            if (row == 0) {  // as ntt_inverse_kernel<., EXPAND>: lift, stored already automorphed
-                ntt_inverse_block<false>(lo, hi, sh, t.inv, tid);
-                __syncthreads();
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    const uint32_t e = (ix_a(tid, r) * p.auto_t) & (2u * kN - 1u);
-                    const uint64_t v = crt_compose_lazy(csub_min(lo[r], kP), hi[r]);
-                    sh[lds_ix(e & (kN - 1u))] = (e & kN) ? kQ - v : v;
-                }
-                __syncthreads();
-                pk_u64x2* dst = reinterpret_cast<pk_u64x2*>(p.dst + (size_t)(2u * an) * kN) + tid;
-#pragma unroll
-                for (int q = 0; q < 4; q++) dst[q * 256] = pk_u64x2{sh[lds_ix(512u * q + 2u * tid)], sh[lds_ix(512u * q + 2u * tid + 1u)]};
-            } else {  // the automorphism of row 1 in the transform domain: a slot permutation, through LDS (slot order)
-#pragma unroll
-                for (int r = 0; r < 8; r++) sh[lds_ix(8u * tid + r)] = x[r];
-                __syncthreads();
-                uint64_t o[8];
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    const uint32_t e = ((2u * (__brev(8u * tid + r) >> 21) + 1u) * p.auto_t) & (2u * kN - 1u);
-                    o[r] = sh[lds_ix(__brev(e >> 1) >> 21)];
-                }
-                pk_store8(p.dst + (size_t)(2u * an + 1u) * kN, tid, o);
-            }
-        }
-    }
-}
-void launch_expand_fused(const DeviceTables& t, const ExpandFusedParams& p, uint32_t next, hipStream_t s) {
-    if (p.cnt == 0) return;
-    Tables tb{t.fwd, t.inv};
-    if (next == FUSED_NEXT_ROUND)
-        hipLaunchKernelGGL(expand_fused_kernel<FUSED_NEXT_ROUND>, dim3(2u * p.cnt), dim3(256), 0, s, tb, p);
-    else
-        hipLaunchKernelGGL(expand_fused_kernel<FUSED_LIFT>, dim3(2u * p.cnt + p.n_extra), dim3(256), 0, s, tb, p);
-}
-
 // Fold chain: the inverse transform + CRT lift of a PK polynomial (a first-dimension accumulator, or the previous fold
 // round's product) followed in registers by the balanced digits and forward transforms the next fold round consumes
 // (nttInvAndCrtLiftCiphertexts / from_ntt then split_and_crt, src/spiral.cpp:1349-1410, 270-330).  The inverse leaves
