@@ -10,7 +10,9 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libspiral_gpu.so")
+# SPIRAL_LIB=<path>: load another build of the library (tuning A/B runs, tools/build_variants.sh); every process of a multi-rank run
+# inherits it.  A variant that lacks a declared entry point loses that binding with a message instead of failing the import.
+LIB_PATH = os.environ.get("SPIRAL_LIB") or os.path.join(HERE, "libspiral_gpu.so")
 CSRC = os.path.join(HERE, "csrc")
 
 
@@ -176,7 +178,13 @@ def lib() -> C.CDLL:
                 "there is no CPU fallback"
             )
         L = C.CDLL(LIB_PATH)
-        for name, (res, args) in PROTOTYPES.items():
+        for name, (res, args) in list(PROTOTYPES.items()):
+            if os.environ.get("SPIRAL_LIB") and not hasattr(L, name):
+                import sys
+
+                print(f"spiral_amd: {LIB_PATH} does not export {name}", file=sys.stderr)
+                del PROTOTYPES[name]
+                continue
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args

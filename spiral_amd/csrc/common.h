@@ -148,6 +148,6 @@ __device__ __forceinline__ uint64_t rescale_dev(uint64_t a, uint64_t inp_mod, ui
 }
 
 // include/util.h:34-38
-__host__ __device__ inline uint32_t get_bits_per(uint32_t dim) { return dim == 56 ? 1u : 56u / dim + 1u; }
+__host__ __device__ constexpr uint32_t get_bits_per(uint32_t dim) { return dim == 56 ? 1u : 56u / dim + 1u; }
 
 }  // namespace spiral

@@ -144,6 +144,23 @@ struct FoldChainParams {
 };
 void launch_fold_chain(const DeviceTables& t, const FoldChainParams& p, uint32_t n_src, hipStream_t s);
 
+// fold round on pairs (ntt.hip fold_pair_kernel): PK polynomials [2*np][3][2] -> for every pair (i, np + i) and polynomial
+// (r, c) the digit DIFFERENCES G^-1(C[np + i]) - G^-1(C[i]), transformed, in the layout D'[i][r + 3k][c] ([np][m2][2]); the
+// round's product is then out[i] = C[i] + Q * D'[i] (launch_fold_mac with an addend).  Exact only when the balanced digits
+// recompose their value (fold_pair_exact).
+struct FoldPairParams {
+    const uint64_t* src;
+    uint64_t* dst;
+    uint32_t ell, bits, fold_np;
+    uint32_t pre_reduce;  // 1: fields are lazy sums (< 2^32), reduce mod m first
+    uint32_t dpb;         // digits per block, 1 .. ell (every block repeats the two inverse transforms)
+    uint32_t lazy_out;    // 1: digit transforms left in [0, 2m)
+};
+// split_and_crt's digits recompose the value exactly -- no borrow is lost at the top of the second carry chain -- when the
+// digits cover at least 57 bits (values are below Q < 2^56) and every shift is a defined one
+constexpr bool fold_pair_exact(uint32_t ell) { return ell >= 2 && ell * get_bits_per(ell) >= 57 && (ell - 1) * get_bits_per(ell) < 64; }
+void launch_fold_pair(const DeviceTables& t, const FoldPairParams& p, uint32_t n_pairs, hipStream_t s);
+
 // ---- layout conversion at the C-ABI boundary -------------------------------------------------------
 // reference polynomial b <-> packed polynomial pk_map(b)
 void launch_ref_to_pk(const uint64_t* ref, uint64_t* pk, uint32_t npolys, IndexMap pk_map, hipStream_t s);
@@ -160,7 +177,10 @@ struct MatmulParams {
 };
 void launch_matmul(const MatmulParams& p, uint32_t batch, hipStream_t s);
 // fold product: out[i][3][2] = key[3][K] * d[i][K][2], K = 2*m2 (src/spiral.cpp:1361-1383)
-void launch_fold_mac(const uint64_t* key, const uint64_t* d, uint64_t* out, uint32_t K, uint32_t np, hipStream_t s);
+// key_stride: polynomials between the key's rows (K when the rows are K long; 2*m2 with K = m2 to take one half of [Q_neg | Q]);
+// addend: optional [np][3][2] PK polynomials added to the products (fields may be any u32: lazy sums are fine)
+void launch_fold_mac(const uint64_t* key, const uint64_t* d, uint64_t* out, uint32_t K, uint32_t np, hipStream_t s, uint32_t key_stride = 0,
+                     const uint64_t* addend = nullptr);
 // out = (a + b) mod m ; out = single * a (src/poly.cpp:138,190)
 void launch_add(const uint64_t* a, const uint64_t* b, uint64_t* out, uint32_t npolys, hipStream_t s);
 void launch_mul_by_const(const uint64_t* single, const uint64_t* a, uint64_t* out, uint32_t npolys, hipStream_t s);

@@ -484,6 +484,73 @@ __global__ __launch_bounds__(256) void fold_chain_kernel(Tables t, FoldChainPara
     }
 }
 
+// Fold round on PAIRS (src/spiral.cpp:1349-1383 computed through an identity).  The reference folds ciphertexts L = C[i] and
+// H = C[np + i] into  Q_neg G^-1(L) + Q G^-1(H)  with Q_neg = NTT(G2 - INTT(Q)), i.e. Q_neg = G2 - Q slot by slot (:2361-2379).
+// Everything is exact arithmetic mod p and mod b, so that is  G2 G^-1(L) + Q (G^-1(H) - G^-1(L)),  and G2 G^-1(L) recomposes L:
+// split_and_crt's balanced digits d_k (:270-330) satisfy sum_k 2^(bits k) d_k = value over the integers whenever the last digit
+// of the second carry chain never borrows, which holds for ell * bits >= 57 (the value is below Q < 2^56, so its top piece is at
+// most 2^(bits - 1); the host checks the condition and otherwise keeps the two-product form).  Hence
+//     out[i] = L + Q * NTT(G^-1(H) - G^-1(L))      -- L's own transform-domain words, which the round already has --
+// with the same canonical residues as the reference: HALF the forward transforms (ell per polynomial pair instead of 2 ell),
+// half the digit operand, a product of K = m2 terms against the Q half of the key instead of 2 m2.
+// A block takes polynomial (r, c) of pair i: both inverse transforms side by side on one twiddle fetch (ntt_inverse_block2),
+// both CRT lifts in registers, then for its dpb digits k the per-coefficient digit difference (an integer in (-1.5 B, 1.5 B),
+// stored as its residues) and one forward transform.  Operand layout D'[i][r + 3 k][c] ([np][m2][2]).
+template <bool SMALL>
+__device__ __forceinline__ int32_t sdigit_signed(uint64_t v, const SDigit& d) {
+    const uint64_t dig = d.sh_digit >= 64 ? 0ull : ((v >> d.sh_digit) & d.mask);
+    const uint64_t low = d.sh_chain >= 64 ? 0ull : ((v >> d.sh_chain) & d.low_mask);
+    const uint32_t piece = (uint32_t)dig + ((d.has_in && low > d.thresh_in) ? 1u : 0u);
+    const bool borrow = piece > (uint32_t)d.thresh && d.may;
+    return borrow ? (int32_t)piece - (int32_t)(uint32_t)d.base : (int32_t)piece;
+}
+__global__ __launch_bounds__(256) void fold_pair_kernel(Tables t, FoldPairParams p) {
+    __shared__ uint64_t sh[2][kLdsWords];
+    const uint32_t tid = threadIdx.x, b = blockIdx.x;
+    const uint32_t cpp = (p.ell + p.dpb - 1u) / p.dpb;
+    const uint32_t s = b / cpp, k0 = (b - s * cpp) * p.dpb, k1 = min(k0 + p.dpb, p.ell);
+    const uint32_t i = s / 6u, rc = s - i * 6u, row = rc >> 1, c = rc & 1u;
+    uint32_t lo[8], hi[8];
+    uint64_t vl[8], vh[8];
+    {
+        uint32_t lo1[8], hi1[8];
+        pk_load8_red(p.src + ((size_t)i * 6u + rc) * kN, p.pre_reduce != 0, tid, lo, hi);
+        pk_load8_red(p.src + ((size_t)(p.fold_np + i) * 6u + rc) * kN, p.pre_reduce != 0, tid, lo1, hi1);
+        ntt_inverse_block2<false>(lo, hi, lo1, hi1, sh[0], sh[1], t.inv, tid);
+        crt_lift8(lo, hi, vl);
+        crt_lift8(lo1, hi1, vh);
+    }
+    const uint32_t m2 = 3u * p.ell;
+    for (uint32_t k = k0; k < k1; k++) {
+        const SDigit sd = sdigit_setup(k, p.bits, p.ell);
+        if (p.bits <= kSmallDigitBits) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t d = (uint32_t)(sdigit_signed<true>(vh[r], sd) - sdigit_signed<true>(vl[r], sd));
+                lo[r] = min(d, d + kP);  // a negative difference wraps to a huge d, and d + m back into [0, m)
+                hi[r] = min(d, d + kB);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                uint32_t ap, ab, bp, bb;
+                sdigit_of<false>(vh[r], sd, ap, ab);
+                sdigit_of<false>(vl[r], sd, bp, bb);
+                // (wide digits: sdigit_of leaves residues below 2^28, which may exceed b)
+                const uint32_t dp = csub_min(ap, kP) - csub_min(bp, kP), db = csub_min(ab, kB) - csub_min(bb, kB);
+                lo[r] = min(dp, dp + kP);
+                hi[r] = min(db, db + kB);
+            }
+        }
+        if (k > k0) __syncthreads();  // the previous transform's last LDS reads
+        ntt_forward_block<false>(lo, hi, sh[0], t.fwd, tid);
+        if (!p.lazy_out) canonicalize8(lo, hi);
+        uint64_t x[8];
+        pk_pack8(lo, hi, x);
+        pk_store8(p.dst + ((size_t)(i * m2 + row + 3u * k) * 2u + c) * kN, tid, x);
+    }
+}
+
 __global__ __launch_bounds__(256) void ref_to_pk_kernel(const uint64_t* ref, uint64_t* pk, IndexMap pk_map) {
     const size_t poly = blockIdx.y;
     const uint32_t z = blockIdx.x * 256u + threadIdx.x;
@@ -539,6 +606,12 @@ void launch_fold_chain(const DeviceTables& t, const FoldChainParams& p, uint32_t
     if (n_src == 0) return;
     Tables tb{t.fwd, t.inv};
     hipLaunchKernelGGL(fold_chain_kernel, dim3(n_src * ((p.ell + p.dpb - 1u) / p.dpb)), dim3(256), 0, s, tb, p);
+}
+
+void launch_fold_pair(const DeviceTables& t, const FoldPairParams& p, uint32_t n_pairs, hipStream_t s) {
+    if (n_pairs == 0) return;
+    Tables tb{t.fwd, t.inv};
+    hipLaunchKernelGGL(fold_pair_kernel, dim3(n_pairs * ((p.ell + p.dpb - 1u) / p.dpb)), dim3(256), 0, s, tb, p);
 }
 
 void launch_ref_to_pk(const uint64_t* ref, uint64_t* pk, uint32_t npolys, IndexMap pk_map, hipStream_t s) {

@@ -48,6 +48,8 @@ struct FoldMacParams {
     const uint64_t* d;    // [np][K][2]
     uint64_t* out;        // [np][3][2]
     uint32_t K;
+    uint32_t ks;          // polynomials between key rows (>= K)
+    const uint64_t* add;  // optional addend [np][3][2] (the pair form: out = C[i] + Q * D'), fields any u32
 };
 // B ciphertexts per workgroup share every key word loaded (the key is common to all ciphertexts of a round)
 template <uint32_t B>
@@ -57,6 +59,16 @@ __global__ __launch_bounds__(kTpb) void fold_mac_kernel(FoldMacParams p) {
     const uint64_t* dp = p.d + (size_t)i0 * p.K * 2 * kN + z;
     const uint64_t* kp = p.key + z;
     Acc2 acc[B][3][2];
+    if (p.add != nullptr && kg == 0) {  // requested before the product loop
+#pragma unroll
+        for (uint32_t b = 0; b < B; b++)
+#pragma unroll
+            for (uint32_t rc = 0; rc < 6; rc++) {
+                const uint64_t a = p.add[((size_t)(i0 + b) * 6 + rc) * kN + z];
+                acc[b][rc >> 1][rc & 1].lo = lo32(a);
+                acc[b][rc >> 1][rc & 1].hi = hi32(a);
+            }
+    }
     if constexpr (B == 1) {
         // The latency-bound rounds (np < 16): "request all 12 terms of the k-group (K = 6 t_GSW = 48), then multiply".  With the loads inside
         // a loop whose every iteration may be the last, the compiler waits for each term before requesting the next -- 12 dependent
@@ -70,7 +82,7 @@ __global__ __launch_bounds__(kTpb) void fold_mac_kernel(FoldMacParams p) {
             for (uint32_t u = 0; u < U; u++) {
                 const uint32_t mm = min(m0 + 4 * u, p.K - 1);
 #pragma unroll
-                for (uint32_t r = 0; r < 3; r++) kv[u][r] = kp[((size_t)r * p.K + mm) * kN];
+                for (uint32_t r = 0; r < 3; r++) kv[u][r] = kp[((size_t)r * p.ks + mm) * kN];
                 dv[u][0] = __builtin_nontemporal_load(&dp[(size_t)mm * 2 * kN]);
                 dv[u][1] = __builtin_nontemporal_load(&dp[((size_t)mm * 2 + 1) * kN]);
             }
@@ -90,7 +102,7 @@ __global__ __launch_bounds__(kTpb) void fold_mac_kernel(FoldMacParams p) {
     for (uint32_t mm = kg; mm < p.K; mm += 4) {
         uint64_t kv[3];
 #pragma unroll
-        for (uint32_t r = 0; r < 3; r++) kv[r] = kp[((size_t)r * p.K + mm) * kN];
+        for (uint32_t r = 0; r < 3; r++) kv[r] = kp[((size_t)r * p.ks + mm) * kN];
 #pragma unroll
         for (uint32_t b = 0; b < B; b++) {
 #ifndef MAC_PLAIN_LOADS  // streamed operand: read once, must not push the shared W / key rows out of L2 (-17 us on expand + convert)
@@ -135,9 +147,9 @@ __global__ __launch_bounds__(kTpb) void fold_mac_kernel(FoldMacParams p) {
                 }
     }
 }
-void launch_fold_mac(const uint64_t* key, const uint64_t* d, uint64_t* out, uint32_t K, uint32_t np, hipStream_t s) {
+void launch_fold_mac(const uint64_t* key, const uint64_t* d, uint64_t* out, uint32_t K, uint32_t np, hipStream_t s, uint32_t key_stride, const uint64_t* addend) {
     if (np == 0) return;
-    FoldMacParams p{key, d, out, K};
+    FoldMacParams p{key, d, out, K, key_stride ? key_stride : K, addend};
     if (np >= 16 && np % 2 == 0)  // wide rounds: 2 ciphertexts per workgroup
         hipLaunchKernelGGL(fold_mac_kernel<2>, dim3(kN / 64, np / 2), dim3(kTpb), 0, s, p);
     else

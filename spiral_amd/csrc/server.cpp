@@ -28,7 +28,7 @@ struct spiral_gpu_server {
     DevBuf db, w_left, w_right, w, v, query, cv, ex_raw, ex_g;
     DevBuf cv_raw, cv_g, gsw, key, cts_keep;
     uint64_t *gs_raw_p = nullptr, *gs_chat_p = nullptr;  // the Regev->GSW halves of cv_raw / cv_g
-    DevBuf qs, acc_own, raw, fold_d, fold_c, resp, stage;
+    DevBuf qs, acc_own, raw, fold_d, fold_c, fold_c2, resp, stage;
     uint64_t* acc = nullptr;
     hipEvent_t ev[8] = {};
     // captured stage groups (hipGraph): [0] expand + convert, [1] lift + fold + finish, [2] the same with
@@ -48,6 +48,9 @@ struct spiral_gpu_server {
     // from ell until the round has at least fold_blocks blocks.  SPIRAL_FOLD_CHAIN=0 (separate lift + digit transforms) and
     // SPIRAL_FOLD_BLOCKS override (tuning / tests).
     bool fold_chain = true;
+    // pair form of a chained fold round (fold_pair_kernel: out = C[i] + Q * NTT(G^-1(C[np+i]) - G^-1(C[i])), half the forward
+    // transforms and half the product); SPIRAL_FOLD_PAIR=0 keeps the reference's two-product form (tests compare both)
+    bool fold_pair = true;
     uint32_t fold_blocks = 768;
     uint32_t fold_g_log = 0;  // distributed fold over 2^fold_g_log ranks: the sweep groups its output by ii mod G
     ExpandShard ex_shard{};   // sharded expansion (set_expand_shard): what this rank expands itself
@@ -105,6 +108,7 @@ int srv_alloc(spiral_gpu_server* S, const spiral_gpu_server* db_owner) {
     const size_t half = s.num_per > 1 ? s.num_per / 2 : 1;
     if (S->fold_d.alloc(half * 2 * s.m2 * 2 * kN)) return -1;
     if (S->fold_c.alloc(half * 6 * kN)) return -1;
+    if (S->fold_c2.alloc(half * 6 * kN)) return -1;
     if (S->resp.alloc((size_t)6 * kN)) return -1;
     return 0;
 }
@@ -120,7 +124,7 @@ void srv_drop_graphs(spiral_gpu_server* S) {
 void srv_free(spiral_gpu_server* S) {
     srv_drop_graphs(S);
     DevBuf* all[] = {&S->db, &S->w_left, &S->w_right, &S->w, &S->v, &S->query, &S->cv, &S->ex_raw, &S->ex_g, &S->cv_raw,
-                     &S->cv_g, &S->gsw, &S->key, &S->cts_keep, &S->qs, &S->acc_own, &S->raw, &S->fold_d, &S->fold_c,
+                     &S->cv_g, &S->gsw, &S->key, &S->cts_keep, &S->qs, &S->acc_own, &S->raw, &S->fold_d, &S->fold_c, &S->fold_c2,
                      &S->resp, &S->stage, &S->wire};
     if (S->db_shared) S->db.p = nullptr;
     for (DevBuf* b : all) b->release();
@@ -595,6 +599,7 @@ static int srv_create(const spiral_gpu_params* p, int device, uint32_t j_begin, 
     S->j1 = j_end;
     S->dim0_shard = j_end - j_begin;
     if (const char* e = getenv("SPIRAL_FOLD_CHAIN")) S->fold_chain = atoi(e) != 0;
+    if (const char* e = getenv("SPIRAL_FOLD_PAIR")) S->fold_pair = atoi(e) != 0;
     if (const char* e = getenv("SPIRAL_FOLD_BLOCKS")) S->fold_blocks = (uint32_t)strtoul(e, nullptr, 10);
     if (p->direct_upload || s.stopround == 0) {
         S->pos_stride = 1;
@@ -1047,10 +1052,29 @@ int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t ro
         launch_ntt_inverse(S->tb, ip, IST_CRT, npolys, S->stream);
         src_pk = nullptr;
     };
+    uint64_t* out_pk = S->fold_c.p;
     for (uint32_t d = d0; d < d0 + rounds; d++) {
         np /= 2;
         const uint32_t n_src = 2 * np * 6;
         const uint64_t* key = S->key.p + (size_t)d * 3 * 2 * s.m2 * kN;
+        if (src_pk == out_pk) out_pk = out_pk == S->fold_c.p ? S->fold_c2.p : S->fold_c.p;  // the pair form's product reads its source
+        if (src_pk && S->fold_chain && S->fold_pair && fold_pair_exact(s.ell)) {
+            FoldPairParams pp{};
+            pp.src = src_pk;
+            pp.dst = S->fold_d.p;
+            pp.ell = s.ell;
+            pp.bits = get_bits_per(s.ell);
+            pp.fold_np = np;
+            pp.pre_reduce = pre_reduce ? 1 : 0;
+            pp.dpb = fold_dpb(S, n_src / 2);
+            pp.lazy_out = lazy_ok(3 * s.ell + 1) ? 1 : 0;  // fold_mac sums m2 = 3 ell products and the addend per accumulator
+            launch_fold_pair(S->tb, pp, n_src / 2, S->stream);
+            // out[i] = C[i] + Q * D'[i]: the Q half of the key rows [Q_neg | Q], the low ciphertexts as the addend
+            launch_fold_mac(key + (size_t)s.m2 * kN, S->fold_d.p, out_pk, s.m2, np, S->stream, 2 * s.m2, src_pk);
+            src_pk = out_pk;
+            pre_reduce = false;
+            continue;
+        }
         if (src_pk && S->fold_chain) {
             FoldChainParams cp{};
             cp.src = src_pk;
@@ -1074,8 +1098,8 @@ int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t ro
             fp.fold_np = np;
             launch_ntt_forward(S->tb, fp, LD_SDIGIT, ST_PK, n_src * s.ell, S->stream);
         }
-        launch_fold_mac(key, S->fold_d.p, S->fold_c.p, 2 * s.m2, np, S->stream);
-        src_pk = S->fold_c.p;
+        launch_fold_mac(key, S->fold_d.p, out_pk, 2 * s.m2, np, S->stream);
+        src_pk = out_pk;
         pre_reduce = false;
     }
     if (src_pk) lift(np * 6);

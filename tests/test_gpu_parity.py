@@ -308,9 +308,13 @@ def test_load_db_in_several_staging_passes(sa, oracle, monkeypatch):
 
 @pytest.mark.parametrize("env", [
     {"SPIRAL_FOLD_CHAIN": "0"},          # separate lift + digit transforms every round
-    {"SPIRAL_FOLD_BLOCKS": "0"},         # fold_chain_kernel, one block per polynomial (all digits) every round
-    {"SPIRAL_FOLD_BLOCKS": "1000000"},   # fold_chain_kernel, one block per (polynomial, digit) every round
+    {"SPIRAL_FOLD_BLOCKS": "0"},         # pair form (fold_pair_kernel), one block per polynomial pair (all digits) every round
+    {"SPIRAL_FOLD_BLOCKS": "1000000"},   # one block per (polynomial pair, digit) every round
     {"SPIRAL_FOLD_BLOCKS": "300"},       # mixed chunk sizes
+    {"SPIRAL_FOLD_PAIR": "0"},                                  # the reference's two-product form Q_neg G^-1(L) + Q G^-1(H) (fold_chain_kernel)
+    {"SPIRAL_FOLD_PAIR": "0", "SPIRAL_FOLD_BLOCKS": "0"},
+    {"SPIRAL_FOLD_PAIR": "0", "SPIRAL_FOLD_BLOCKS": "1000000"},
+    {"SPIRAL_FOLD_PAIR": "0", "SPIRAL_FOLD_BLOCKS": "300"},
 ])
 def test_fold_chain_schedules(sa, oracle, env, monkeypatch):
     """the fold's schedule variants (read from the environment when the server is created) all give the oracle's answer"""

@@ -2,9 +2,6 @@
 SPIRAL_LIB=<path> times an alternative build of the library.  tools/ntt_time.py [batch ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import spiral_amd._lib as L
-if os.environ.get("SPIRAL_LIB"):
-    L.LIB_PATH = os.environ["SPIRAL_LIB"]
 import spiral_amd as sa
 for n in [int(x) for x in sys.argv[1:]] or [256, 1024, 4096, 16384, 65536]:
     f, i = sa.time_ntt(n, 20)

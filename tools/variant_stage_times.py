@@ -1,8 +1,6 @@
 """stage times of answer_resident() with an alternative build of the library (SPIRAL_LIB=path)"""
 import os, sys; sys.path.insert(0, '.')
 import numpy as np
-import spiral_amd._lib as L
-if os.environ.get("SPIRAL_LIB"): L.LIB_PATH = os.environ["SPIRAL_LIB"]
 import spiral_amd as sa
 pg = sa.make_params(8, 7); s = sa.get_shape(pg)
 srv = sa.Server(pg); srv.fill_db_random(3)
