@@ -42,6 +42,7 @@ enum FwdLoad : uint32_t {
     LD_PDIGIT = 6,  // SpiralPack: unsigned reduced digit k (gadget_invert + to_ntt, src/testing.cpp:130-131, 226-227, 612-617)
                     // with the source / destination maps of FwdParams::pmode
     LD_DBGEN1 = 7,  // SpiralPack database: 1 x 1 plaintext of (trial, item), centred lift (src/testing.cpp:845-869)
+    LD_SDIFF = 8,   // fold round in pair form from lifted ciphertexts: difference of the balanced digits k of raw[np + i] and raw[i]
     LD_EXPAND = 5,  // one expansion round: digits of automorph(c)[0] and the reduced automorph(c)[1] of every
                     // active ciphertext, both parities, in one launch      (src/spiral.cpp:1711-1720)
 };
@@ -155,6 +156,7 @@ struct FoldPairParams {
     uint32_t pre_reduce;  // 1: fields are lazy sums (< 2^32), reduce mod m first
     uint32_t dpb;         // digits per block, 1 .. ell (every block repeats the two inverse transforms)
     uint32_t lazy_out;    // 1: digit transforms left in [0, 2m)
+    uint32_t team;        // 1: fold_team_kernel -- 512-thread workgroups, one half per ciphertext of the pair, 2 dpb digits per block
 };
 // split_and_crt's digits recompose the value exactly -- no borrow is lost at the top of the second carry chain -- when the
 // digits cover at least 57 bits (values are below Q < 2^56) and every shift is a defined one

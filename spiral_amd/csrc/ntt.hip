@@ -1,5 +1,6 @@
 // Batched NTT / INTT kernels with fused pre- and post-operations, gfx950.
 // One 256-thread workgroup per output polynomial.  See ntt_device.h for the transform itself.
+#include <cstdlib>
 #include <type_traits>
 
 #include "kernels.h"
@@ -25,6 +26,11 @@ __device__ __forceinline__ uint64_t load_raw(const uint64_t* src, uint32_t idx, 
 
 __device__ __forceinline__ uint64_t digit_of(uint64_t v, uint32_t k, uint32_t bits, uint64_t mask) {
     uint32_t sh = k * bits;
+    if (bits <= 27u) {  // the value's two words and a wave-uniform offset: one v_alignbit instead of a 64-bit shift
+        const bool up = sh >= 32u;
+        const uint32_t d = __builtin_amdgcn_alignbit(up ? 0u : hi32(v), up ? hi32(v) : lo32(v), sh & 31u) & (uint32_t)mask;
+        return sh >= 64 ? 0u : d;
+    }
     return sh >= 64 ? 0ull : ((v >> sh) & mask);  // a shift count >= 64 is UB in src/util.cpp:136; defined as 0
 }
 
@@ -94,6 +100,82 @@ __device__ __forceinline__ void sdigit_of(uint64_t v, const SDigit& d, uint32_t&
         } else {
             rp = digit_residue<false>((uint32_t)piece, kP);
             rb = digit_residue<false>((uint32_t)piece, kB);
+        }
+    }
+}
+
+// The same digit as a signed integer (piece, or piece - 2^bits when it borrows) in 32-bit arithmetic: the value is below 2^56 and
+// every offset is a launch constant, so the digit and the chain's low part are v_alignbit / shift extractions from the value's two
+// words, 9 instructions per value (the 64-bit shifts, masks and compares of the generic form are the most expensive part of a
+// digit loader).  "No carry in" and "never borrows" are encoded in the constants (an empty mask against a full threshold), and
+// which word the digit and the chain start in (DHI, CHI) is a wave-uniform choice made once around the 8-value loop.
+// ok: digits of at most 27 bits whose chain prefix fits one word (j * bits <= 32) -- every published parameter set; the loaders fall
+// back to sdigit_of<false> otherwise.
+struct SDig32 {
+    uint32_t d_sh, d_mask;            // digit: shift within the word pair (or within the high word), mask (0 beyond bit 63)
+    uint32_t c_sh, c_mask, c_thresh;  // chain prefix (the low j digits) and its carry threshold T_j
+    uint32_t base, thresh;
+    bool d_hi, c_hi, ok;              // the digit / the chain starts in the high word
+};
+__device__ __forceinline__ SDig32 sdig32_setup(uint32_t k, uint32_t bits, uint32_t ell) {
+    SDig32 d;
+    const uint32_t half = ell >> 1, start = k < half ? 0u : half, j = k - start;
+    const uint32_t o = k * bits, oc = start * bits, w = j * bits;
+    d.ok = bits <= kSmallDigitBits && w <= 32u;
+    d.base = 1u << (bits & 31u);
+    const bool may = k < half ? (k + 1 < half) : true;
+    d.thresh = may ? d.base >> 1 : ~0u;
+    d.d_hi = o >= 32u;
+    d.d_sh = o & 31u;
+    d.d_mask = o >= 64u ? 0u : d.base - 1u;
+    d.c_hi = oc >= 32u;
+    d.c_sh = oc & 31u;
+    d.c_mask = (j == 0 || oc >= 64u) ? 0u : (w >= 32u ? ~0u : (1u << w) - 1u);
+    uint32_t t = 0;
+    for (uint32_t i = 0; i < j; i++) t = (t << (bits & 31u)) + (d.base >> 1);
+    d.c_thresh = j == 0 ? ~0u : t;
+    return d;
+}
+template <bool DHI, bool CHI>
+__device__ __forceinline__ int32_t sdig32(uint64_t v, const SDig32& d) {
+    const uint32_t lo = lo32(v), hi = hi32(v);
+    uint32_t piece = (DHI ? hi >> d.d_sh : __builtin_amdgcn_alignbit(hi, lo, d.d_sh)) & d.d_mask;
+    const uint32_t low = (CHI ? hi >> d.c_sh : __builtin_amdgcn_alignbit(hi, lo, d.c_sh)) & d.c_mask;
+    piece += low > d.c_thresh ? 1u : 0u;
+    return (int32_t)(piece - (piece > d.thresh ? d.base : 0u));
+}
+// residues of a signed digit / digit difference s, |s| < 2^28: a negative s wraps to a huge u32 and s + m back into [0, m)
+__device__ __forceinline__ void signed_residues(int32_t s, uint32_t& rp, uint32_t& rb) {
+    const uint32_t d = (uint32_t)s;
+    rp = min(d, d + kP);
+    rb = min(d, d + kB);
+}
+// digit differences G^-1(h)_k - G^-1(l)_k of a thread's 8 pairs of lifted coefficients as residues (the pair form of a fold
+// round); H(r), L(r) fetch the values (registers or LDS)
+template <class FH, class FL>
+__device__ __forceinline__ void sdigit_diff8(FH H, FL L, uint32_t k, uint32_t bits, uint32_t ell, uint32_t* lo, uint32_t* hi) {
+    const SDig32 d = sdig32_setup(k, bits, ell);
+    if (d.ok) {
+        if (!d.d_hi) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) signed_residues(sdig32<false, false>(H(r), d) - sdig32<false, false>(L(r), d), lo[r], hi[r]);
+        } else if (!d.c_hi) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) signed_residues(sdig32<true, false>(H(r), d) - sdig32<true, false>(L(r), d), lo[r], hi[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; r++) signed_residues(sdig32<true, true>(H(r), d) - sdig32<true, true>(L(r), d), lo[r], hi[r]);
+        }
+    } else {  // wide digits or long chains: sdigit_of leaves residues below 2^28, which may exceed b
+        const SDigit sd = sdigit_setup(k, bits, ell);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            uint32_t ap, ab, bp, bb;
+            sdigit_of<false>(H(r), sd, ap, ab);
+            sdigit_of<false>(L(r), sd, bp, bb);
+            const uint32_t dp = csub_min(ap, kP) - csub_min(bp, kP), db = csub_min(ab, kB) - csub_min(bb, kB);
+            lo[r] = min(dp, dp + kP);
+            hi[r] = min(db, db + kB);
         }
     }
 }
@@ -219,6 +301,19 @@ __global__ __launch_bounds__(256, 8) void ntt_forward_kernel(Tables t, FwdParams
         };
         DIGIT_WIDTH_DISPATCH(bits, body);
         s = b;
+    } else if constexpr (LOAD == LD_SDIFF) {
+        // pair form of a fold round from lifted ciphertexts (see fold_pair_kernel): source s = (pair i, r, c) over [np][3][2],
+        // L = raw[i][r][c], H = raw[np + i][r][c]; the digit difference G^-1(H)_k - G^-1(L)_k as residues
+        const uint32_t i = s / 6u, rc = s - i * 6u;
+        const uint64_t* sl = p.src + ((size_t)i * 6u + rc) * kN;
+        const uint64_t* sh_ = p.src + ((size_t)(p.fold_np + i) * 6u + rc) * kN;
+        uint64_t rl[8], rh[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            rl[r] = sl[ix_a(tid, r)];
+            rh[r] = sh_[ix_a(tid, r)];
+        }
+        sdigit_diff8([&](int r) { return rh[r]; }, [&](int r) { return rl[r]; }, k, p.bits, p.ell, lo, hi);
     } else if constexpr (LOAD == LD_LIMBS) {
         const uint64_t* src = p.src + (size_t)p.src_map(s) * (2 * kN);
 #pragma unroll
@@ -279,6 +374,9 @@ __global__ __launch_bounds__(256, 8) void ntt_forward_kernel(Tables t, FwdParams
             } else {
                 di = s * nd + k;
             }
+        } else if constexpr (LOAD == LD_SDIFF) {
+            const uint32_t i = s / 6u, rc = s - i * 6u;  // operand layout D'[i][r + 3k][c]
+            di = (i * 3u * p.ell + (rc >> 1) + 3u * k) * 2u + (rc & 1u);
         } else if constexpr (LOAD == LD_SDIGIT) {
             // source s = (ct i', r, c) over [2*np][3][2]; operand layout D[i' % np][(i' / np)*m2 + r + 3k][c]
             const uint32_t ct = s / 6u, rc = s - ct * 6u, r = rc >> 1, c = rc & 1u;
@@ -313,6 +411,75 @@ __global__ __launch_bounds__(256, 8) void ntt_forward_kernel(Tables t, FwdParams
         const uint32_t ic = ii * 2u + c, nic = 2u * p.num_per;
 #pragma unroll
         for (int r = 0; r < 8; r++) db_put_word(p.dst, pk_pos_tk(tid, r), j - p.j0, ic, m, nic, p.dim0_shard, pack(lo[r], hi[r]));  // z = pk_pos(slot)
+    }
+}
+
+// Two gadget digits of one source polynomial per workgroup (LD_DIGIT / LD_EXPAND, ST_PK): the source is read once for both and
+// the two forward transforms share every twiddle fetch (ntt_forward_block2).  Job b2 = (source, digit pair kk): digits 2kk and
+// 2kk + 1 (the second absent when the digit count is odd); destinations and results exactly those of ntt_forward_kernel.
+template <uint32_t LOAD>
+__global__ __launch_bounds__(256) void ntt_forward2_kernel(Tables t, FwdParams p) {
+    __shared__ uint64_t sh[2][kLdsWords];
+    const uint32_t tid = threadIdx.x, b2 = blockIdx.x;
+    uint32_t tdim, kk, ob;  // digits per source, pair index, job id of digit 0 of this source in ntt_forward_kernel's numbering
+    const uint64_t* src;
+    uint32_t bits;
+    if constexpr (LOAD == LD_EXPAND) {
+        const uint32_t jpe = (p.t_e + 1u) >> 1, jpo = (p.t_o + 1u) >> 1, je2 = p.cnt_e * jpe;
+        uint32_t a;
+        if (b2 < je2) {
+            tdim = p.t_e;
+            a = b2 / jpe;
+            kk = b2 - a * jpe;
+            ob = a * tdim;
+        } else {
+            tdim = p.t_o;
+            const uint32_t bb = b2 - je2;
+            a = bb / jpo;
+            kk = bb - a * jpo;
+            ob = p.cnt_e * p.t_e + a * tdim;
+            a += p.cnt_e;
+        }
+        src = p.src + (size_t)a * 2u * kN;
+        bits = get_bits_per(tdim);
+    } else {
+        tdim = p.n_digits;
+        const uint32_t jp = (tdim + 1u) >> 1, s = b2 / jp;
+        kk = b2 - s * jp;
+        ob = s * tdim;
+        src = p.src + (size_t)p.src_map(s) * kN;
+        bits = p.bits;
+    }
+    uint64_t raw[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) raw[r] = src[ix_a(tid, r)];
+    const uint32_t k0 = 2u * kk, k1 = k0 + 1u;
+    const bool two = k1 < tdim;
+    const uint64_t mask = (1ull << bits) - 1;
+    uint32_t lo0[8], hi0[8], lo1[8], hi1[8];
+    auto body = [&](auto small) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t d0 = (uint32_t)digit_of(raw[r], k0, bits, mask), d1 = (uint32_t)digit_of(raw[r], k1, bits, mask);
+            lo0[r] = digit_residue<decltype(small)::value>(d0, kP);
+            hi0[r] = digit_residue<decltype(small)::value>(d0, kB);
+            lo1[r] = digit_residue<decltype(small)::value>(d1, kP);
+            hi1[r] = digit_residue<decltype(small)::value>(d1, kB);
+        }
+    };
+    DIGIT_WIDTH_DISPATCH(bits, body);
+    ntt_forward_block2<false>(lo0, hi0, lo1, hi1, sh[0], sh[1], t.fwd, tid);
+    const bool lazy = LOAD == LD_EXPAND || p.lazy_out != 0;
+    if (!lazy) {
+        canonicalize8(lo0, hi0);
+        canonicalize8(lo1, hi1);
+    }
+    uint64_t v[8];
+    pk_pack8(lo0, hi0, v);
+    pk_store8(p.dst + (size_t)p.dst_map(ob + k0) * kN, tid, v);
+    if (two) {
+        pk_pack8(lo1, hi1, v);
+        pk_store8(p.dst + (size_t)p.dst_map(ob + k1) * kN, tid, v);
     }
 }
 
@@ -496,14 +663,6 @@ __global__ __launch_bounds__(256) void fold_chain_kernel(Tables t, FoldChainPara
 // A block takes polynomial (r, c) of pair i: both inverse transforms side by side on one twiddle fetch (ntt_inverse_block2),
 // both CRT lifts in registers, then for its dpb digits k the per-coefficient digit difference (an integer in (-1.5 B, 1.5 B),
 // stored as its residues) and one forward transform.  Operand layout D'[i][r + 3 k][c] ([np][m2][2]).
-template <bool SMALL>
-__device__ __forceinline__ int32_t sdigit_signed(uint64_t v, const SDigit& d) {
-    const uint64_t dig = d.sh_digit >= 64 ? 0ull : ((v >> d.sh_digit) & d.mask);
-    const uint64_t low = d.sh_chain >= 64 ? 0ull : ((v >> d.sh_chain) & d.low_mask);
-    const uint32_t piece = (uint32_t)dig + ((d.has_in && low > d.thresh_in) ? 1u : 0u);
-    const bool borrow = piece > (uint32_t)d.thresh && d.may;
-    return borrow ? (int32_t)piece - (int32_t)(uint32_t)d.base : (int32_t)piece;
-}
 __global__ __launch_bounds__(256) void fold_pair_kernel(Tables t, FoldPairParams p) {
     __shared__ uint64_t sh[2][kLdsWords];
     const uint32_t tid = threadIdx.x, b = blockIdx.x;
@@ -522,32 +681,48 @@ __global__ __launch_bounds__(256) void fold_pair_kernel(Tables t, FoldPairParams
     }
     const uint32_t m2 = 3u * p.ell;
     for (uint32_t k = k0; k < k1; k++) {
-        const SDigit sd = sdigit_setup(k, p.bits, p.ell);
-        if (p.bits <= kSmallDigitBits) {
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const uint32_t d = (uint32_t)(sdigit_signed<true>(vh[r], sd) - sdigit_signed<true>(vl[r], sd));
-                lo[r] = min(d, d + kP);  // a negative difference wraps to a huge d, and d + m back into [0, m)
-                hi[r] = min(d, d + kB);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                uint32_t ap, ab, bp, bb;
-                sdigit_of<false>(vh[r], sd, ap, ab);
-                sdigit_of<false>(vl[r], sd, bp, bb);
-                // (wide digits: sdigit_of leaves residues below 2^28, which may exceed b)
-                const uint32_t dp = csub_min(ap, kP) - csub_min(bp, kP), db = csub_min(ab, kB) - csub_min(bb, kB);
-                lo[r] = min(dp, dp + kP);
-                hi[r] = min(db, db + kB);
-            }
-        }
+        sdigit_diff8([&](int r) { return vh[r]; }, [&](int r) { return vl[r]; }, k, p.bits, p.ell, lo, hi);
         if (k > k0) __syncthreads();  // the previous transform's last LDS reads
         ntt_forward_block<false>(lo, hi, sh[0], t.fwd, tid);
         if (!p.lazy_out) canonicalize8(lo, hi);
         uint64_t x[8];
         pk_pack8(lo, hi, x);
         pk_store8(p.dst + ((size_t)(i * m2 + row + 3u * k) * 2u + c) * kN, tid, x);
+    }
+}
+
+// The same round with TWO 256-thread halves per workgroup (512 threads): half 0 inverse-transforms and lifts L, half 1 H, at
+// the same time and each in its own LDS tile; the lifted polynomials cross through the tiles (16 KiB each way), after which
+// each half transforms its own dpb of the block's 2 dpb digit differences.  No inverse transform is repeated when a pair's
+// digits all sit in one block (wide rounds: 1 + ell/2 transforms deep instead of 2 + ell), and the latency-bound rounds are
+// one inverse + one forward transform deep (dpb = 1) instead of two + one.  Every thread passes the same barriers: the digit
+// loop runs dpb times in both halves, a digit index beyond ell is computed on a clamped index and not stored.
+__global__ __launch_bounds__(512, 4) void fold_team_kernel(Tables t, FoldPairParams p) {
+    __shared__ uint64_t sh[2][kLdsWords];
+    __shared__ uint64_t vb[2][kN];  // the lifted polynomials L, H: read back per digit instead of held in 32 VGPRs
+    const uint32_t half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), tid = threadIdx.x & 255u, b = blockIdx.x;
+    uint64_t* mine = sh[half];
+    const uint32_t per_block = 2u * p.dpb, cpp = (p.ell + per_block - 1u) / per_block;
+    const uint32_t s = b / cpp, k0 = (b - s * cpp) * per_block + half * p.dpb;
+    const uint32_t i = s / 6u, rc = s - i * 6u, row = rc >> 1, c = rc & 1u;
+    uint32_t lo[8], hi[8];
+    pk_load8_red(p.src + ((size_t)(half * p.fold_np + i) * 6u + rc) * kN, p.pre_reduce != 0, tid, lo, hi);
+    ntt_inverse_block<false>(lo, hi, mine, t.inv, tid);
+#pragma unroll
+    for (int r = 0; r < 8; r++) vb[half][ix_a(tid, r)] = crt_compose_lazy(csub_min(lo[r], kP), hi[r]);
+    __syncthreads();  // both lifted polynomials are in vb; the inverse transforms' last tile reads are done
+    const uint32_t m2 = 3u * p.ell;
+    for (uint32_t it = 0; it < p.dpb; it++) {
+        const uint32_t kq = k0 + it, k = min(kq, p.ell - 1u);
+        sdigit_diff8([&](int r) { return vb[1][ix_a(tid, r)]; }, [&](int r) { return vb[0][ix_a(tid, r)]; }, k, p.bits, p.ell, lo, hi);  // H - L
+        if (it > 0) __syncthreads();  // the previous transform's last LDS reads
+        ntt_forward_block<false>(lo, hi, mine, t.fwd, tid);
+        if (!p.lazy_out) canonicalize8(lo, hi);
+        if (kq < p.ell) {
+            uint64_t x[8];
+            pk_pack8(lo, hi, x);
+            pk_store8(p.dst + ((size_t)(i * m2 + row + 3u * k) * 2u + c) * kN, tid, x);
+        }
     }
 }
 
@@ -574,10 +749,27 @@ __global__ __launch_bounds__(256) void pk_to_ref_kernel(const uint64_t* pk, uint
 void launch_ntt_forward(const DeviceTables& t, const FwdParams& p, uint32_t load, uint32_t store, uint32_t nblocks, hipStream_t s) {
     if (nblocks == 0) return;
     Tables tb{t.fwd, t.inv};
+    // Two digits per workgroup on one twiddle fetch (ntt_forward2_kernel) pay in steady state only -- 14-24 % from 16 k transforms up, nothing
+    // at one or two generations of resident workgroups (profiles/r04_twiddle_sharing.txt): used from kFwd2Min transforms per launch.
+    // SPIRAL_FWD2=0 / 1 forces it off / on (tests, A/B).
+    constexpr uint32_t kFwd2Min = 8192;
+    static const int fwd2_env = getenv("SPIRAL_FWD2") ? atoi(getenv("SPIRAL_FWD2")) : -1;
+    const bool fwd2 = fwd2_env >= 0 ? fwd2_env != 0 : nblocks >= kFwd2Min;
+    if (fwd2 && store == ST_PK && load == LD_DIGIT && p.n_digits >= 2) {
+        const uint32_t nsrc = nblocks / p.n_digits;
+        hipLaunchKernelGGL((ntt_forward2_kernel<LD_DIGIT>), dim3(nsrc * ((p.n_digits + 1u) / 2u)), dim3(256), 0, s, tb, p);
+        return;
+    }
+    if (fwd2 && store == ST_PK && load == LD_EXPAND) {
+        const uint32_t cnt_o = p.t_o ? (nblocks - p.cnt_e * p.t_e) / p.t_o : 0u;
+        hipLaunchKernelGGL((ntt_forward2_kernel<LD_EXPAND>), dim3(p.cnt_e * ((p.t_e + 1u) / 2u) + cnt_o * ((p.t_o + 1u) / 2u)), dim3(256), 0, s, tb, p);
+        return;
+    }
     FWD_CASE(LD_RAW, ST_PK)
     FWD_CASE(LD_RAW, ST_REF)
     FWD_CASE(LD_DIGIT, ST_PK)
     FWD_CASE(LD_SDIGIT, ST_PK)
+    FWD_CASE(LD_SDIFF, ST_PK)
     FWD_CASE(LD_LIMBS, ST_REF)
     FWD_CASE(LD_LIMBS, ST_PK)
     FWD_CASE(LD_DBGEN, ST_DB)
@@ -611,6 +803,10 @@ void launch_fold_chain(const DeviceTables& t, const FoldChainParams& p, uint32_t
 void launch_fold_pair(const DeviceTables& t, const FoldPairParams& p, uint32_t n_pairs, hipStream_t s) {
     if (n_pairs == 0) return;
     Tables tb{t.fwd, t.inv};
+    if (p.team) {
+        hipLaunchKernelGGL(fold_team_kernel, dim3(n_pairs * ((p.ell + 2u * p.dpb - 1u) / (2u * p.dpb))), dim3(512), 0, s, tb, p);
+        return;
+    }
     hipLaunchKernelGGL(fold_pair_kernel, dim3(n_pairs * ((p.ell + p.dpb - 1u) / p.dpb)), dim3(256), 0, s, tb, p);
 }
 

@@ -51,6 +51,10 @@ struct spiral_gpu_server {
     // pair form of a chained fold round (fold_pair_kernel: out = C[i] + Q * NTT(G^-1(C[np+i]) - G^-1(C[i])), half the forward
     // transforms and half the product); SPIRAL_FOLD_PAIR=0 keeps the reference's two-product form (tests compare both)
     bool fold_pair = true;
+    // pair-form rounds with at least this many polynomial pairs run unchained (lift launch + LD_SDIFF digit launch + product); the
+    // narrower ones chain the lift into the digit transforms (one launch less).  SPIRAL_FOLD_UNCHAIN_MIN overrides.
+    uint32_t fold_unchain_min = 48;
+    bool fold_team = true;  // SPIRAL_FOLD_TEAM=0: fold_pair_kernel (one 256-thread workgroup runs both inverse transforms)
     uint32_t fold_blocks = 768;
     uint32_t fold_g_log = 0;  // distributed fold over 2^fold_g_log ranks: the sweep groups its output by ii mod G
     ExpandShard ex_shard{};   // sharded expansion (set_expand_shard): what this rank expands itself
@@ -600,6 +604,8 @@ static int srv_create(const spiral_gpu_params* p, int device, uint32_t j_begin, 
     S->dim0_shard = j_end - j_begin;
     if (const char* e = getenv("SPIRAL_FOLD_CHAIN")) S->fold_chain = atoi(e) != 0;
     if (const char* e = getenv("SPIRAL_FOLD_PAIR")) S->fold_pair = atoi(e) != 0;
+    if (const char* e = getenv("SPIRAL_FOLD_TEAM")) S->fold_team = atoi(e) != 0;
+    if (const char* e = getenv("SPIRAL_FOLD_UNCHAIN_MIN")) S->fold_unchain_min = (uint32_t)strtoul(e, nullptr, 10);
     if (const char* e = getenv("SPIRAL_FOLD_BLOCKS")) S->fold_blocks = (uint32_t)strtoul(e, nullptr, 10);
     if (p->direct_upload || s.stopround == 0) {
         S->pos_stride = 1;
@@ -1058,6 +1064,31 @@ int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t ro
         const uint32_t n_src = 2 * np * 6;
         const uint64_t* key = S->key.p + (size_t)d * 3 * 2 * s.m2 * kN;
         if (src_pk == out_pk) out_pk = out_pk == S->fold_c.p ? S->fold_c2.p : S->fold_c.p;  // the pair form's product reads its source
+        if (src_pk && S->fold_chain && S->fold_pair && fold_pair_exact(s.ell) && n_src / 2 >= S->fold_unchain_min) {
+            // wide round: the lift of all 2 np ciphertexts as one full-occupancy launch, then one digit-difference transform per
+            // workgroup (LD_SDIFF) -- no inverse transform is repeated, both kernels run 8 workgroups per CU
+            const uint64_t* low = src_pk;
+            InvParams ip{};
+            ip.src = src_pk;
+            ip.dst = S->raw.p;
+            ip.src_map = ip.dst_map = identity_map();
+            ip.pre_reduce = pre_reduce ? 1 : 0;
+            launch_ntt_inverse(S->tb, ip, IST_CRT, n_src, S->stream);
+            FwdParams fp{};
+            fp.src = S->raw.p;
+            fp.dst = S->fold_d.p;
+            fp.src_map = identity_map();
+            fp.n_digits = s.ell;
+            fp.bits = get_bits_per(s.ell);
+            fp.ell = s.ell;
+            fp.fold_np = np;
+            fp.lazy_out = lazy_ok(3 * s.ell + 1) ? 1 : 0;
+            launch_ntt_forward(S->tb, fp, LD_SDIFF, ST_PK, (n_src / 2) * s.ell, S->stream);
+            launch_fold_mac(key + (size_t)s.m2 * kN, S->fold_d.p, out_pk, s.m2, np, S->stream, 2 * s.m2, low);
+            src_pk = out_pk;
+            pre_reduce = false;
+            continue;
+        }
         if (src_pk && S->fold_chain && S->fold_pair && fold_pair_exact(s.ell)) {
             FoldPairParams pp{};
             pp.src = src_pk;
@@ -1066,7 +1097,14 @@ int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t ro
             pp.bits = get_bits_per(s.ell);
             pp.fold_np = np;
             pp.pre_reduce = pre_reduce ? 1 : 0;
-            pp.dpb = fold_dpb(S, n_src / 2);
+            pp.team = S->fold_team ? 1 : 0;
+            if (pp.team) {  // a block = two halves of dpb digits each; halve dpb until the round has about fold_blocks halves
+                uint32_t dpb = (s.ell + 1) / 2;
+                while (dpb > 1 && (n_src / 2) * 2 * ((s.ell + 2 * dpb - 1) / (2 * dpb)) < S->fold_blocks) dpb = (dpb + 1) / 2;
+                pp.dpb = dpb;
+            } else {
+                pp.dpb = fold_dpb(S, n_src / 2);
+            }
             pp.lazy_out = lazy_ok(3 * s.ell + 1) ? 1 : 0;  // fold_mac sums m2 = 3 ell products and the addend per accumulator
             launch_fold_pair(S->tb, pp, n_src / 2, S->stream);
             // out[i] = C[i] + Q * D'[i]: the Q half of the key rows [Q_neg | Q], the low ciphertexts as the addend
