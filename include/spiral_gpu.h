@@ -250,6 +250,18 @@ int spiral_gpu_server_run_unpack_convert_sweep(spiral_gpu_server *s, const void 
  * needs no GSW bit) while the all-gather is in flight, run_unpack_gsw (unpack + regevToGSW + fold keys) once it has landed */
 int spiral_gpu_server_run_scal2mat_sweep(spiral_gpu_server *s);
 int spiral_gpu_server_run_unpack_gsw(spiral_gpu_server *s, const void *gathered);
+/* Pipelined sweep for N > 1.  The output columns of multiplyQueryByDatabase are independent (src/spiral.cpp:628-999: the i and c
+ * loops enclose the j loop), so a rank can sweep them in K = 2^k stages of num_per/K ciphertexts and start the reduce-scatter of
+ * a stage's accumulators while the next stage streams the database.  set_sweep_stages(K) -- after set_fold_ranks -- lays the
+ * accumulator buffer out [stage][rank][ciphertext]: stage s is the contiguous 1/K of the buffer at offset s/K, and reduce-scattering
+ * it over the G ranks gives rank g rows [s L/K, (s+1) L/K) of the chunk fold_local expects (L = num_per/G), so K reduce-scatters
+ * of 1/K each replace the one.  first_dim_stage(s) launches stage s only; first_dim() all stages at once (same layout).
+ * K must leave whole 64-column blocks per stage (K <= num_per/32, max_sweep_stages) and needs the packed database layout.
+ * run_scal2mat: ScalToMat alone (run_scal2mat_sweep without the sweep), after which the stages are issued one by one. */
+int spiral_gpu_server_set_sweep_stages(spiral_gpu_server *s, uint32_t n_stages);
+uint32_t spiral_gpu_server_max_sweep_stages(spiral_gpu_server *s);
+int spiral_gpu_server_first_dim_stage(spiral_gpu_server *s, uint32_t stage);
+int spiral_gpu_server_run_scal2mat(spiral_gpu_server *s);
 /* make the sweep write into caller-owned device memory (e.g. a torch tensor) */
 int spiral_gpu_server_set_acc(spiral_gpu_server *s, void *device_ptr);
 

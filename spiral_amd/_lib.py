@@ -125,6 +125,10 @@ PROTOTYPES = {
     "spiral_gpu_server_run_unpack_convert_sweep": (C.c_int, [C.c_void_p, C.c_void_p]),
     "spiral_gpu_server_run_scal2mat_sweep": (C.c_int, [C.c_void_p]),
     "spiral_gpu_server_run_unpack_gsw": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "spiral_gpu_server_set_sweep_stages": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "spiral_gpu_server_max_sweep_stages": (C.c_uint32, [C.c_void_p]),
+    "spiral_gpu_server_first_dim_stage": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "spiral_gpu_server_run_scal2mat": (C.c_int, [C.c_void_p]),
     "spiral_gpu_server_acc": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "spiral_gpu_server_set_acc": (C.c_int, [C.c_void_p, C.c_void_p]),
     "spiral_gpu_server_answer": (C.c_int, [C.c_void_p, U64P, U64P, U64P, C.POINTER(C.c_double)]),

@@ -248,7 +248,12 @@ void launch_fold_key_from_reoriented(const uint64_t* q_re, const uint64_t* qneg_
 // device DB layout: common.h (packed 7-byte words for real geometries, plain for tiny ones), ic = ii*2 + c, nic = 2*num_per.
 // acc[ii][r][c][z] PK (fields < m).
 // g_log: log2 of the number of ranks of a distributed fold (accumulators grouped by ii mod 2^g_log), 0 = natural order
-void launch_sweep(const uint64_t* db, const uint32_t* qs, uint64_t* acc, uint32_t num_per, uint32_t jm_total, uint32_t g_log, hipStream_t s);
+// k_log: log2 of the number of STAGES of a pipelined sweep (0 = one): the accumulators are laid out [stage][rank][ct] so that every
+// stage's block can be reduce-scattered on its own (sweep.hip acc_pos); stage >= 0 launches only that stage's column blocks
+// (wide packed geometries, sweep_stages_ok), stage < 0 all of them
+void launch_sweep(const uint64_t* db, const uint32_t* qs, uint64_t* acc, uint32_t num_per, uint32_t jm_total, uint32_t g_log, hipStream_t s, uint32_t k_log = 0,
+                  int stage = -1);
+bool sweep_stages_ok(uint32_t num_per, uint32_t jm_total, uint32_t g_log, uint32_t k_log);
 // n = 2 .. kSweepMaxBatch queries against one pass over the database (records qs[b] -> accumulators acc[b]); only where
 // sweep_batch_ok (the packed layout with at least 64 output columns: every published geometry but the smallest streaming ones)
 constexpr uint32_t kSweepMaxBatch = 4;

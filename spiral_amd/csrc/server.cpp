@@ -35,7 +35,7 @@ struct spiral_gpu_server {
     // reduce_first; instantiated lazily, invalidated when a captured pointer or flag changes
     bool use_graphs = false;
     // [3] = Regev->GSW conversion on the side stream, [4] = whole query, [5] = fold_local, [6] = fold_root, [7] = run_pre + sweep
-    hipGraphExec_t graph[12] = {};  // [8] = sharded expansion + pack, [9] = unpack + convert + sweep, [10] = ScalToMat + sweep, [11] = unpack + Regev->GSW
+    hipGraphExec_t graph[13] = {};  // [12] = ScalToMat alone  // [8] = sharded expansion + pack, [9] = unpack + convert + sweep, [10] = ScalToMat + sweep, [11] = unpack + Regev->GSW
     const void *cap_chunk = nullptr, *cap_gathered = nullptr;
     void* cap_ct = nullptr;  // the caller's buffers captured into graphs 5 and 6
     // overlap mode: run_pre forks the Regev->GSW conversion (needed only by the folding) onto side_stream so that it
@@ -57,6 +57,7 @@ struct spiral_gpu_server {
     bool fold_team = true;  // SPIRAL_FOLD_TEAM=0: fold_pair_kernel (one 256-thread workgroup runs both inverse transforms)
     uint32_t fold_blocks = 768;
     uint32_t fold_g_log = 0;  // distributed fold over 2^fold_g_log ranks: the sweep groups its output by ii mod G
+    uint32_t sweep_k_log = 0; // pipelined sweep in 2^sweep_k_log stages (set_sweep_stages): accumulators laid out [stage][rank][ct]
     ExpandShard ex_shard{};   // sharded expansion (set_expand_shard): what this rank expands itself
     const void* cap_bits_out = nullptr;  // the caller's exchange buffers captured into graphs 8 and 9
     const void* cap_bits_in = nullptr;
@@ -983,7 +984,42 @@ int spiral_gpu_server_first_dim(spiral_gpu_server* S) {
     if (!S) return fail("null server");
     HIP_OK(hipSetDevice(S->device));
     if (!S->have_db) return fail("no database loaded");
-    launch_sweep(S->db.p, (const uint32_t*)S->qs.p, S->acc, S->s.num_per, 2 * S->dim0_shard, S->fold_g_log, S->stream);
+    launch_sweep(S->db.p, (const uint32_t*)S->qs.p, S->acc, S->s.num_per, 2 * S->dim0_shard, S->fold_g_log, S->stream, S->sweep_k_log);
+    return 0;
+}
+
+// Pipelined sweep (N > 1): the output columns are independent (src/spiral.cpp:628-999 loops over i and c outside j), so a rank may
+// sweep them in K stages of num_per / K ciphertexts and hand every stage's accumulators to its own reduce-scatter while the next
+// stage streams the database.  set_sweep_stages lays the accumulators out [stage][rank][ct] (every stage one contiguous block of
+// 1/K of the buffer; a rank's reduce-scattered rows still come out in the order fold_local expects); first_dim_stage launches one
+// stage; first_dim launches all of them at once into the same layout.
+int spiral_gpu_server_set_sweep_stages(spiral_gpu_server* S, uint32_t n_stages) {
+    if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
+    if (n_stages == 0 || (n_stages & (n_stages - 1))) return fail("sweep stages must be a power of two");
+    const uint32_t k_log = ceil_log2(n_stages);
+    if (!sweep_stages_ok(S->s.num_per, 2 * S->dim0_shard, S->fold_g_log, k_log))
+        return fail("%u sweep stages: needs the packed layout, whole 64-column blocks per stage (at most %u stages here) and a ciphertext per rank and stage", n_stages,
+                    S->s.num_per / 32);
+    S->sweep_k_log = k_log;
+    srv_drop_graphs(S);
+    return 0;
+}
+
+uint32_t spiral_gpu_server_max_sweep_stages(spiral_gpu_server* S) {
+    if (!S) return 0;
+    uint32_t k = 0;
+    while (k < 16 && sweep_stages_ok(S->s.num_per, 2 * S->dim0_shard, S->fold_g_log, k + 1)) k++;
+    return 1u << k;
+}
+
+int spiral_gpu_server_first_dim_stage(spiral_gpu_server* S, uint32_t stage) {
+    if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
+    if (!S->have_db) return fail("no database loaded");
+    if (stage >= (1u << S->sweep_k_log)) return fail("stage %u of %u", stage, 1u << S->sweep_k_log);
+    if (S->sweep_k_log == 0) return spiral_gpu_server_first_dim(S);
+    launch_sweep(S->db.p, (const uint32_t*)S->qs.p, S->acc, S->s.num_per, 2 * S->dim0_shard, S->fold_g_log, S->stream, S->sweep_k_log, (int)stage);
     return 0;
 }
 
@@ -1004,7 +1040,7 @@ int spiral_gpu_server_first_dim_batch(spiral_gpu_server* const* servers, uint32_
     uint64_t* acc[kSweepMaxBatch];
     for (uint32_t b = 0; b < n; b++) {
         spiral_gpu_server* S = servers[b];
-        if (S->db.p != S0->db.p || S->device != S0->device || S->dim0_shard != S0->dim0_shard || S->s.num_per != S0->s.num_per || S->fold_g_log != S0->fold_g_log)
+        if (S->db.p != S0->db.p || S->device != S0->device || S->dim0_shard != S0->dim0_shard || S->s.num_per != S0->s.num_per || S->fold_g_log != S0->fold_g_log || S->sweep_k_log != 0)
             return fail("first_dim_batch: server %u does not sweep the same database image with the same layout as server 0", b);
         for (uint32_t c = 0; c < b; c++)
             if (servers[c] == S) return fail("first_dim_batch: server %u listed twice", b);
@@ -1162,6 +1198,7 @@ int spiral_gpu_server_set_fold_ranks(spiral_gpu_server* S, uint32_t n_ranks) {
     HIP_OK(hipSetDevice(S->device));
     if (n_ranks == 0 || (n_ranks & (n_ranks - 1)) || n_ranks > S->s.num_per) return fail("fold ranks must be a power of two <= num_per");
     S->fold_g_log = ceil_log2(n_ranks);
+    S->sweep_k_log = 0;  // the stage layout depends on the rank count: set_sweep_stages comes after
     srv_drop_graphs(S);
     return 0;
 }
@@ -1404,6 +1441,13 @@ int spiral_gpu_server_run_scal2mat_sweep(spiral_gpu_server* S) {
     });
 }
 
+// ScalToMat alone (the pipelined schedule issues the sweep stage by stage after it)
+int spiral_gpu_server_run_scal2mat(spiral_gpu_server* S) {
+    if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
+    return run_group(S, 12, S->stream, [&]() { return convert_scal2mat(S, S->stream); });
+}
+
 int spiral_gpu_server_run_unpack_gsw(spiral_gpu_server* S, const void* gathered) {
     if (!S || !gathered) return fail("null argument");
     HIP_OK(hipSetDevice(S->device));
@@ -1594,7 +1638,7 @@ int spiral_gpu_server_time_sweep(spiral_gpu_server* S, int iters, float* avg_ms)
     if (!S->have_db) return fail("no database loaded");
     HIP_OK(hipSetDevice(S->device));
     HIP_OK(hipEventRecord(S->ev[0], S->stream));
-    for (int i = 0; i < iters; i++) launch_sweep(S->db.p, (const uint32_t*)S->qs.p, S->acc, S->s.num_per, 2 * S->dim0_shard, S->fold_g_log, S->stream);
+    for (int i = 0; i < iters; i++) launch_sweep(S->db.p, (const uint32_t*)S->qs.p, S->acc, S->s.num_per, 2 * S->dim0_shard, S->fold_g_log, S->stream, S->sweep_k_log);
     HIP_OK(hipEventRecord(S->ev[1], S->stream));
     HIP_OK(hipStreamSynchronize(S->stream));
     float ms = 0;

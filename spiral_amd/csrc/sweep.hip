@@ -49,9 +49,17 @@ __device__ __forceinline__ void reduce6(uint64_t (&a)[6]) {
 // acc[perm(ii)][r][c][z], ic = ii*2 + c  ->  polynomial index 6*perm(ii) + 2*r + c.  perm groups the ciphertexts by
 // ii mod G (G = 2^g_log ranks of a distributed fold: rank g then owns the contiguous chunk of cts ii = g + G*k, which
 // is what one reduce-scatter hands it); G = 1 is the identity.
-__device__ __forceinline__ void store_acc(uint64_t* acc, const uint64_t (&a)[6], uint32_t ic, uint32_t z, uint32_t num_per, uint32_t g_log) {
+// Position of ciphertext i0 = g + G k in the accumulator buffer: [stage s][rank g][k' < Ls] with k = s Ls + k', Ls = 2^ls_log.
+// One stage (ls_log = log2(num_per / G)) is the plain grouping by rank; with K = 2^k_log stages (ls_log smaller by k_log) the
+// ciphertexts of stage s -- the contiguous columns [s num_per/K, (s+1) num_per/K) -- form one contiguous [G][Ls] block, which one
+// reduce-scatter per stage turns into rank g's rows k of that stage (the sweep of stage s + 1 runs under it, server.cpp).
+__device__ __forceinline__ uint32_t acc_pos(uint32_t i0, uint32_t g_log, uint32_t ls_log) {
+    const uint32_t g = i0 & ((1u << g_log) - 1u), k = i0 >> g_log;
+    return ((((k >> ls_log) << g_log) | g) << ls_log) | (k & ((1u << ls_log) - 1u));
+}
+__device__ __forceinline__ void store_acc(uint64_t* acc, const uint64_t (&a)[6], uint32_t ic, uint32_t z, uint32_t g_log, uint32_t ls_log) {
     const uint32_t i0 = ic >> 1, c = ic & 1u;
-    const uint32_t ii = (i0 & ((1u << g_log) - 1u)) * (num_per >> g_log) + (i0 >> g_log);
+    const uint32_t ii = acc_pos(i0, g_log, ls_log);
 #pragma unroll
     for (uint32_t r = 0; r < 3; r++) acc[((size_t)(6u * ii + 2u * r + c)) * kN + z] = pack((uint32_t)a[r], (uint32_t)a[3 + r]);
 }
@@ -114,7 +122,8 @@ struct SweepBatch {
     uint64_t* acc[kSweepMaxBatch];
 };
 template <int MODE, int NB = 1>
-__global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __restrict__ db, SweepBatch bt, uint32_t nic, uint32_t dim0, uint32_t g_log) {
+__global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __restrict__ db, SweepBatch bt, uint32_t nic, uint32_t dim0, uint32_t g_log, uint32_t ls_log,
+                                                             uint32_t icb0, uint32_t n_icb) {
     static_assert(NB == 1 || MODE == 0, "batched sweeps use the wide geometry");
     const uint32_t* __restrict__ qs = bt.qs[0];
     uint64_t* __restrict__ acc = bt.acc[0];
@@ -129,7 +138,8 @@ __global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __r
     // touched them: 4 x 25 MB instead of 25 MB at config 2.)
     uint32_t work = blockIdx.x;
     if ((gridDim.x & 7u) == 0) work = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const uint32_t zg = work / nblk, icb = work - zg * nblk;  // WIDE: zg = group of kSweepZ slots; else one tile of pz slots
+    // (a launch may cover only the column blocks [icb0, icb0 + n_icb) of the wide geometry: one stage of a pipelined sweep)
+    const uint32_t zg = work / n_icb, icb = icb0 + (work - zg * n_icb);  // WIDE: zg = group of kSweepZ slots; else one tile of pz slots
     const uint32_t groups = dim0 >> 3;
     // WIDE: the workgroup's waves take kSweepZ consecutive tiles whole.  !WIDE: there are only N/pz tiles, each a long
     // stream, so the waves of a workgroup split ONE tile's j range between them (load concurrency is what buys bandwidth)
@@ -216,13 +226,12 @@ __global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __r
     // acc[perm(ii)][r][c][z], ic = ii*2 + c -> polynomial 6*perm(ii) + 2*r + c; perm groups the ciphertexts by ii mod G
     // (G = 2^g_log ranks of a distributed fold: rank g then owns the contiguous chunk ii = g + G*k, which is what one
     // reduce-scatter hands it); G = 1 is the identity.
-    const uint32_t num_per = nic >> 1;
     if constexpr (WIDE) {
 #pragma unroll
         for (uint32_t m = 0; m < 3; m++) {
             const uint32_t idx = threadIdx.x + kSweepZ * 64u * m, res = idx / kSweepZ, zz = idx - res * kSweepZ;
             const uint32_t col = res / 3u, r = res - col * 3u, ic = icb * 64u + col, i0 = ic >> 1, c = ic & 1u;
-            const uint32_t ii = (i0 & ((1u << g_log) - 1u)) * (num_per >> g_log) + (i0 >> g_log);
+            const uint32_t ii = acc_pos(i0, g_log, ls_log);
             acc[((size_t)(6u * ii + 2u * r + c)) * kN + zg * kSweepZ + zz] = sh[zz * kSweepRow + res];
         }
     } else if (threadIdx.x < 192u) {  // 64 lanes x 3 results of this tile, each the sum of the kSweepZ waves' partials (< 16 * 2^28)
@@ -234,7 +243,7 @@ __global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __r
             sp += lo32(x);
             sb += hi32(x);
         }
-        const uint32_t ii = (i0 & ((1u << g_log) - 1u)) * (num_per >> g_log) + (i0 >> g_log);
+        const uint32_t ii = acc_pos(i0, g_log, ls_log);
         acc[((size_t)(6u * ii + 2u * r + c)) * kN + zg * pz + zz] = pack(mod_p(sp), mod_b(sb));
     }
     }  // batch
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __r
 
 // plain-layout path (dim0 < 8, test sizes only): one thread per (z, ic)
 __global__ __launch_bounds__(256) void sweep_small_kernel(const uint64_t* __restrict__ db, const uint32_t* __restrict__ qs,
-                                                          uint64_t* __restrict__ acc, uint32_t nic, uint32_t dim0, uint32_t g_log) {
+                                                          uint64_t* __restrict__ acc, uint32_t nic, uint32_t dim0, uint32_t g_log, uint32_t ls_log) {
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     const uint32_t z = g / nic, ic = g - z * nic;
     if (z >= kN) return;
@@ -254,13 +263,18 @@ __global__ __launch_bounds__(256) void sweep_small_kernel(const uint64_t* __rest
         if ((j & 127u) == 127u) reduce6(a);
     }
     reduce6(a);
-    store_acc(acc, a, ic, z, nic >> 1, g_log);
+    store_acc(acc, a, ic, z, g_log, ls_log);
 }
 
+static uint32_t log2u(uint32_t x) {
+    uint32_t l = 0;
+    while ((1u << l) < x) l++;
+    return l;
+}
 bool sweep_batch_ok(uint32_t num_per, uint32_t jm_total) { return 2 * num_per >= 64 && db_packed(2 * num_per, jm_total / 2); }
 void launch_sweep_batch(const uint64_t* db, const uint32_t* const* qs, uint64_t* const* acc, uint32_t n, uint32_t num_per, uint32_t jm_total, uint32_t g_log,
                         hipStream_t s) {
-    const uint32_t nic = 2 * num_per, dim0 = jm_total / 2;
+    const uint32_t nic = 2 * num_per, dim0 = jm_total / 2, ls_log = log2u(num_per) - g_log;
     SweepBatch bt{};
     for (uint32_t b = 0; b < n; b++) {
         bt.qs[b] = qs[b];
@@ -268,32 +282,41 @@ void launch_sweep_batch(const uint64_t* db, const uint32_t* const* qs, uint64_t*
     }
     const dim3 grid((kN / kSweepZ) * (nic >> 6)), block(kSweepZ * 64);
     switch (n) {
-        case 2: hipLaunchKernelGGL((sweep_kernel<0, 2>), grid, block, 0, s, db, bt, nic, dim0, g_log); break;
-        case 3: hipLaunchKernelGGL((sweep_kernel<0, 3>), grid, block, 0, s, db, bt, nic, dim0, g_log); break;
-        case 4: hipLaunchKernelGGL((sweep_kernel<0, 4>), grid, block, 0, s, db, bt, nic, dim0, g_log); break;
+        case 2: hipLaunchKernelGGL((sweep_kernel<0, 2>), grid, block, 0, s, db, bt, nic, dim0, g_log, ls_log, 0u, nic >> 6); break;
+        case 3: hipLaunchKernelGGL((sweep_kernel<0, 3>), grid, block, 0, s, db, bt, nic, dim0, g_log, ls_log, 0u, nic >> 6); break;
+        case 4: hipLaunchKernelGGL((sweep_kernel<0, 4>), grid, block, 0, s, db, bt, nic, dim0, g_log, ls_log, 0u, nic >> 6); break;
         default: abort();
     }
 }
-void launch_sweep(const uint64_t* db, const uint32_t* qs, uint64_t* acc, uint32_t num_per, uint32_t jm_total, uint32_t g_log, hipStream_t s) {
+bool sweep_stages_ok(uint32_t num_per, uint32_t jm_total, uint32_t g_log, uint32_t k_log) {
+    if (k_log == 0) return true;
+    const uint32_t nic = 2 * num_per;  // whole 64-column blocks per stage, at least one ciphertext per rank and stage
+    return (num_per & (num_per - 1)) == 0 && db_packed(nic, jm_total / 2) && (nic >> 6) >= (1u << k_log) && log2u(num_per) >= g_log + k_log;
+}
+void launch_sweep(const uint64_t* db, const uint32_t* qs, uint64_t* acc, uint32_t num_per, uint32_t jm_total, uint32_t g_log, hipStream_t s, uint32_t k_log,
+                  int stage) {
     const uint32_t nic = 2 * num_per, dim0 = jm_total / 2;
     if (dim0 == 0) return;
+    const uint32_t ls_log = log2u(num_per) - g_log - k_log;
     SweepBatch bt{};
     bt.qs[0] = qs;
     bt.acc[0] = acc;
     if (db_packed(nic, dim0)) {
-        static const bool stage = [] {
+        static const bool stage_recs = [] {
             const char* e = getenv("SPIRAL_SWEEP_STAGE");  // tuning only: 0 = narrow geometries load their records per lane
             return e ? atoi(e) != 0 : true;
         }();
-        if (nic >= 64)
-            hipLaunchKernelGGL(sweep_kernel<0>, dim3((kN / kSweepZ) * (nic >> 6)), dim3(kSweepZ * 64), 0, s, db, bt, nic, dim0, g_log);
-        else if (nic >= 8 && stage)  // one workgroup per tile of 64/nic <= 8 slots, its waves split the j range; records staged in LDS
-            hipLaunchKernelGGL(sweep_kernel<2>, dim3(kN / (64 / nic)), dim3(kSweepZ * 64), 0, s, db, bt, nic, dim0, g_log);
+        if (nic >= 64) {
+            const uint32_t nblk = nic >> 6, per = nblk >> k_log;  // column blocks per stage
+            const uint32_t icb0 = stage < 0 ? 0u : (uint32_t)stage * per, n_icb = stage < 0 ? nblk : per;
+            hipLaunchKernelGGL(sweep_kernel<0>, dim3((kN / kSweepZ) * n_icb), dim3(kSweepZ * 64), 0, s, db, bt, nic, dim0, g_log, ls_log, icb0, n_icb);
+        } else if (nic >= 8 && stage_recs)  // one workgroup per tile of 64/nic <= 8 slots, its waves split the j range; records staged in LDS
+            hipLaunchKernelGGL(sweep_kernel<2>, dim3(kN / (64 / nic)), dim3(kSweepZ * 64), 0, s, db, bt, nic, dim0, g_log, ls_log, 0u, 1u);
         else
-            hipLaunchKernelGGL(sweep_kernel<1>, dim3(kN / (64 / nic)), dim3(kSweepZ * 64), 0, s, db, bt, nic, dim0, g_log);
+            hipLaunchKernelGGL(sweep_kernel<1>, dim3(kN / (64 / nic)), dim3(kSweepZ * 64), 0, s, db, bt, nic, dim0, g_log, ls_log, 0u, 1u);
     } else {
         const uint32_t threads = kN * nic;
-        hipLaunchKernelGGL(sweep_small_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, db, qs, acc, nic, dim0, g_log);
+        hipLaunchKernelGGL(sweep_small_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, db, qs, acc, nic, dim0, g_log, ls_log);
     }
 }
 

@@ -181,6 +181,20 @@ class Server:
         """ScalToMat + first_dim: the database-dependent part needs no GSW bit, so it can run under their all-gather"""
         check(lib().spiral_gpu_server_run_scal2mat_sweep(self.h))
 
+    def set_sweep_stages(self, n_stages: int):
+        """pipelined sweep: accumulators laid out [stage][rank][ct], so each stage's 1/n of the buffer can be reduce-scattered while the next sweeps"""
+        check(lib().spiral_gpu_server_set_sweep_stages(self.h, n_stages))
+
+    def max_sweep_stages(self) -> int:
+        return int(lib().spiral_gpu_server_max_sweep_stages(self.h))
+
+    def first_dim_stage(self, stage: int):
+        check(lib().spiral_gpu_server_first_dim_stage(self.h, stage))
+
+    def run_scal2mat(self):
+        """ScalToMat alone (the pipelined schedule issues the sweep stage by stage after it)"""
+        check(lib().spiral_gpu_server_run_scal2mat(self.h))
+
     def run_unpack_gsw(self, gathered_ptr: int):
         """unpack of the all-gathered GSW bits + Regev->GSW conversion (fold keys)"""
         check(lib().spiral_gpu_server_run_unpack_gsw(self.h, C.c_void_p(gathered_ptr)))

@@ -21,7 +21,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, root_fold, shard_expand, overlap, q):
+def _worker(rank, world, port, root_fold, shard_expand, overlap, q, nu=(4, 4), stages=0):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
@@ -37,7 +37,7 @@ def _worker(rank, world, port, root_fold, shard_expand, overlap, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
     kw = dict(t_gsw=4)
-    po, pg = O.make_params(4, 4, **kw), sa.make_params(4, 4, **kw)
+    po, pg = O.make_params(*nu, **kw), sa.make_params(*nu, **kw)
     s = O.shape_of(po)
     cl = O.Client(po, seed=77)  # same keys and queries on every rank
     wl, wr, w, v = cl.pub_params()
@@ -59,14 +59,32 @@ def _worker(rank, world, port, root_fold, shard_expand, overlap, q):
         srv.set_expand_shard(rank, world)
         bits = torch.zeros(srv.gsw_bits_words(), dtype=torch.int64, device=dev)
         bits_all = torch.zeros(world * bits.numel(), dtype=torch.int64, device=dev)
+    if stages:
+        assert stages <= srv.max_sweep_stages()
+        srv.set_sweep_stages(stages)  # accumulators laid out [stage][rank][ct]
     srv.use_graphs(True)
     ok = True
     db = O.gen_db(po, 5) if rank == 0 else None
+    total = 1 << sum(nu)
     with torch.cuda.stream(stream):
-        for idx in (9, 200, 255, 9):
+        for idx in (9, total - 56, total - 1, 9):
             qy = cl.query(idx)
             srv.set_query(qy)
-            if shard_expand and overlap:  # bench.py's overlapped order: the all-gather under ScalToMat + sweep
+            if shard_expand and overlap and stages:  # bench.py's pipelined order: stage k's reduce-scatter under stage k + 1's sweep
+                srv.run_expand_pack(bits.data_ptr())
+                w_bits = sdist.all_gather_gsw_bits(bits_all, bits, async_op=True)
+                srv.run_scal2mat()
+                al, cl_ = acc.numel() // stages, chunk.numel() // stages
+                works = []
+                for k in range(stages):
+                    srv.first_dim_stage(k)
+                    works.append(sdist.reduce_scatter_accumulators(chunk[k * cl_:(k + 1) * cl_], acc[k * al:(k + 1) * al], async_op=True))
+                w_bits.wait()
+                srv.run_unpack_gsw(bits_all.data_ptr())
+                for wk in works:
+                    if wk is not None:
+                        wk.wait()
+            elif shard_expand and overlap:  # bench.py's overlapped order: the all-gather under ScalToMat + sweep
                 srv.run_expand_pack(bits.data_ptr())
                 w_bits = sdist.all_gather_gsw_bits(bits_all, bits, async_op=True)
                 srv.run_scal2mat_sweep()
@@ -104,20 +122,38 @@ def _worker(rank, world, port, root_fold, shard_expand, overlap, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("root_fold,shard_expand,overlap", [(False, False, False), (True, False, False), (False, True, False), (True, True, False), (False, True, True)])
-def test_two_processes_one_gpu(root_fold, shard_expand, overlap):
+def _run_ranks(world, *args, **kw):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, root_fold, shard_expand, overlap, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port) + args + (q,), kwargs=kw) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(timeout=300)
+        p.join(timeout=600)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert q.get(timeout=5) is True
+
+
+@pytest.mark.parametrize("root_fold,shard_expand,overlap", [(False, False, False), (True, False, False), (False, True, False), (True, True, False), (False, True, True)])
+def test_two_processes_one_gpu(root_fold, shard_expand, overlap):
+    _run_ranks(2, root_fold, shard_expand, overlap)
+
+
+def test_two_processes_pipelined_sweep():
+    """the pipelined schedule with two real processes: num_per = 64 ciphertexts swept in 2 stages, each stage's half of the accumulator
+    buffer reduce-scattered on its own (async) while the next stage runs; answer == the oracle's"""
+    _run_ranks(2, False, True, True, nu=(5, 6), stages=2)
+
+
+@pytest.mark.parametrize("world,nu,stages", [(4, (4, 4), 0), (8, (4, 4), 0), (4, (5, 6), 2), (8, (6, 6), 2)])
+def test_four_and_eight_processes_one_gpu(world, nu, stages):
+    """the answer path with 4 and 8 REAL processes (every rank on cuda:0, gloo collectives): sharded expansion (each rank its own subtree
+    and every world-th GSW bit), j-shards of dim0 / world, reduce-scatter by ciphertext, local folds, all-gather, root folds -- the
+    comm-overlap order, and the pipelined order (sweep stages) -- bit-exact against the oracle on rank 0"""
+    _run_ranks(world, False, True, True, nu=nu, stages=stages)
 
 
 def test_bench_two_rank_flow_on_one_gpu():
@@ -151,11 +187,29 @@ def test_bench_self_launch_without_launcher():
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["value"] > 0
     assert out["rccl"]["world_size"] == 2 and [x["rank"] for x in out["rccl"]["ranks_seen"]] == [0, 1] and out["rccl"]["backend"] == "gloo"
-    assert set(out["schedules"]["ms_per_query"]) == {"in-order", "comm-overlap"} and out["schedules"]["chosen"] in out["schedules"]["ms_per_query"]
-    assert out["value"] == min(out["schedules"]["ms_per_query"].values())
+    assert set(out["schedules"]["ms_per_query"]) == {"in-order", "comm-overlap", "pipelined"} and out["schedules"]["chosen"] == "comm-overlap"
+    assert out["value"] == out["schedules"]["ms_per_query"]["comm-overlap"] and out["schedules"]["sweep_stages"] == 4
+    assert out["schedules"]["fastest"] in out["schedules"]["ms_per_query"]
     assert set(out["collectives_us"]) == {"all_gather_gsw_bits", "reduce_scatter_accumulators", "all_gather_folded_cts"}
     c3 = out["also"]["config3"]
     assert c3["n_gpus"] == 2 and c3["value"] > 0 and c3["roofline"]["achieved"] > 0 and "2^24" in c3["workload"]
+
+
+def test_bench_eight_ranks_on_one_gpu():
+    """`python bench.py --gpus 8` on the launcher-less path with eight ranks sharing the one device (gloo): the world the first 8-GPU run
+    will have -- eight ranks seen by the communicator, all three schedules timed, rank 0's line"""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--shared-device", "--nu1", "7", "--nu2", "6", "--no-config3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 8 and out["rccl"]["world_size"] == 8 and sorted(x["rank"] for x in out["rccl"]["ranks_seen"]) == list(range(8))
+    assert set(out["schedules"]["ms_per_query"]) == {"in-order", "comm-overlap", "pipelined"} and out["schedules"]["sweep_stages"] == 2
+    assert set(out["collectives_us"]) == {"all_gather_gsw_bits", "reduce_scatter_accumulators", "all_gather_folded_cts"}
+    assert "j-shard x8" in out["config"]["parallelism"] and out["value"] > 0
 
 
 @pytest.mark.parametrize("extra", [[], ["--root-fold"]])
@@ -188,6 +242,7 @@ def test_bench_pack_trial_shards():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["value"] > 0 and "trials x2 (8 per rank)" in out["config"]["parallelism"] and out["roofline"]["achieved"] > 0
+    assert out["rccl"]["world_size"] == 2 and [x["rank"] for x in out["rccl"]["ranks_seen"]] == [0, 1] and out["collectives_us"]["all_gather_folded_trials"] > 0
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "pack", "--gpus", "1", "--steps", "3", "--warmup", "1", "--force-dist", "--backend", "nccl"]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)

@@ -689,6 +689,74 @@ def test_distributed_fold_emulated_on_one_gpu(sa, oracle, G, graphs):
         srv.close()
 
 
+@pytest.mark.parametrize("G,K,nu2", [(1, 2, 6), (2, 2, 6), (8, 2, 6), (2, 4, 7), (4, 4, 7)])
+def test_pipelined_sweep_stages_emulated_on_one_gpu(sa, oracle, G, K, nu2):
+    """the pipelined sweep: G emulated ranks sweep their j-shards in K column-block stages (first_dim_stage) into accumulators laid out
+    [stage][rank][ct]; every stage's contiguous 1/K of the buffers is summed and scattered on its own (the per-stage reduce-scatter) into
+    rows [s L/K, (s+1) L/K) of each rank's chunk; local folds, gather, root fold == the oracle's answer.  Also: first_dim() with stages
+    set writes the same buffer as the K stage launches."""
+    import torch
+    from spiral_amd import server as SV
+
+    O = oracle
+    kw = dict(t_gsw=8)
+    po, pg = O.make_params(6, nu2, **kw), sa.make_params(6, nu2, **kw)  # shards of dim0 / G >= 8: the packed database layout
+    s = O.shape_of(po)
+    cl = O.Client(po, seed=41)
+    wl, wr, w, v = cl.pub_params()
+    db = O.gen_db(po, 78)
+    dev = torch.device("cuda", 0)
+    words = s.num_per * 6 * N
+    L = words // G
+    srvs, accs, chunks, cts = [], [], [], []
+    for g in range(G):
+        srv = sa.Server(pg, 0, g * s.dim0 // G, (g + 1) * s.dim0 // G)
+        srv.gen_db(78)
+        srv.set_pub_params(wl, wr, w, v)
+        srv.set_fold_ranks(G)
+        assert srv.max_sweep_stages() == s.num_per // 32
+        srv.set_sweep_stages(K)
+        accs.append(torch.zeros(words, dtype=torch.int64, device=dev))
+        chunks.append(torch.zeros(L, dtype=torch.int64, device=dev))
+        cts.append(torch.zeros(6 * N, dtype=torch.int64, device=dev))
+        srv.set_acc(accs[g].data_ptr())
+        srv.use_graphs(True)
+        srvs.append(srv)
+    gathered = torch.zeros(G * 6 * N, dtype=torch.int64, device=dev)
+    al, cl_ = words // K, L // K
+    for idx in (1000, 3):
+        q = cl.query(idx)
+        for g in range(G):
+            srvs[g].set_query(q)
+            srvs[g].run_pre()
+            for st in range(K):
+                srvs[g].first_dim_stage(st)
+            srvs[g].sync()
+        staged = [a.clone() for a in accs]
+        for g in range(G):  # all stages in one launch: the same buffer
+            accs[g].zero_()
+            srvs[g].first_dim()
+            srvs[g].sync()
+            assert torch.equal(accs[g], staged[g]), f"first_dim() vs {K} stage launches, rank {g}"
+        for st in range(K):  # the per-stage reduce-scatter
+            total = torch.stack([a[st * al:(st + 1) * al] for a in accs]).sum(0)
+            for g in range(G):
+                chunks[g][st * cl_:(st + 1) * cl_].copy_(total[g * cl_:(g + 1) * cl_])
+        torch.cuda.synchronize()
+        for g in range(G):
+            srvs[g].fold_local(chunks[g].data_ptr(), cts[g].data_ptr())
+            srvs[g].sync()
+        gathered.copy_(torch.cat(cts))
+        torch.cuda.synchronize()
+        srvs[0].fold_root(gathered.data_ptr())
+        srvs[0].sync()
+        assert_eq(srvs[0].read(SV.BUF_FINAL), O.answer(po, q, wl, wr, w, v, db), f"pipelined sweep G={G} K={K} idx={idx}")
+    with pytest.raises(Exception):
+        srvs[0].set_sweep_stages(s.num_per // 16)  # fewer than one 64-column block per stage
+    for srv in srvs:
+        srv.close()
+
+
 @pytest.mark.slow
 def test_full_size_stream_direct_upload(sa, oracle):
     """SpiralStream-style direct upload at the published "(20, 256)/spiralstream" parameters
