@@ -490,11 +490,7 @@ def bench_base(args, ctx, workload, steps, warmup, primary):
             srv.run_expand_pack(bits.data_ptr())
             w_bits = sdist.all_gather_gsw_bits(bits_all, bits, async_op=True)
             srv.run_scal2mat()
-            al, cl = acc.numel() // n_stages, chunk.numel() // n_stages
-            works = []
-            for k in range(n_stages):
-                srv.first_dim_stage(k)
-                works.append(sdist.reduce_scatter_accumulators(chunk[k * cl:(k + 1) * cl], acc[k * al:(k + 1) * al], async_op=True))
+            works = sdist.reduce_scatter_stages(chunk, acc, n_stages, async_op=True, after_stage=srv.first_dim_stage)
             w_bits.wait()
             srv.run_unpack_gsw(bits_all.data_ptr())
             for wk in works:

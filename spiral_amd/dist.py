@@ -47,6 +47,28 @@ def reduce_scatter_accumulators(chunk, acc, group=None, async_op=False):
     return work if async_op else chunk
 
 
+def acc_position(ii: int, n_ranks: int, num_per: int, n_stages: int = 1) -> int:
+    """where the sweep writes ciphertext ii = g + G k of the accumulator buffer (sweep.hip acc_pos): [stage s][rank g][k' < Ls] with
+    k = s Ls + k', Ls = num_per / (G K).  One stage = grouped by rank (set_fold_ranks); K stages = every stage a contiguous 1/K of the
+    buffer that is reduce-scattered on its own while the next stage sweeps (set_sweep_stages)."""
+    g, k = ii % n_ranks, ii // n_ranks
+    ls = num_per // (n_ranks * n_stages)
+    return ((k // ls) * n_ranks + g) * ls + k % ls
+
+
+def reduce_scatter_stages(chunk, acc, n_stages: int, group=None, async_op=False, after_stage=None):
+    """the pipelined form: stage s's contiguous 1/K of `acc` is reduce-scattered into rows [s L/K, (s+1) L/K) of `chunk`.
+    after_stage(s), when given, is called before stage s's collective is issued (the caller launches the sweep of stage s there);
+    async_op: returns the Work handles (None entries on gloo, where the collective is synchronous)."""
+    al, cl = acc.numel() // n_stages, chunk.numel() // n_stages
+    works = []
+    for s in range(n_stages):
+        if after_stage is not None:
+            after_stage(s)
+        works.append(reduce_scatter_accumulators(chunk[s * cl:(s + 1) * cl], acc[s * al:(s + 1) * al], group=group, async_op=async_op))
+    return works if async_op else chunk
+
+
 def all_gather_cts(gathered, ct, group=None):
     """collect the ranks' locally folded ciphertexts in rank order (96 KiB each)"""
     import torch.distributed as dist

@@ -66,7 +66,7 @@ def test_two_rank_shard_and_reduce_equals_unsharded():
     assert ok
 
 
-def _worker_sharded_fold(rank, world, port, q):
+def _worker_sharded_fold(rank, world, port, q, stages=1):
     """reduce-scatter + local fold + all-gather + root fold (bench.py's N > 1 path) with the oracle as the kernels"""
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -92,12 +92,18 @@ def _worker_sharded_fold(rank, world, port, q):
     dbv = db.reshape(O.N, s.num_per, 2, s.dim0, 2)[:, :, :, j0:j1, :]
     part = O.multiply_query_by_database(O.reorient_ciphertexts(cts[j0:j1]), np.ascontiguousarray(dbv).reshape(-1), j1 - j0, s.num_per)
     packed = (part[..., 0, :] | (part[..., 1, :] << np.uint64(32))).astype(np.uint64)  # [ii][3][2][N]
-    perm = np.array([(ii % G) * (s.num_per // G) + ii // G for ii in range(s.num_per)])  # Server.set_fold_ranks layout
+    perm = np.array([sdist.acc_position(ii, G, s.num_per, stages) for ii in range(s.num_per)])  # Server.set_fold_ranks / set_sweep_stages layout
+    assert sorted(perm) == list(range(s.num_per))
+    if stages == 1:
+        assert all(perm[ii] == (ii % G) * (s.num_per // G) + ii // G for ii in range(s.num_per))
     grouped = np.zeros_like(packed)
     grouped[perm] = packed
     acc = torch.from_numpy(grouped.view(np.int64).reshape(-1).copy())
     chunk = torch.zeros(acc.numel() // G, dtype=torch.int64)
-    sdist.reduce_scatter_accumulators(chunk, acc)
+    if stages == 1:
+        sdist.reduce_scatter_accumulators(chunk, acc)
+    else:  # one reduce-scatter per stage, each over a contiguous 1/stages of the buffer
+        sdist.reduce_scatter_stages(chunk, acc, stages)
     L = s.num_per // G
     tot = chunk.numpy().view(np.uint64).reshape(L, 3, 2, O.N)
     ntt = np.stack([(tot & np.uint64(0xFFFFFFFF)) % np.uint64(O.P), (tot >> np.uint64(32)) % np.uint64(O.B)], axis=-2)
@@ -128,13 +134,15 @@ def _worker_sharded_fold(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_distributed_fold_equals_single_device():
+@pytest.mark.parametrize("stages", [1, 2])
+def test_two_rank_distributed_fold_equals_single_device(stages):
+    """stages = 2: the pipelined layout -- the accumulators [stage][rank][ct], one reduce-scatter per stage"""
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_sharded_fold, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_sharded_fold, args=(r, 2, port, q, stages)) for r in range(2)]
     for p in procs:
         p.start()
     ok = q.get(timeout=300)
