@@ -120,8 +120,15 @@ def cpu_baseline(params_kw, np, workload):
                 best = cur
         return (got,) + best
 
+    # 1 thread: once with the scalar restatement of the transforms (reported beside), then -- `value` -- with the reference's USE_AVX2
+    # form of them (forward butterflies four at a time for t >= 4 + vector closing corrections, src/core.cpp:292-349, 479-506;
+    # tests/test_oracle.py proves the two equal), so that the baseline is the reference's algorithm AND its instruction mix
+    _, ms_scalar, _, _ = timed(1)
+    simd = O.set_ntt_simd(True)
     _, ms1, fd1, sw1 = timed(1)
     out = {"value": round(ms1, 1), "unit": "ms/query", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
+           "transform_isa": (O.ntt_isa() + " forward butterflies (t >= 4) and closing corrections, scalar inverse butterflies -- the reference's USE_AVX2 split") if simd else "scalar",
+           "value_scalar_transforms": round(ms_scalar, 1),
            "first_dim_ms": round(fd1, 1), "sweep_loop_ms": round(sw1, 1), "sweep_gbps": round(sweep_bytes / sw1 / 1e6, 2), "sweep_isa": O.sweep_isa(),
            "build": "gcc -O3 -march=native -fopenmp on this box" if native else "prebuilt gcc -O3 -march=x86-64-v3",
            "sample": f"1 full query of {workload} ({O.db_words(po) * 8 / 2**30:.0f} GiB NTT-form database of arbitrary valid words), oracle/ restatement; "

@@ -175,8 +175,10 @@ int spiral_gpu_server_read_db_columns(spiral_gpu_server *s, uint32_t ii_begin, u
 /* --random-data analogue: arbitrary valid NTT-form words, timing only */
 int spiral_gpu_server_fill_db_random(spiral_gpu_server *s, uint64_t seed);
 /* a second in-flight query on one database: `s` releases its own image and sweeps `owner`'s (same parameters, shard and device;
- * the owner outlives `s` and does not reload while `s` answers; loads through `s` fail).  One handle per query lane, each on
- * its own stream: the latency-bound expansion / folding of one query runs under the HBM-bound sweep of another. */
+ * the owner does not reload while `s` answers; loads through `s` fail).  One handle per query lane, each on
+ * its own stream: the latency-bound expansion / folding of one query runs under the HBM-bound sweep of another.
+ * Lifetime: the owner counts its lanes.  spiral_gpu_server_destroy(owner) while lanes exist frees everything of the owner except the
+ * image and invalidates the handle; the image itself is freed with the last lane, so a lane never sweeps freed memory. */
 int spiral_gpu_server_share_db(spiral_gpu_server *s, spiral_gpu_server *owner);
 /* the same in one step and without ever allocating a second image: a new server with `owner`'s parameters, device and shard
  * whose database IS the owner's (a query lane).  Works for images larger than half of HBM, where create + share_db cannot. */
@@ -199,7 +201,12 @@ int spiral_gpu_server_lift(spiral_gpu_server *s, int reduce_first); /* nttInvAnd
  * converted query against the image into server b's accumulators, each bit-identical to its own first_dim().  Asynchronous:
  * the launch runs on servers[0]'s stream and the other lanes' streams are ordered around it with events, so per lane the
  * sequence run_pre(lane) ... first_dim_batch(all) ... run_post(lane, 0) needs no host synchronisation.  Pays where the sweep is
- * most of a query (large databases); a single query's latency is first_dim(). */
+ * most of a query (large databases); a single query's latency is first_dim().
+ * Every server is checked (same image and layout, database present, query converted since its last set_query) before anything is
+ * launched: a failing call leaves no lane swept.  Geometries with fewer than 64 output columns (nu2 <= 4: 2 num_per < 64) or without the
+ * packed database layout have no batched kernel: the call then runs one first_dim() per server, in order -- same results, no shared pass.
+ * The lanes are ordered with hipEventRecord / hipStreamWaitEvent on their streams: call it OUTSIDE stream capture (none of the
+ * lanes' streams may be capturing a hipGraph; run_pre / run_post capture and replay their own groups either side of it). */
 int spiral_gpu_server_first_dim_batch(spiral_gpu_server *const *servers, uint32_t n);
 int spiral_gpu_server_fold(spiral_gpu_server *s);      /* foldOneFurtherDimension x nu2               */
 int spiral_gpu_server_finish(spiral_gpu_server *s);    /* response modulus switch, :1441-1447         */

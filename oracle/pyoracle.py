@@ -379,6 +379,34 @@ def pack_items(pts, coeff_bits):
     return np.packbits(bits, bitorder="little")
 
 
+def ntt_isa() -> str:
+    f = lib().orc_ntt_isa
+    f.restype = C.c_char_p
+    return f().decode()
+
+
+def set_ntt_simd(on: bool) -> bool:
+    """route the transforms through the reference's vector form (AVX2 forward butterflies + closing corrections); returns what is in force"""
+    lib().orc_set_ntt_simd.restype = C.c_int
+    return bool(lib().orc_set_ntt_simd(C.c_int(1 if on else 0)))
+
+
+def ntt_forward_scalar(x: np.ndarray) -> np.ndarray:
+    out = np.ascontiguousarray(x, dtype=np.uint64).copy()
+    flat = out.reshape(-1, NTTP)
+    for k in range(flat.shape[0]):
+        lib().orc_ntt_forward_scalar(flat[k].ctypes.data_as(_u64p))
+    return out
+
+
+def ntt_inverse_scalar(x: np.ndarray) -> np.ndarray:
+    out = np.ascontiguousarray(x, dtype=np.uint64).copy()
+    flat = out.reshape(-1, NTTP)
+    for k in range(flat.shape[0]):
+        lib().orc_ntt_inverse_scalar(flat[k].ctypes.data_as(_u64p))
+    return out
+
+
 def set_threads(n):
     """threads of the OpenMP (`make native`) build; the default build ignores it and returns 1"""
     lib().orc_set_threads.restype = C.c_int

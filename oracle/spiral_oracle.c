@@ -115,9 +115,95 @@ void orc_get_tables(uint64_t *out) {
 /* NTT core                                                                                         */
 /* ------------------------------------------------------------------------------------------------ */
 
+/* The reference's vector form of the same transforms (USE_AVX2, src/core.cpp:292-349 and :479-506): the forward butterflies four
+ * at a time wherever a group is at least four wide (t >= 4: three _mm256_mul_epu32 per four butterflies), the t < 4 stages scalar,
+ * and the closing [0,4m) -> [0,m) corrections of both transforms as vector compare / mask / subtract; the inverse butterflies are
+ * scalar in the reference too (:447-474).  orc_set_ntt_simd(1) routes orc_ntt_forward / orc_ntt_inverse through it so that the CPU
+ * baseline times the instruction mix the reference runs; the default stays the scalar restatement.  The comparisons here are
+ * ">= bound" (cmpgt against bound - 1) where the reference's vector code has "> bound" (:304, :336-343, which can leave m or 2m in
+ * place of 0): outputs are then word-for-word those of the scalar path, which tests/test_oracle.py checks. */
+static int g_ntt_simd = 0;
+#if defined(__AVX2__)
+#include <immintrin.h>
+#define ORC_NTT_ISA "avx2"
+static inline __m256i csub_epi64(__m256i x, __m256i bound, __m256i bound_m1) { /* x >= bound ? x - bound : x, values < 2^63 */
+    return _mm256_sub_epi64(x, _mm256_and_si256(_mm256_cmpgt_epi64(x, bound_m1), bound));
+}
+static void canonicalize_avx2(uint64_t *a, uint64_t m) {
+    const __m256i two_m = _mm256_set1_epi64x((long long)(2 * m)), two_m1 = _mm256_set1_epi64x((long long)(2 * m - 1));
+    const __m256i one_m = _mm256_set1_epi64x((long long)m), one_m1 = _mm256_set1_epi64x((long long)(m - 1));
+    for (uint32_t i = 0; i < N; i += 4) {
+        __m256i x = _mm256_loadu_si256((const __m256i *)(a + i));
+        x = csub_epi64(csub_epi64(x, two_m, two_m1), one_m, one_m1);
+        _mm256_storeu_si256((__m256i *)(a + i), x);
+    }
+}
+static void ntt_forward_avx2(uint64_t *op) {
+    for (int n = 0; n < 2; n++) {
+        const uint64_t *w = &g_tab[(4 + 2 * n) * N], *ws = &g_tab[(5 + 2 * n) * N];
+        uint64_t *a = op + n * N;
+        const uint32_t m = (uint32_t)MODS[n], two_m = 2 * m;
+        const __m256i vm = _mm256_set1_epi64x(m), v2m = _mm256_set1_epi64x(two_m), v2m1 = _mm256_set1_epi64x((long long)two_m - 1);
+        for (uint32_t grp = 1, t = N / 2; grp < N; grp <<= 1, t >>= 1) {
+            for (uint32_t i = 0; i < grp; i++) {
+                const uint64_t W = w[grp + i], Ws = ws[grp + i];
+                uint64_t *x = a + 2 * i * t, *y = x + t;
+                if (t >= 4) {
+                    const __m256i vw = _mm256_set1_epi64x((long long)W), vws = _mm256_set1_epi64x((long long)Ws);
+                    for (uint32_t j = 0; j < t; j += 4) {
+                        const __m256i xv = _mm256_loadu_si256((const __m256i *)(x + j)), yv = _mm256_loadu_si256((const __m256i *)(y + j));
+                        const __m256i cx = csub_epi64(xv, v2m, v2m1);
+                        const __m256i q = _mm256_srli_epi64(_mm256_mul_epu32(yv, vws), 32);
+                        const __m256i tt = _mm256_sub_epi64(_mm256_mul_epu32(yv, vw), _mm256_mul_epu32(q, vm)); /* in [0,2m) */
+                        _mm256_storeu_si256((__m256i *)(x + j), _mm256_add_epi64(cx, tt));
+                        _mm256_storeu_si256((__m256i *)(y + j), _mm256_add_epi64(cx, _mm256_sub_epi64(v2m, tt)));
+                    }
+                } else {
+                    for (uint32_t j = 0; j < t; j++) {
+                        uint32_t xv = (uint32_t)x[j], yv = (uint32_t)y[j];
+                        uint32_t cx = xv - (xv >= two_m ? two_m : 0);
+                        uint64_t q = ((uint64_t)yv * Ws) >> 32;
+                        uint64_t tt = W * yv - q * m;
+                        x[j] = cx + tt;
+                        y[j] = cx + (two_m - tt);
+                    }
+                }
+            }
+        }
+        canonicalize_avx2(a, m);
+    }
+}
+#else
+#define ORC_NTT_ISA "scalar"
+#endif
+const char *orc_ntt_isa(void) { return ORC_NTT_ISA; }
+int orc_set_ntt_simd(int on) {
+#if defined(__AVX2__)
+    g_ntt_simd = on != 0;
+#else
+    g_ntt_simd = 0;
+#endif
+    return g_ntt_simd;
+}
+
 /* src/core.cpp:254-351 (scalar branch :274-290): lazy Harvey butterflies, values in [0,4m) */
+static void ntt_forward_scalar(uint64_t *op);
+static void ntt_inverse_impl(uint64_t *op, int simd_tail);
 void orc_ntt_forward(uint64_t *op) {
     build_tables();
+#if defined(__AVX2__)
+    if (g_ntt_simd) {
+        ntt_forward_avx2(op);
+        return;
+    }
+#endif
+    ntt_forward_scalar(op);
+}
+void orc_ntt_forward_scalar(uint64_t *op) {
+    build_tables();
+    ntt_forward_scalar(op);
+}
+static void ntt_forward_scalar(uint64_t *op) {
     for (int n = 0; n < 2; n++) {
         const uint64_t *w = &g_tab[(4 + 2 * n) * N], *ws = &g_tab[(5 + 2 * n) * N];
         uint64_t *a = op + n * N;
@@ -148,6 +234,13 @@ void orc_ntt_forward(uint64_t *op) {
 /* src/core.cpp:426-513: Gentleman-Sande with the 1/2 folded into every stage */
 void orc_ntt_inverse(uint64_t *op) {
     build_tables();
+    ntt_inverse_impl(op, g_ntt_simd);
+}
+void orc_ntt_inverse_scalar(uint64_t *op) {
+    build_tables();
+    ntt_inverse_impl(op, 0);
+}
+static void ntt_inverse_impl(uint64_t *op, int simd_tail) {
     for (int n = 0; n < 2; n++) {
         const uint64_t *w = &g_tab[(0 + 2 * n) * N], *ws = &g_tab[(1 + 2 * n) * N];
         uint64_t *a = op + n * N;
@@ -167,6 +260,13 @@ void orc_ntt_inverse(uint64_t *op) {
                 }
             }
         }
+#if defined(__AVX2__)
+        if (simd_tail) { /* :479-506 */
+            canonicalize_avx2(a, m);
+            continue;
+        }
+#endif
+        (void)simd_tail;
         for (uint32_t i = 0; i < N; i++) {
             uint64_t x = a[i];
             if (x >= two_m) x -= two_m;

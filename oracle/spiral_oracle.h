@@ -152,6 +152,14 @@ void orc_multiply_query_by_database_slots(uint64_t *out, const uint64_t *reorien
 /* the scalar cell only, and which vector form this build's orc_multiply_query_by_database uses ("avx512" | "avx2" | "scalar") */
 void orc_multiply_query_by_database_scalar(uint64_t *out, const uint64_t *cts, const uint64_t *db, size_t dim0, size_t num_per);
 const char *orc_sweep_isa(void);
+/* the transforms in the reference's vector form (USE_AVX2: forward butterflies for t >= 4 and both closing corrections, core.cpp:292-349,
+ * 479-506; the inverse butterflies are scalar there too): orc_set_ntt_simd(1) routes orc_ntt_forward / orc_ntt_inverse -- and with them
+ * every stage built on them -- through it (returns what is in force: 0 on a build without AVX2); orc_ntt_isa() names the ISA compiled in;
+ * the *_scalar entries always run the scalar restatement (tests prove the two equal) */
+const char *orc_ntt_isa(void);
+int orc_set_ntt_simd(int on);
+void orc_ntt_forward_scalar(uint64_t *op);
+void orc_ntt_inverse_scalar(uint64_t *op);
 /* threads for the `native` (-fopenmp) build used by bench.py's all-cores CPU baseline; a no-op returning 1 otherwise */
 int orc_set_threads(int n);
 void orc_db_item(const orc_params *p, uint64_t seed, uint64_t item, uint64_t *pt /* raw [2][2][N] */);

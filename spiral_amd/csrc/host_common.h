@@ -51,6 +51,9 @@ inline uint32_t ceil_log2(uint64_t x) {
 inline int shape_of(const spiral_gpu_params* p, spiral_gpu_shape* s) {
     if (!p || !s) return fail("null argument");
     if (p->nu1 > 16 || p->nu2 > 16) return fail("nu1/nu2 out of range");
+    // 56 digits at most: the expansion's digit transforms are left lazy ([0, 2m), LD_EXPAND) and expand_mac_round_* sums up to
+    // t_exp + t_exp_right of them per u64 accumulator -- raising the cap needs lazy_ok to hold for the new sum
+    static_assert(spiral::lazy_ok(56) && spiral::lazy_ok(2 * 56), "the digit-count cap below keeps the lazy expansion digits inside the u64 accumulators");
     if (p->t_gsw < 2 || p->t_gsw > 28 || p->t_conv < 1 || p->t_conv > 56 || p->t_exp < 1 || p->t_exp > 56 || p->t_exp_right < 1 ||
         p->t_exp_right > 56)
         return fail("gadget dimension out of range");

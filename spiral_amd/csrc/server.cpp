@@ -20,8 +20,14 @@ struct spiral_gpu_server {
     hipStream_t own_stream = nullptr, stream = nullptr;
     DeviceTables tb;
     bool keep_cts = false, have_db = false, have_pp = false, have_query = false;
+    bool have_records = false;  // the sweep's query records of the current query have been enqueued (ScalToMat ran since set_query)
     DevBuf wire;  // bit-packed response (read_response_wire)
     bool db_shared = false;  // db.p is another server's image (share_db): never written, never freed here
+    // lifetime of a shared image: a lane points at its owner, the owner counts its lanes.  Destroying an owner that still has lanes
+    // frees everything but the image and leaves a husk (zombie) that the last lane to go deletes -- a lane never sweeps freed memory.
+    spiral_gpu_server* db_owner = nullptr;
+    uint32_t n_lanes = 0;
+    bool zombie = false;
     // expanded-ciphertext positions inside cv: first-dim j at j*pos_stride + pos_first, rest i at i*pos_stride + pos_rest
     uint32_t pos_stride = 1, pos_first = 0, pos_rest = 0, n_cv = 0;
 
@@ -65,6 +71,9 @@ struct spiral_gpu_server {
 
 namespace {
 
+void lane_attach(spiral_gpu_server* lane, spiral_gpu_server* owner);
+void lane_detach(spiral_gpu_server* lane);
+
 // digits per workgroup of a fold round with n_src source polynomials: as few workgroups as keep the chip busy (every
 // workgroup repeats the inverse transform once), halved from ell until the round has about fold_blocks of them
 uint32_t fold_dpb(const spiral_gpu_server* S, uint32_t n_src) {
@@ -82,6 +91,7 @@ int srv_alloc(spiral_gpu_server* S, const spiral_gpu_server* db_owner) {
         S->db.words = db_owner->db.words;
         S->db_shared = true;
         S->have_db = true;
+        lane_attach(S, const_cast<spiral_gpu_server*>(db_owner));
     } else if (S->db.alloc(db_device_words((uint32_t)nic, S->dim0_shard))) {
         return -1;
     }
@@ -126,8 +136,13 @@ void srv_drop_graphs(spiral_gpu_server* S) {
         }
 }
 
-void srv_free(spiral_gpu_server* S) {
+void srv_free(spiral_gpu_server* S, bool keep_db = false) {
     srv_drop_graphs(S);
+    DevBuf keep;
+    if (keep_db) {
+        keep = S->db;
+        S->db.p = nullptr;
+    }
     DevBuf* all[] = {&S->db, &S->w_left, &S->w_right, &S->w, &S->v, &S->query, &S->cv, &S->ex_raw, &S->ex_g, &S->cv_raw,
                      &S->cv_g, &S->gsw, &S->key, &S->cts_keep, &S->qs, &S->acc_own, &S->raw, &S->fold_d, &S->fold_c, &S->fold_c2,
                      &S->resp, &S->stage, &S->wire};
@@ -140,6 +155,25 @@ void srv_free(spiral_gpu_server* S) {
     if (S->ev_batch) (void)hipEventDestroy(S->ev_batch);
     if (S->side_stream) (void)hipStreamDestroy(S->side_stream);
     if (S->own_stream) (void)hipStreamDestroy(S->own_stream);
+    S->side_stream = S->own_stream = nullptr;
+    S->ev_fork = S->ev_join = S->ev_batch = nullptr;
+    for (auto& e : S->ev) e = nullptr;
+    if (keep_db) S->db = keep;
+}
+
+// lane <-> owner bookkeeping of a shared database image
+void lane_attach(spiral_gpu_server* lane, spiral_gpu_server* owner) {
+    lane->db_owner = owner;
+    owner->n_lanes++;
+}
+void lane_detach(spiral_gpu_server* lane) {
+    spiral_gpu_server* owner = lane->db_owner;
+    if (!owner) return;
+    lane->db_owner = nullptr;
+    if (--owner->n_lanes == 0 && owner->zombie) {  // the owner was destroyed first: its image goes with its last lane
+        owner->db.release();
+        delete owner;
+    }
 }
 
 // the fold needs the keys the forked conversion produces
@@ -641,6 +675,7 @@ static int srv_create(const spiral_gpu_params* p, int device, uint32_t j_begin, 
             return fail("hipEventCreate failed");
         }
     if (srv_alloc(S, db_owner)) {
+        lane_detach(S);
         srv_free(S);
         delete S;
         return -1;
@@ -655,15 +690,22 @@ int spiral_gpu_server_create(const spiral_gpu_params* p, int device, uint32_t j_
 
 int spiral_gpu_server_create_lane(spiral_gpu_server* owner, spiral_gpu_server** out) {
     if (!owner || !out) return fail("null argument");
-    if (owner->db_shared) return fail("the owner does not own its database image");
+    if (owner->db_shared || owner->zombie) return fail("the owner does not own its database image");
     if (!owner->have_db) return fail("the owner has no database loaded");
     return srv_create(&owner->p, owner->device, owner->j0, owner->j1, owner, out);
 }
 
 void spiral_gpu_server_destroy(spiral_gpu_server* S) {
-    if (!S) return;
+    if (!S || S->zombie) return;
     (void)hipSetDevice(S->device);
     (void)hipDeviceSynchronize();
+    if (S->n_lanes > 0) {  // lanes still sweep this server's image: keep the image (only), the last lane frees it
+        srv_free(S, true);
+        S->zombie = true;
+        S->have_pp = S->have_query = false;
+        return;
+    }
+    lane_detach(S);
     srv_free(S);
     delete S;
 }
@@ -822,7 +864,7 @@ int spiral_gpu_server_fill_db_random(spiral_gpu_server* S, uint64_t seed) {
 // under the HBM-bound sweep of the other.
 int spiral_gpu_server_share_db(spiral_gpu_server* S, spiral_gpu_server* owner) {
     if (!S || !owner || S == owner) return fail("share_db needs two different servers");
-    if (owner->db_shared) return fail("the owner does not own its database image");
+    if (owner->db_shared || owner->zombie) return fail("the owner does not own its database image");
     if (S->device != owner->device || S->j0 != owner->j0 || S->dim0_shard != owner->dim0_shard || S->p.nu1 != owner->p.nu1 || S->p.nu2 != owner->p.nu2 ||
         S->s.num_per != owner->s.num_per)
         return fail("share_db: the servers differ in device, shard or database geometry");
@@ -833,7 +875,12 @@ int spiral_gpu_server_share_db(spiral_gpu_server* S, spiral_gpu_server* owner) {
     HIP_OK(hipSetDevice(S->device));
     HIP_OK(hipStreamSynchronize(S->stream));
     srv_drop_graphs(S);  // captured sweeps hold the old image's address
+    if (S->n_lanes > 0) return fail("share_db: this server's own image is swept by %u lanes", S->n_lanes);
     if (!S->db_shared) S->db.release();
+    if (S->db_owner != owner) {
+        lane_detach(S);
+        lane_attach(S, owner);
+    }
     S->db.p = owner->db.p;
     S->db.words = owner->db.words;
     S->db_shared = true;
@@ -859,6 +906,7 @@ int spiral_gpu_server_set_query(spiral_gpu_server* S, const uint64_t* query) {
     HIP_OK(hipSetDevice(S->device));
     if (upload_ref_ntt(S, query, S->query.p, (size_t)S->s.n_query_cts * 2)) return -1;
     S->have_query = true;
+    S->have_records = false;
     return 0;
 }
 
@@ -891,6 +939,7 @@ int convert_part(spiral_gpu_server* S, uint32_t what, hipStream_t st, bool mark_
     const spiral_gpu_shape& s = S->s;
     const uint32_t ps = S->pos_stride, ngs = p.nu2 * s.ell;
     if (ngs == 0) what &= ~CONV_GSW;
+    if (what & CONV_S2M) S->have_records = true;  // (a replayed graph sets it in run_group)
     const uint32_t n1 = (what & CONV_S2M) ? S->dim0_shard : 0, n2 = (what & CONV_GSW) ? 2 * ngs : 0;
     const IndexMap map1{1, 2 * ps, 2 * (S->j0 * ps + S->pos_first)};  // row 0 of ct pos(j0 + a)
     const IndexMap map2{2, 2 * ps, 2 * S->pos_rest};                   // rows 0, 1 of the nu2*ell GSW-bit cts
@@ -1038,8 +1087,10 @@ int spiral_gpu_server_first_dim_batch(spiral_gpu_server* const* servers, uint32_
     if (!S0->have_db) return fail("no database loaded");
     const uint32_t* qs[kSweepMaxBatch];
     uint64_t* acc[kSweepMaxBatch];
-    for (uint32_t b = 0; b < n; b++) {
+    for (uint32_t b = 0; b < n; b++) {  // every lane is validated before anything is launched: a failure leaves no lane swept
         spiral_gpu_server* S = servers[b];
+        if (!S->have_db) return fail("first_dim_batch: server %u has no database", b);
+        if (!S->have_records) return fail("first_dim_batch: server %u has not converted its query (run_pre / convert first)", b);
         if (S->db.p != S0->db.p || S->device != S0->device || S->dim0_shard != S0->dim0_shard || S->s.num_per != S0->s.num_per || S->fold_g_log != S0->fold_g_log || S->sweep_k_log != 0)
             return fail("first_dim_batch: server %u does not sweep the same database image with the same layout as server 0", b);
         for (uint32_t c = 0; c < b; c++)
@@ -1300,6 +1351,7 @@ int run_group(spiral_gpu_server* S, int slot, hipStream_t st, F body) {
         if (e != hipSuccess) return fail("hipGraphInstantiate failed: %s", hipGetErrorString(e));
     }
     HIP_OK(hipGraphLaunch(S->graph[slot], st));
+    if (slot == 0 || slot == 4 || slot == 7 || slot == 9 || slot == 10 || slot == 12) S->have_records = true;  // the groups that hold ScalToMat
     return 0;
 }
 }  // namespace

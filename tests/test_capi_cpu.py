@@ -132,9 +132,10 @@ def test_bench_self_launch_command_and_cpu_quota(monkeypatch):
     assert e.value.code == 7
     cmd = seen["cmd"]
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
-    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-len(argv):] == argv and cmd[-len(argv) - 1].endswith("bench.py")
+    # the launcher's own rendezvous on a port it binds itself (no bind-close-reuse race), on the loopback address
+    assert "--standalone" in cmd and cmd[cmd.index("--local-addr") + 1] == "127.0.0.1" and cmd[-len(argv):] == argv and cmd[-len(argv) - 1].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     assert ("torch" in sys.modules) == torch_loaded_before  # the parent never touches torch / the GPU
     assert 1 <= bench.cpu_quota_cores() <= (os.cpu_count() or 1)
     a = bench.parse_args(["--comm-overlap"])
-    assert a.schedule == "comm-overlap" and bench.parse_args([]).schedule == "both"
+    assert a.schedule == "comm-overlap" and bench.parse_args([]).schedule == "all" and bench.parse_args([]).sweep_stages == 4

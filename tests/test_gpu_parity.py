@@ -600,9 +600,28 @@ def test_batched_sweep_equals_single_sweeps(sa, oracle, nu1, nu2, n):
     with pytest.raises(RuntimeError):
         sa.first_dim_batch([lanes[0], other])
     other.close()
+    # every lane is validated before anything is launched: a lane whose new query has not been converted fails the call and no
+    # lane is swept (the accumulators stay what the last round left)
+    before = [srv.read(SV.BUF_ACC).copy() for srv in lanes]
+    lanes[-1].set_query(clients[-1].query(1))
+    for srv in lanes[:-1]:
+        srv.run_pre()
+    with pytest.raises(RuntimeError, match="has not converted"):
+        sa.first_dim_batch(lanes)
+    for srv, acc0 in zip(lanes, before):
+        srv.sync()
+        assert_eq(srv.read(SV.BUF_ACC), acc0, "accumulators untouched by the refused batch")
+    # lifetime: closing the owner first keeps the image alive for its lanes (freed with the last of them)
+    owner.close()
+    if n > 1:
+        lane, cl, pp = lanes[1], clients[1], pps[1]
+        q = cl.query(3)
+        lane.set_query(q)
+        lane.run_query()
+        lane.sync()
+        assert_eq(lane.read(SV.BUF_FINAL), O.answer(po, q, pp[0], pp[1], pp[2], pp[3], db), "a lane answers after its owner was closed")
     for srv in lanes[1:]:
         srv.close()
-    owner.close()
 
 
 def test_sharded_first_dim_sums_to_unsharded(sa, oracle):

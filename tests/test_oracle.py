@@ -207,6 +207,40 @@ def test_vectorised_sweep_cell_equals_scalar(oracle, oracle_mt, dim0):
     assert oracle.sweep_isa() in ("avx2", "avx512", "scalar") and oracle_mt.sweep_isa() in ("avx2", "avx512", "scalar")
 
 
+def test_vectorised_transforms_equal_scalar(oracle, oracle_mt):
+    """the transforms in the reference's USE_AVX2 form (forward butterflies four at a time for t >= 4, scalar below; both closing
+    corrections as vector compares, src/core.cpp:292-349, 479-506) against the scalar restatement: random residues, lazy inputs up to
+    4m - 1 (ntt_forward accepts them), the extreme patterns 0 / m - 1 / 2m / 2m - 1 / 4m - 1 in every slot, for both builds; and a
+    whole answer computed with the vector transforms switched on is word for word the scalar one"""
+    rng = np.random.default_rng(77)
+    for O in (oracle, oracle_mt):
+        if O.ntt_isa() != "avx2":
+            pytest.skip("oracle built without AVX2")
+        mods = (O.P, O.B)
+        cases = [np.stack([rng.integers(0, m, size=(4, O.N), dtype=np.uint64) for m in mods], axis=1),
+                 np.stack([rng.integers(0, 4 * m, size=(4, O.N), dtype=np.uint64) for m in mods], axis=1)]
+        for f in (lambda m: 0, lambda m: m - 1, lambda m: 2 * m, lambda m: 2 * m - 1, lambda m: 4 * m - 1, lambda m: m):
+            cases.append(np.stack([np.full((1, O.N), f(m), dtype=np.uint64) for m in mods], axis=1))
+        try:
+            for x in cases:
+                want_f = O.ntt_forward_scalar(x)
+                canon = np.stack([x[:, i] % np.uint64(m) for i, m in enumerate(mods)], axis=1)  # the inverse takes values below 2m
+                want_i = O.ntt_inverse_scalar(canon)
+                assert O.set_ntt_simd(True) is True
+                assert (O.ntt_forward(x) == want_f).all() and (O.ntt_inverse(canon) == want_i).all()
+                assert O.set_ntt_simd(False) is False
+                assert (O.ntt_forward(x) == want_f).all()
+            po = O.make_params(3, 3, t_gsw=4)
+            cl = O.Client(po, seed=8)
+            wl, wr, w, v = cl.pub_params()
+            db, q = O.gen_db(po, 2), cl.query(37)
+            want = O.answer(po, q, wl, wr, w, v, db)
+            O.set_ntt_simd(True)
+            assert (O.answer(po, q, wl, wr, w, v, db) == want).all()
+        finally:
+            O.set_ntt_simd(False)
+
+
 def test_threaded_native_build_gives_identical_results(oracle, oracle_mt):
     """the -fopenmp -march=native build on many threads (full-size parity tests, bench.py's all-cores baseline) must be
     the same function as the default single-threaded build: base path with expansion + stopround, and the pack path"""
