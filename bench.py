@@ -639,6 +639,9 @@ def bench_base(args, ctx, workload, steps, warmup, primary):
         pairs = ([("all_gather_gsw_bits", 4, 5)] if shard_expand else []) + ([("reduce_scatter_accumulators", 6, 7), ("all_gather_folded_cts", 8, 9)] if sharded_fold else [("reduce_accumulators", 6, 7)])
         coll = {n: round(sum(ev[k][a].elapsed_time(ev[k][b]) for k in sampled) / len(sampled) * 1e3, 1) for n, a, b in pairs}
     sweep_ms = stages["sweep"] / 1e3
+    # the same kernel timed over 24 back-to-back launches on the server stream, outside the timed region (spiral_gpu_server_time_sweep): the
+    # in-loop figure averages only the sampled steps (steps / event_every launches) and moves +-4 % with them; both are printed
+    sweep_ms_24 = srv.time_sweep(24) if world == 1 else None
     bytes_sweep = srv.sweep_bytes()
     achieved = bytes_sweep / (sweep_ms * 1e-3) / 1e9
     traffic, traffic_src = pmc_traffic(world, nu1, nu2)
@@ -672,7 +675,11 @@ def bench_base(args, ctx, workload, steps, warmup, primary):
                              "the device keeps a word's two 28-bit residues in 7 bytes, so a launch physically moves device_bytes_per_launch: achieved_device_bytes / "
                              "frac_device_bytes are the HBM utilisation in physical bytes.  `traffic` is NOT measured in this run: it is the rocprofv3 PMC figure "
                              "(FETCH_SIZE / WRITE_SIZE passes) read from the committed file named in traffic_source, valid for configs[1] on one GPU only (null otherwise)",
-                     "launches_timed": len(sampled), "shard": f"j in [{j0},{j1}) on rank 0"},
+                     "launches_timed": len(sampled), "shard": f"j in [{j0},{j1}) on rank 0",
+                     "standalone_24_launches": ({"avg_launch_ms": round(sweep_ms_24, 4), "achieved": round(bytes_sweep / (sweep_ms_24 * 1e-3) / 1e9, 1),
+                                                 "frac": round(bytes_sweep / (sweep_ms_24 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                                 "note": "24 back-to-back launches of the same kernel on the same inputs after the timed region (HIP events on the launch stream)"}
+                                                if sweep_ms_24 else None)},
     }
     if use_dist:
         out["schedules"] = {"ms_per_query": {k: round(v, 4) for k, v in timed.items()}, "chosen": best, "fastest": fastest, "sweep_stages": n_stages if "pipelined" in timed else None,

@@ -20,6 +20,7 @@ struct spiral_gpu_server {
     hipStream_t own_stream = nullptr, stream = nullptr;
     DeviceTables tb;
     bool keep_cts = false, have_db = false, have_pp = false, have_query = false;
+    bool raw_from_acc = false;  // S->raw holds the lift of what S->acc holds now (lift ran, no sweep / write_raw / fold since): the stage fold may use the pair form
     bool have_records = false;  // the sweep's query records of the current query have been enqueued (ScalToMat ran since set_query)
     DevBuf wire;  // bit-packed response (read_response_wire)
     bool db_shared = false;  // db.p is another server's image (share_db): never written, never freed here
@@ -1034,6 +1035,7 @@ int spiral_gpu_server_first_dim(spiral_gpu_server* S) {
     HIP_OK(hipSetDevice(S->device));
     if (!S->have_db) return fail("no database loaded");
     launch_sweep(S->db.p, (const uint32_t*)S->qs.p, S->acc, S->s.num_per, 2 * S->dim0_shard, S->fold_g_log, S->stream, S->sweep_k_log);
+    S->raw_from_acc = false;
     return 0;
 }
 
@@ -1069,6 +1071,7 @@ int spiral_gpu_server_first_dim_stage(spiral_gpu_server* S, uint32_t stage) {
     if (stage >= (1u << S->sweep_k_log)) return fail("stage %u of %u", stage, 1u << S->sweep_k_log);
     if (S->sweep_k_log == 0) return spiral_gpu_server_first_dim(S);
     launch_sweep(S->db.p, (const uint32_t*)S->qs.p, S->acc, S->s.num_per, 2 * S->dim0_shard, S->fold_g_log, S->stream, S->sweep_k_log, (int)stage);
+    S->raw_from_acc = false;
     return 0;
 }
 
@@ -1108,6 +1111,7 @@ int spiral_gpu_server_first_dim_batch(spiral_gpu_server* const* servers, uint32_
         HIP_OK(hipStreamWaitEvent(S0->stream, servers[b]->ev_batch, 0));
     }
     launch_sweep_batch(S0->db.p, qs, acc, n, S0->s.num_per, 2 * S0->dim0_shard, S0->fold_g_log, S0->stream);
+    for (uint32_t b = 0; b < n; b++) servers[b]->raw_from_acc = false;
     HIP_OK(hipEventRecord(S0->ev_batch, S0->stream));
     for (uint32_t b = 1; b < n; b++) HIP_OK(hipStreamWaitEvent(servers[b]->stream, S0->ev_batch, 0));
     return 0;
@@ -1122,6 +1126,7 @@ int spiral_gpu_server_lift(spiral_gpu_server* S, int reduce_first) {
     ip.src_map = ip.dst_map = identity_map();
     ip.pre_reduce = reduce_first ? 1 : 0;
     launch_ntt_inverse(S->tb, ip, IST_CRT, S->s.num_per * 6, S->stream);
+    S->raw_from_acc = true;
     return 0;
 }
 
@@ -1133,8 +1138,12 @@ namespace {
 // are the PK polynomials [np0][3][2] at src_pk (accumulators, lazy sums when pre_reduce) and the lift is chained into
 // the digit transforms (fold_chain_kernel); later rounds chain from the previous round's product the same way.
 // finish: the folded ciphertext is the answer; follow with the response modulus switch (spiral_gpu_server_finish).
-int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t rounds, const uint64_t* src_pk, bool pre_reduce, bool finish = false) {
+// raw_addend: with src_pk == nullptr, the transform-domain words of the ciphertexts lifted in S->raw, when the caller still has them
+// (the stage API's fold after lift: the accumulators) -- the first round can then take the pair form too (LD_SDIFF on S->raw).
+int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t rounds, const uint64_t* src_pk, bool pre_reduce, bool finish = false,
+                    const uint64_t* raw_addend = nullptr) {
     const spiral_gpu_shape& s = S->s;
+    S->raw_from_acc = false;  // S->raw ends up holding the folded ciphertext
     uint32_t np = np0;
     auto lift = [&](uint32_t npolys) {
         InvParams ip{};
@@ -1151,16 +1160,20 @@ int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t ro
         const uint32_t n_src = 2 * np * 6;
         const uint64_t* key = S->key.p + (size_t)d * 3 * 2 * s.m2 * kN;
         if (src_pk == out_pk) out_pk = out_pk == S->fold_c.p ? S->fold_c2.p : S->fold_c.p;  // the pair form's product reads its source
-        if (src_pk && S->fold_chain && S->fold_pair && fold_pair_exact(s.ell) && n_src / 2 >= S->fold_unchain_min) {
+        const bool from_raw = !src_pk && raw_addend && S->fold_pair && fold_pair_exact(s.ell);  // lifted already, transform-domain words at hand
+        if (from_raw || (src_pk && S->fold_chain && S->fold_pair && fold_pair_exact(s.ell) && n_src / 2 >= S->fold_unchain_min)) {
             // wide round: the lift of all 2 np ciphertexts as one full-occupancy launch, then one digit-difference transform per
             // workgroup (LD_SDIFF) -- no inverse transform is repeated, both kernels run 8 workgroups per CU
-            const uint64_t* low = src_pk;
-            InvParams ip{};
-            ip.src = src_pk;
-            ip.dst = S->raw.p;
-            ip.src_map = ip.dst_map = identity_map();
-            ip.pre_reduce = pre_reduce ? 1 : 0;
-            launch_ntt_inverse(S->tb, ip, IST_CRT, n_src, S->stream);
+            const uint64_t* low = from_raw ? raw_addend : src_pk;
+            if (!from_raw) {
+                InvParams ip{};
+                ip.src = src_pk;
+                ip.dst = S->raw.p;
+                ip.src_map = ip.dst_map = identity_map();
+                ip.pre_reduce = pre_reduce ? 1 : 0;
+                launch_ntt_inverse(S->tb, ip, IST_CRT, n_src, S->stream);
+            }
+            raw_addend = nullptr;
             FwdParams fp{};
             fp.src = S->raw.p;
             fp.dst = S->fold_d.p;
@@ -1241,7 +1254,7 @@ int spiral_gpu_server_fold(spiral_gpu_server* S) {
     if (!S) return fail("null server");
     HIP_OK(hipSetDevice(S->device));
     if (srv_join_side(S)) return -1;  // no-op inside run_post's capture: run_post joined before capturing
-    return run_fold_rounds(S, S->s.num_per, 0, S->p.nu2, nullptr, false);  // src/spiral.cpp:1622-1626
+    return run_fold_rounds(S, S->s.num_per, 0, S->p.nu2, nullptr, false, false, S->raw_from_acc ? S->acc : nullptr);  // src/spiral.cpp:1622-1626
 }
 
 int spiral_gpu_server_set_fold_ranks(spiral_gpu_server* S, uint32_t n_ranks) {
@@ -1320,6 +1333,7 @@ void* spiral_gpu_server_acc(spiral_gpu_server* S, size_t* bytes) {
 int spiral_gpu_server_set_acc(spiral_gpu_server* S, void* device_ptr) {
     if (!S) return fail("null server");
     S->acc = device_ptr ? (uint64_t*)device_ptr : S->acc_own.p;
+    S->raw_from_acc = false;
     srv_drop_graphs(S);  // the accumulator pointer is baked into the captured lift
     return 0;
 }
@@ -1681,6 +1695,7 @@ int spiral_gpu_server_write_raw(spiral_gpu_server* S, const uint64_t* raw_cts) {
     if (!S || !raw_cts) return fail("null argument");
     HIP_OK(hipSetDevice(S->device));
     HIP_OK(hipMemcpy(S->raw.p, raw_cts, (size_t)S->s.num_per * 6 * kPolyBytes, hipMemcpyHostToDevice));
+    S->raw_from_acc = false;
     return 0;
 }
 

@@ -141,7 +141,7 @@ def test_config2_every_stage_bit_exact(sa, oracle_mt, request):
     srv.close()
 
 
-def sampled_checks(sa, M, po, pg, seed, idx, cl, label, request, n_slots=6, n_items=12):
+def sampled_checks(sa, M, po, pg, seed, idx, cl, label, request, n_slots=6, n_items=12, batches=()):
     """the size-independent checks for a database too large for a host-side reference: see the module docstring"""
     from spiral_amd import server as SV
 
@@ -181,6 +181,41 @@ def sampled_checks(sa, M, po, pg, seed, idx, cl, label, request, n_slots=6, n_it
         want_ii = M.multiply_query_by_database(re, sub, s.dim0, 1)
         assert_eq(got_acc[ii:ii + 1], want_ii, f"{label}: all 2048 slots of output ciphertext {ii}")
     record(request, f"{label}: sweep slot-complete on output ciphertexts {cols} (all 2048 slots x 6 polynomials each), on slots {zs} for all {s.num_per} ciphertexts; sha256 of those columns {sha(got_acc[cols])}")
+    # the batched sweep (sweep_kernel<0, B>: B queries per pass over the database) at this geometry: every lane's accumulators against
+    # the same sampled slots and slot-complete columns, each lane with its own query
+    if batches:
+        import torch
+
+        nb = max(batches)
+        lanes, res = [srv], [re]
+        for b in range(1, nb):
+            lane = sa.Server(pg, share_db_of=srv)
+            lane.set_pub_params(wl, wr, w, v)
+            qb = cl.query((idx * (b + 1) + 12345 * b) % total)
+            lane.set_query(qb)
+            lanes.append(lane)
+            res.append(M.reorient_ciphertexts(M.stage_convert(po, M.stage_expand(po, qb, wl, wr), w, v)[0]))
+        streams = [torch.cuda.Stream() for _ in lanes]
+        for ln, st in zip(lanes, streams):
+            ln.set_stream(st.cuda_stream)
+        srv.set_query(q)
+        subs = {ii: srv.read_db_columns(ii, 1) for ii in cols}
+        for B in batches:
+            for ln in lanes[:B]:
+                ln.run_pre()
+            sa.first_dim_batch(lanes[:B])
+            for b, ln in enumerate(lanes[:B]):
+                ln.sync()
+                acc_b = ln.read(SV.BUF_ACC)
+                assert_eq(acc_b[..., zs], M.multiply_query_by_database_slots(res[b][zs], slabs, s.dim0, s.num_per), f"{label}: batch of {B}, lane {b}: accumulators on slots {zs}")
+                for ii in cols:
+                    assert_eq(acc_b[ii:ii + 1], M.multiply_query_by_database(res[b], subs[ii], s.dim0, 1), f"{label}: batch of {B}, lane {b}: all slots of output ciphertext {ii}")
+                if b == 0:
+                    assert_eq(acc_b, got_acc, f"{label}: batch of {B}, lane 0 == its single sweep")
+        record(request, f"{label}: batched sweeps B = {list(batches)}: every lane's accumulators bit-exact on slots {zs} (all ciphertexts) and slot-complete on ciphertexts {cols}")
+        for ln in lanes[1:]:
+            ln.close()
+        srv.set_stream(0)
     # and everything after the sweep from the device's full accumulators
     raw = M.from_ntt(got_acc)
     want_fin = M.stage_fold(po, raw, gsw)
@@ -196,7 +231,7 @@ def test_config3_geometry_sampled_slots(sa, oracle_mt, request):
     M = oracle_mt
     kw = dict(t_gsw=10, t_conv=4, t_exp=8, t_exp_right=56, qprime_bits=22, p_db=256)
     po, pg = M.make_params(9, 10, **kw), sa.make_params(9, 10, **kw)
-    sampled_checks(sa, M, po, pg, 99, 424242 % (1 << 19), M.Client(po, seed=6), "config 3 geometry (32 GiB)", request)
+    sampled_checks(sa, M, po, pg, 99, 424242 % (1 << 19), M.Client(po, seed=6), "config 3 geometry (32 GiB)", request, batches=(2, 4))
 
 
 def test_configs3_spiralstream_2_20_x_100KB(sa, oracle_mt, request):
@@ -234,24 +269,29 @@ def test_config5_pack_bit_exact(sa, oracle_mt, request):
     cv[0] = q.reshape(2, 2, N)
     cv = M.expand_improved(cv, s.g, po.t_exp, wl, po.t_exp_right, wr, s.n_right, s.ell * po.nu2, s.stopround)
     re = M.reorient_dim1(cv, s.dim0, 2)
-    # a fixed subset of the trials, whatever the box's memory: each trial's FULL sweep output (all slots, all ciphertexts)
-    # against the oracle's sweep of that trial's 4 GiB database, one database on the host at a time
+    # ALL trials, one 4 GiB database on the host at a time (no 64 GiB host image, whatever the box's memory): each trial's FULL sweep
+    # output (all slots, all ciphertexts) against the oracle's sweep of that trial's database, then the oracle's own lift + fold of the
+    # trial (foldCiphertextsDim1, src/testing.cpp:596-624); the 16 folded ciphertexts packed and switched by the oracle (pack :198-241,
+    # :1074-1081) must give the device's packed ciphertext and response
+    gsw = M.regev_to_simple_gsw(cv, v, po.t_conv, s.ell, po.nu2)
+    neg = M.pack_fold_neg(gsw, s.ell, po.nu2)
+    v_ct = np.zeros((s.trials, 2, N), dtype=np.uint64)
     shas = []
-    for t in (0, 7, 15):
+    for t in range(s.trials):
         db_t = M.pack_gen_db_trial(po, out_n, seed, t)
         got_t = srv.read_acc(t)
-        assert_eq(got_t, M.sweep_dim1(db_t, re, s.dim0, s.num_per), f"config 5, trial {t}: first-dimension accumulators")
-        shas.append(f"{t}:{sha(got_t)}")
+        want_t = M.sweep_dim1(db_t, re, s.dim0, s.num_per)
         del db_t
-    record(request, f"config 5: first-dimension accumulators of trials 0, 7, 15 bit-exact in full (sha256 {' '.join(shas)})")
-    if host_gib_available() > 160:  # all 16 trials at once (64 GiB of reference-layout database on the host): packed ciphertext + response
-        db = np.empty((s.trials, s.dim0 * s.num_per * N), dtype=np.uint64)
-        for t in range(s.trials):
-            db[t] = M.pack_gen_db_trial(po, out_n, seed, t)
-        want_resp, want_packed = M.pack_answer(po, out_n, q, wl, wr, v, vw, db)
-        assert_eq(packed, want_packed, "config 5: packed ciphertext")
-        assert_eq(resp, want_resp, "config 5: response")
-        record(request, f"config 5: all-trials: yes -- packed ciphertext and response bit-exact over all {s.trials} trials; sha256 response {sha(resp)}")
-    else:
-        record(request, f"config 5: all-trials: no ({host_gib_available():.0f} GiB of host memory available, 160 needed); trials 0, 7, 15 compared in full, response decodes")
+        assert_eq(got_t, want_t, f"config 5, trial {t}: first-dimension accumulators")
+        if t in (0, 7, 15):
+            shas.append(f"{t}:{sha(got_t)}")
+        v_ct[t] = M.fold_dim1(M.from_ntt(want_t), gsw, neg, s.ell, po.nu2)
+    record(request, f"config 5: first-dimension accumulators of all {s.trials} trials bit-exact in full (sha256 {' '.join(shas)})")
+    want_packed = M.pack(v_ct, vw, out_n, po.t_conv)
+    praw = M.from_ntt(want_packed)
+    want_resp = np.stack([np.array([M.rescale(int(x) % M.Q, M.Q, s.qprime if r == 0 else 4 * po.p_db) for x in praw[r].ravel()], dtype=np.uint64).reshape(praw[r].shape)
+                          for r in range(out_n + 1)])
+    assert_eq(packed, want_packed, "config 5: packed ciphertext")
+    assert_eq(resp, want_resp, "config 5: response")
+    record(request, f"config 5: all-trials: yes (streamed one trial at a time) -- packed ciphertext and response bit-exact over all {s.trials} trials; sha256 response {sha(resp)}")
     srv.close()
