@@ -7,10 +7,8 @@
 // 8 coefficients x 2 limbs in VGPRs and runs three radix-2 stages per pass with lazy u32 Harvey
 // butterflies; passes exchange data through a 16 KiB LDS tile (3 exchanges for 11 stages).
 // Outputs are canonical residues in [0, m).
-// (Round 2 measured the alternative with 16 coefficients per thread -- 128 threads per polynomial, passes of 4 + 4 + 3 stages,
-// two LDS exchanges instead of three, tools/ntt16_core.h: 4.5 % fewer VALU instructions per polynomial, but 114 VGPRs (4 waves
-// per SIMD instead of 8) and twice the serial work per thread: 9 % slower on wide batches (9.6 vs 8.8 ns per transform on the
-// same box) and +2 us per launch in the latency-bound narrow rounds.  This 8-coefficient form stays.)
+// (16 coefficients per thread -- 128 threads per polynomial, passes of 4 + 4 + 3 stages, two LDS exchanges -- was measured in round 2 and lost:
+// 4.5 % fewer VALU instructions but 114 VGPRs and twice the serial work per thread, 9 % slower on wide batches; HISTORY.md.)
 #pragma once
 #include "common.h"
 #ifndef TWI
