@@ -16,7 +16,8 @@ db = O.fill_db_random(99, O.db_words(po))
 mk = lambda shape: np.ascontiguousarray(np.stack([rng.integers(0, m, size=shape + (O.N,), dtype=np.uint64) for m in (O.P, O.B)], axis=-2))
 wl, wr = mk((s.n_left, 2, po.t_exp)), mk((s.n_right, 2, po.t_exp_right))
 w, v = mk((3, 8)), mk((3, 8)); q = mk((1, 2))
-print("sweep cell:", O.sweep_isa(), "| OMP env:", {k: v for k, v in os.environ.items() if k.startswith(("OMP_", "GOMP_"))})
+O.set_ntt_simd(True)  # the reference's USE_AVX2 transforms, as bench.py's cpu_baseline
+print("transforms:", O.ntt_isa(), "| sweep cell:", O.sweep_isa(), "| OMP env:", {k: v for k, v in os.environ.items() if k.startswith(("OMP_", "GOMP_"))})
 for th in [int(x) for x in sys.argv[1:]]:
     O.set_threads(th)
     for rep in range(2):  # the second pass is the warm one (scratch blocks cached by malloc, threads started)
