@@ -211,8 +211,10 @@ def model_features(nu_1, nu_2, t_GSW, t_conv, t_exp, t_exp_right=56, direct=0):
     f["conv_transforms"] = (dim0 + 2 * nu_2 * ell) * (1 + t_conv)
     f["conv_macs"] = dim0 * 6 * t_conv + nu_2 * ell * (6 * t_conv + 6 * t_conv)
     f["fold_rounds"] = nu_2
-    f["fold_transforms"] = (num_per - 1) * 2 * 6 * (ell + 1) if nu_2 else 0   # 2 np' cts x 6 polys x (1 lift + ell digits), summed over the rounds
-    f["fold_macs"] = (num_per - 1) * 6 * 2 * 3 * ell
+    # pair form of a fold round: per pair of ciphertexts 6 polynomials x (2 lifts + ell digit-difference transforms) and a
+    # product of m2 = 3 ell terms per output polynomial; summed over the rounds (np' = num_per/2 ... 1 pairs)
+    f["fold_transforms"] = (num_per - 1) * 6 * (ell + 2) if nu_2 else 0
+    f["fold_macs"] = (num_per - 1) * 6 * 3 * ell
     return f
 
 
