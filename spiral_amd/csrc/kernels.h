@@ -43,6 +43,8 @@ enum FwdLoad : uint32_t {
                     // with the source / destination maps of FwdParams::pmode
     LD_DBGEN1 = 7,  // SpiralPack database: 1 x 1 plaintext of (trial, item), centred lift (src/testing.cpp:845-869)
     LD_SDIFF = 8,   // fold round in pair form from lifted ciphertexts: difference of the balanced digits k of raw[np + i] and raw[i]
+    LD_PDIFF = 9,   // SpiralPack fold round in pair form from lifted ciphertexts [trial][2 np][2]: difference of the unsigned digits k of
+                    // ct np + i and ct i, destination D'[trial][i][row + 2k]  (foldCiphertextsDim1 through the identity of fold_pair_kernel)
     LD_EXPAND = 5,  // one expansion round: digits of automorph(c)[0] and the reduced automorph(c)[1] of every
                     // active ciphertext, both parities, in one launch      (src/spiral.cpp:1711-1720)
 };
@@ -321,7 +323,10 @@ void launch_qs1_from_cv(const uint64_t* cv, uint32_t* qs1, uint32_t dim0, uint32
 void launch_qs1_from_reoriented(const uint64_t* re, uint32_t* qs1, uint32_t dim0, hipStream_t s);
 // convertDb layout (:316-340) z*(num_per*dim0) + ii*dim0 + j -> device layout
 // foldCiphertextsDim1 product for `count` ciphertexts: out[b][2] = key[2][K] * d[b][K]   (src/testing.cpp:596-624)
-void launch_pack_fold_mac(const uint64_t* key, const uint64_t* d, uint64_t* out, uint32_t K, uint32_t count, hipStream_t s);
+// key_stride: polynomials between the key's two rows (0 = K); addend (pair form: out = L + F * D'): PK ciphertexts, ciphertext b = t * np + i at
+// polynomial (t * add_stride + i) * 2 + r of `addend`
+void launch_pack_fold_mac(const uint64_t* key, const uint64_t* d, uint64_t* out, uint32_t K, uint32_t count, hipStream_t s, uint32_t key_stride = 0,
+                          const uint64_t* addend = nullptr, uint32_t np = 1, uint32_t add_stride = 1);
 void launch_db1_relayout(const uint64_t* ref, uint64_t* dev, uint32_t num_per, uint32_t dim0, hipStream_t s);
 // gsw[i][r][2j] = tmp[i*ell+j][r], gsw[i][r][2j+1] = cv[2*(i*ell+j)+1][r]   (regevToSimpleGsw, :108-139)
 void launch_pack_gsw_assemble(const uint64_t* tmp, const uint64_t* cv, uint64_t* gsw, uint32_t ell, uint32_t nu2, hipStream_t s);

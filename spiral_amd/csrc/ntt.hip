@@ -314,6 +314,32 @@ __global__ __launch_bounds__(256, 8) void ntt_forward_kernel(Tables t, FwdParams
             rh[r] = sh_[ix_a(tid, r)];
         }
         sdigit_diff8([&](int r) { return rh[r]; }, [&](int r) { return rl[r]; }, k, p.bits, p.ell, lo, hi);
+    } else if constexpr (LOAD == LD_PDIFF) {
+        // SpiralPack fold round in pair form: source s = (trial t, pair i, row) over [nt][np][2]; lifted ciphertexts [t][2 np][2] at p.src;
+        // unsigned digits (gadget_invert, src/util.cpp:114), whose base-2^bits expansion always recomposes the value
+        const uint32_t ti = s >> 1, row = s & 1u, t = ti / p.fold_np, i = ti - t * p.fold_np;
+        const uint64_t* sl = p.src + ((size_t)(t * 2u * p.fold_np + i) * 2u + row) * kN;
+        const uint64_t* sh_ = p.src + ((size_t)(t * 2u * p.fold_np + p.fold_np + i) * 2u + row) * kN;
+        uint64_t rl[8], rh[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            rl[r] = sl[ix_a(tid, r)];
+            rh[r] = sh_[ix_a(tid, r)];
+        }
+        const uint64_t mask = (1ull << p.bits) - 1;
+        if (p.bits <= kSmallDigitBits) {
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+                signed_residues((int32_t)(uint32_t)digit_of(rh[r], k, p.bits, mask) - (int32_t)(uint32_t)digit_of(rl[r], k, p.bits, mask), lo[r], hi[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t dh = (uint32_t)digit_of(rh[r], k, p.bits, mask), dl = (uint32_t)digit_of(rl[r], k, p.bits, mask);
+                const uint32_t dp = dh % kP - dl % kP, db = dh % kB - dl % kB;
+                lo[r] = min(dp, dp + kP);
+                hi[r] = min(db, db + kB);
+            }
+        }
     } else if constexpr (LOAD == LD_LIMBS) {
         const uint64_t* src = p.src + (size_t)p.src_map(s) * (2 * kN);
 #pragma unroll
@@ -374,6 +400,8 @@ __global__ __launch_bounds__(256, 8) void ntt_forward_kernel(Tables t, FwdParams
             } else {
                 di = s * nd + k;
             }
+        } else if constexpr (LOAD == LD_PDIFF) {
+            di = (s >> 1) * (2u * p.n_digits) + 2u * k + (s & 1u);  // operand layout D'[t][i][row + 2k]
         } else if constexpr (LOAD == LD_SDIFF) {
             const uint32_t i = s / 6u, rc = s - i * 6u;  // operand layout D'[i][r + 3k][c]
             di = (i * 3u * p.ell + (rc >> 1) + 3u * k) * 2u + (rc & 1u);
@@ -770,6 +798,7 @@ void launch_ntt_forward(const DeviceTables& t, const FwdParams& p, uint32_t load
     FWD_CASE(LD_DIGIT, ST_PK)
     FWD_CASE(LD_SDIGIT, ST_PK)
     FWD_CASE(LD_SDIFF, ST_PK)
+    FWD_CASE(LD_PDIFF, ST_PK)
     FWD_CASE(LD_LIMBS, ST_REF)
     FWD_CASE(LD_LIMBS, ST_PK)
     FWD_CASE(LD_DBGEN, ST_DB)

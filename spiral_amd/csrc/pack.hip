@@ -303,15 +303,27 @@ struct PackAcc {
 };
 template <uint32_t B>
 __global__ __launch_bounds__(kTpb) void pack_fold_mac_kernel(const uint64_t* __restrict__ key, const uint64_t* __restrict__ d, uint64_t* __restrict__ out,
-                                                             uint32_t K) {
+                                                             uint32_t K, uint32_t ks, const uint64_t* __restrict__ add, uint32_t np, uint32_t add_stride) {
     __shared__ uint64_t sh[3][64][4 * B];
     const uint32_t zz = threadIdx.x & 63u, kg = threadIdx.x >> 6, z = blockIdx.x * 64u + zz, b0 = blockIdx.y * B;
     const uint64_t* dp = d + (size_t)b0 * K * kN + z;
     const uint64_t* kp = key + z;
     PackAcc acc[B][2];
+    if (add != nullptr && kg == 0) {  // pair form: the low ciphertext of the pair, requested before the product loop
+#pragma unroll
+        for (uint32_t b = 0; b < B; b++) {
+            const uint32_t t = (b0 + b) / np, i = (b0 + b) - t * np;
+#pragma unroll
+            for (uint32_t r = 0; r < 2; r++) {
+                const uint64_t a = add[((size_t)(t * add_stride + i) * 2 + r) * kN + z];
+                acc[b][r].lo = lo32(a);
+                acc[b][r].hi = hi32(a);
+            }
+        }
+    }
 #pragma unroll 4
     for (uint32_t m = kg; m < K; m += 4) {
-        const uint64_t k0 = kp[(size_t)m * kN], k1 = kp[(size_t)(K + m) * kN];
+        const uint64_t k0 = kp[(size_t)m * kN], k1 = kp[(size_t)(ks + m) * kN];
 #pragma unroll
         for (uint32_t b = 0; b < B; b++) {
             const uint64_t dv = __builtin_nontemporal_load(&dp[((size_t)b * K + m) * kN]);
@@ -344,12 +356,14 @@ __global__ __launch_bounds__(kTpb) void pack_fold_mac_kernel(const uint64_t* __r
             }
     }
 }
-void launch_pack_fold_mac(const uint64_t* key, const uint64_t* d, uint64_t* out, uint32_t K, uint32_t count, hipStream_t s) {
+void launch_pack_fold_mac(const uint64_t* key, const uint64_t* d, uint64_t* out, uint32_t K, uint32_t count, hipStream_t s, uint32_t key_stride,
+                          const uint64_t* addend, uint32_t np, uint32_t add_stride) {
     if (count == 0) return;
+    const uint32_t ks = key_stride ? key_stride : K;
     if (count % 4 == 0 && count >= 64)
-        hipLaunchKernelGGL(pack_fold_mac_kernel<4>, dim3(kN / 64, count / 4), dim3(kTpb), 0, s, key, d, out, K);
+        hipLaunchKernelGGL(pack_fold_mac_kernel<4>, dim3(kN / 64, count / 4), dim3(kTpb), 0, s, key, d, out, K, ks, addend, np, add_stride);
     else
-        hipLaunchKernelGGL(pack_fold_mac_kernel<1>, dim3(kN / 64, count), dim3(kTpb), 0, s, key, d, out, K);
+        hipLaunchKernelGGL(pack_fold_mac_kernel<1>, dim3(kN / 64, count), dim3(kTpb), 0, s, key, d, out, K, ks, addend, np, add_stride);
 }
 
 // arbitrary valid words (benchmarks)

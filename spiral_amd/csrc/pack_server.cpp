@@ -19,7 +19,7 @@ struct spiral_gpu_pack_server {
     uint32_t n_cv = 0;
     size_t db_words = 0;  // per trial
     DevBuf db, w_left, w_right, v, v_w, query, cv, ex_raw, ex_g;
-    DevBuf gs_raw, gs_chat, gs_tmp, gsw, key, qs1, acc, raw, fold_d, fold_c, pk_ginv, pk_ct2, pk_res, pk_raw, resp, stage, wire;
+    DevBuf gs_raw, gs_chat, gs_tmp, gsw, key, qs1, acc, raw, fold_d, fold_c, fold_c2, pk_ginv, pk_ct2, pk_res, pk_raw, resp, stage, wire;
     hipEvent_t ev[8] = {};
 };
 
@@ -53,7 +53,7 @@ int pack_shape_of(const spiral_gpu_params* p, uint32_t out_n, spiral_gpu_pack_sh
 
 void pk_free(spiral_gpu_pack_server* S) {
     DevBuf* all[] = {&S->db, &S->w_left, &S->w_right, &S->v, &S->v_w, &S->query, &S->cv, &S->ex_raw, &S->ex_g, &S->gs_raw, &S->gs_chat, &S->gs_tmp,
-                     &S->gsw, &S->key, &S->qs1, &S->acc, &S->raw, &S->fold_d, &S->fold_c, &S->pk_ginv, &S->pk_ct2, &S->pk_res, &S->pk_raw, &S->resp,
+                     &S->gsw, &S->key, &S->qs1, &S->acc, &S->raw, &S->fold_d, &S->fold_c, &S->fold_c2, &S->pk_ginv, &S->pk_ct2, &S->pk_res, &S->pk_raw, &S->resp,
                      &S->stage, &S->wire};
     for (DevBuf* b : all) b->release();
     for (auto& e : S->ev)
@@ -90,6 +90,7 @@ int pk_alloc(spiral_gpu_pack_server* S) {
     const size_t half = s.num_per / 2;
     if (S->fold_d.alloc((size_t)S->nt * half * 4 * s.ell * kN)) return -1;
     if (S->fold_c.alloc((size_t)S->nt * half * 2 * kN)) return -1;
+    if (S->fold_c2.alloc((size_t)S->nt * half * 2 * kN)) return -1;
     if (S->pk_ginv.alloc((size_t)s.trials * p.t_conv * kN)) return -1;
     if (S->pk_ct2.alloc((size_t)s.trials * kN)) return -1;
     if (S->pk_res.alloc(rows * S->out_n * kN)) return -1;
@@ -376,8 +377,38 @@ static int pk_front(spiral_gpu_pack_server* S, const uint64_t* query) {
     uint32_t np = s.num_per;
     const uint64_t* src = S->acc.p;
     uint32_t src_stride = s.num_per;
+    // Pair form (SPIRAL_FOLD_PAIR=0 keeps the reference's two products): folding_neg = gadget - F (:1027-1032), so
+    // F_neg G^-1(L) + F G^-1(H) = L + F (G^-1(H) - G^-1(L)) -- the unsigned digits always recompose their value -- i.e. per round one lift
+    // of the 2 np ciphertexts, ell digit-difference transforms per polynomial pair (LD_PDIFF) and a product of K = 2 ell terms + L.
+    static const bool pair = [] {
+        const char* e = getenv("SPIRAL_FOLD_PAIR");
+        return e ? atoi(e) != 0 : true;
+    }();
+    uint64_t* out = S->fold_c.p;
     for (uint32_t cur = 0; cur < p.nu2; cur++) {
         np /= 2;
+        if (src == out) out = out == S->fold_c.p ? S->fold_c2.p : S->fold_c.p;
+        if (pair) {
+            InvParams ip{};
+            ip.src = src;
+            ip.dst = S->raw.p;  // [t][2 np][2], compact
+            ip.src_map = IndexMap{4 * np, 2 * src_stride, 0};
+            ip.dst_map = identity_map();
+            launch_ntt_inverse(S->tb, ip, IST_CRT, nt * 4 * np, st);
+            FwdParams fp{};
+            fp.src = S->raw.p;
+            fp.dst = S->fold_d.p;
+            fp.src_map = fp.dst_map = identity_map();
+            fp.n_digits = ell;
+            fp.bits = get_bits_per(ell);
+            fp.fold_np = np;
+            fp.lazy_out = lazy_ok(2 * ell + 1) ? 1 : 0;  // pack_fold_mac sums 2 ell products and the addend per accumulator
+            launch_ntt_forward(S->tb, fp, LD_PDIFF, ST_PK, nt * np * 2 * ell, st);
+            launch_pack_fold_mac(S->key.p + ((size_t)cur * 2 * 4 * ell + 2 * ell) * kN, S->fold_d.p, out, 2 * ell, nt * np, st, 4 * ell, src, np, src_stride);
+            src = out;
+            src_stride = np;
+            continue;
+        }
         FoldChainParams cp{};
         cp.src = src;
         cp.dst = S->fold_d.p;
@@ -391,8 +422,8 @@ static int pk_front(spiral_gpu_pack_server* S, const uint64_t* query) {
         while (dpb > 1 && n_src * ((ell + dpb - 1) / dpb) < 768u) dpb = (dpb + 1) / 2;
         cp.dpb = dpb;
         launch_fold_chain(S->tb, cp, n_src, st);
-        launch_pack_fold_mac(S->key.p + (size_t)cur * 2 * 4 * ell * kN, S->fold_d.p, S->fold_c.p, 4 * ell, nt * np, st);
-        src = S->fold_c.p;
+        launch_pack_fold_mac(S->key.p + (size_t)cur * 2 * 4 * ell * kN, S->fold_d.p, out, 4 * ell, nt * np, st);
+        src = out;
         src_stride = np;
     }
     {

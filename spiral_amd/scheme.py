@@ -254,8 +254,9 @@ def pack_model_features(nu_1, nu_2, t_GSW, t_conv, t_exp, n, t_exp_right=56, dir
         f["conv_macs"] = nu_2 * ell * 2 * 2 * t_conv
     f["key_polys"] = nu_2 * 2 * 4 * ell  # fold keys assembled from the (uploaded or converted) GSW ciphertexts
     f["fold_rounds"] = nu_2
-    f["fold_transforms"] = trials * (4 * (num_per - 1) * (1 + ell) + 2)  # 2 np cts x 2 polys x (1 lift + ell digits) per round, + the last lift
-    f["fold_macs"] = trials * (num_per - 1) * 2 * 4 * ell
+    # pair form: per round 2 np cts x 2 polys lifted, np pairs x 2 polys x ell digit-difference transforms, a product of 2 ell terms; + the last lift
+    f["fold_transforms"] = trials * ((num_per - 1) * (4 + 2 * ell) + 2)
+    f["fold_macs"] = trials * (num_per - 1) * 2 * 2 * ell
     f["pack_transforms"] = trials * (1 + t_conv) + n * (n + 1)  # digits of every trial's row 0, the lift of the packed ct
     f["pack_macs"] = n * (n + 1) * n * t_conv
     return f
