@@ -292,7 +292,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     ap.add_argument("--overlap", type=int, default=0, help="1: Regev->GSW conversion on a side stream under the sweep (measured slower: the sweep loses "
-                    "more to the contention, 349 -> 422 us, than the 30 us of conversion it hides); 0: everything in order on one stream")
+                    "more to the contention than the conversion it hides); 2: the split schedule -- the odd tree of the expansion and the Regev->GSW "
+                    "conversion as their own launch sequence on a side stream beside the even tree + ScalToMat + sweep; 0: everything in order on one stream")
     ap.add_argument("--event-every", type=int, default=5, help="bracket the stages with HIP events on every n-th timed step only (1 = every step)")
     ap.add_argument("--root-fold", action="store_true", help="N > 1: plain reduce to rank 0, which lifts and folds alone")
     ap.add_argument("--no-batched-sweep", dest="batched_sweep", action="store_false", help="N = 1: skip the batched-sweep part of the throughput leg")
@@ -456,7 +457,7 @@ def bench_base(args, ctx, workload, steps, warmup, primary):
     if "pipelined" in schedules and n_stages < 2:
         raise SystemExit("--schedule pipelined: this geometry does not split into sweep stages (needs num_per >= 64)")
     srv.use_graphs(not args.no_graphs)  # expand+convert and lift+fold+finish replay as two hipGraphs
-    srv.set_overlap(bool(args.overlap))
+    srv.set_overlap(int(args.overlap))
 
     # HIP events bracket the stages (and give the sweep's launch duration for the roofline) on every event_every-th timed
     # step; an event record costs the stream ~6 us, so the other steps replay the whole query (one GPU) or everything before

@@ -220,6 +220,11 @@ int spiral_gpu_server_run_pre(spiral_gpu_server *s);
  * keys only the folding reads) onto an internal side stream, so that it executes under the HBM-bound first-dimension
  * sweep; fold / fold_local / fold_root / run_post / sync join it.  Results are identical, only the schedule changes. */
 int spiral_gpu_server_set_overlap(spiral_gpu_server *s, int on);
+/* on = 2, the split schedule: after round 0 the even-index and the odd-index trees of expandImproved never read each other (a ciphertext is
+ * created from the one 2^r slots below it, src/spiral.cpp:1709), and with stopround > 0 the evens are the first-dimension ciphertexts and the
+ * odds the GSW bits -- so the whole GSW side of a query (odd tree + regevToGSW + fold keys) runs as its own launch sequence on the side
+ * stream, forked when the query is set, beside the even tree + scalToMat + sweep on the server stream; the folding joins it.  run_query then
+ * issues three launch groups on two streams instead of one graph.  Needs query compression with stopround > 0 and an unsharded expansion. */
 int spiral_gpu_server_run_post(spiral_gpu_server *s, int reduce_first);
 /* the whole single-GPU answer (run_pre, first_dim, run_post(0)) as one group: with use_graphs on, one hipGraph launch
  * per query and no host-visible seam between the stages */

@@ -157,7 +157,11 @@ inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_
                 const uint64_t* w_right, uint32_t max_bits_right, uint32_t stopround, const ExpandWork& wk, hipStream_t st,
                 const uint64_t* query = nullptr,  // query: the packed query ciphertext when cv[0] does not hold it yet
                 uint32_t r_begin = 0, uint32_t r_end = 0xffffffffu,  // rounds [r_begin, min(r_end, g))
-                const ExpandShard& shard = ExpandShard{}) {
+                const ExpandShard& shard = ExpandShard{},
+                uint32_t parity = 3) {  // bit 0: the even-index ciphertexts, bit 1: the odd-index ones.  After round 0 the two trees never read each
+                                        // other (a ciphertext is created from the one num_in = 2^r slots below it: same parity for r >= 1, and in
+                                        // round 0 both come from the query), so with stopround > 0 -- evens = first-dimension ciphertexts, odds = GSW
+                                        // bits -- the two halves can run as independent launch sequences on their own work buffers
     // active odd-index ciphertexts of round r (:1701-1702); the even ones are all 2^r
     auto odd_count = [&](uint32_t r) {
         const uint32_t num_in = 1u << r;
@@ -168,10 +172,11 @@ inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_
     for (uint32_t r = r_begin; r < std::min(r_end, g); r++) {
         const uint32_t num_in = 1u << r;
         const uint32_t t = (kN >> r) + 1;
-        uint32_t cnt_even = num_in, cnt_odd = odd_count(r);
+        uint32_t cnt_even = (parity & 1u) ? num_in : 0u, cnt_odd = (parity & 2u) ? odd_count(r) : 0u;
+        if (cnt_even + cnt_odd == 0) continue;
         ExpandActive act{};
         if (shard.g_log) {
-            if (r > shard.j_log) {  // 2^(r - j_log) blocks of J even ciphertexts: this rank's is the one its low bits name
+            if (r > shard.j_log && cnt_even) {  // 2^(r - j_log) blocks of J even ciphertexts: this rank's is the one its low bits name
                 cnt_even = 1u << shard.j_log;
                 act.e_off = (shard.rank & ((1u << (r - shard.j_log)) - 1u)) << shard.j_log;
             }

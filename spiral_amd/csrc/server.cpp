@@ -32,7 +32,7 @@ struct spiral_gpu_server {
     // expanded-ciphertext positions inside cv: first-dim j at j*pos_stride + pos_first, rest i at i*pos_stride + pos_rest
     uint32_t pos_stride = 1, pos_first = 0, pos_rest = 0, n_cv = 0;
 
-    DevBuf db, w_left, w_right, w, v, query, cv, ex_raw, ex_g;
+    DevBuf db, w_left, w_right, w, v, query, cv, ex_raw, ex_g, ex_raw2, ex_g2;  // (the second work set: the odd tree of a split expansion)
     DevBuf cv_raw, cv_g, gsw, key, cts_keep;
     uint64_t *gs_raw_p = nullptr, *gs_chat_p = nullptr;  // the Regev->GSW halves of cv_raw / cv_g
     DevBuf qs, acc_own, raw, fold_d, fold_c, fold_c2, resp, stage;
@@ -47,7 +47,10 @@ struct spiral_gpu_server {
     void* cap_ct = nullptr;  // the caller's buffers captured into graphs 5 and 6
     // overlap mode: run_pre forks the Regev->GSW conversion (needed only by the folding) onto side_stream so that it
     // runs under the HBM-bound sweep; the fold entry points join it
-    bool overlap = false, side_pending = false;
+    // overlap 2 ("split"): the whole GSW side of the query -- the odd-index tree of the expansion AND the Regev->GSW conversion -- runs as its
+    // own launch sequence on side_stream, beside the even tree + ScalToMat + sweep on the main stream; only the folding needs it
+    int overlap = 0;
+    bool side_pending = false;
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_batch = nullptr;  // first_dim_batch: this lane's records are ready / the shared sweep is done
@@ -144,7 +147,7 @@ void srv_free(spiral_gpu_server* S, bool keep_db = false) {
         keep = S->db;
         S->db.p = nullptr;
     }
-    DevBuf* all[] = {&S->db, &S->w_left, &S->w_right, &S->w, &S->v, &S->query, &S->cv, &S->ex_raw, &S->ex_g, &S->cv_raw,
+    DevBuf* all[] = {&S->db, &S->w_left, &S->w_right, &S->w, &S->v, &S->query, &S->cv, &S->ex_raw, &S->ex_g, &S->ex_raw2, &S->ex_g2, &S->cv_raw,
                      &S->cv_g, &S->gsw, &S->key, &S->cts_keep, &S->qs, &S->acc_own, &S->raw, &S->fold_d, &S->fold_c, &S->fold_c2,
                      &S->resp, &S->stage, &S->wire};
     if (S->db_shared) S->db.p = nullptr;
@@ -1025,7 +1028,12 @@ int spiral_gpu_server_set_overlap(spiral_gpu_server* S, int on) {
     if (!S) return fail("null server");
     HIP_OK(hipSetDevice(S->device));
     if (srv_join_side(S)) return -1;
-    S->overlap = on != 0;
+    if (on == 2) {  // split: the odd tree needs its own work buffers, and evens / odds must be first-dimension / GSW ciphertexts
+        if (S->p.direct_upload || S->s.g == 0 || S->s.stopround == 0 || S->ex_shard.g_log) return fail("split overlap needs query compression with stopround > 0 on an unsharded expansion");
+        if (!S->ex_raw2.p && S->ex_raw2.alloc((size_t)S->n_cv * 2 * kN)) return -1;
+        if (!S->ex_g2.p && S->ex_g2.alloc(expand_g_polys(S->s.g, S->p.t_exp, S->p.t_exp_right) * kN)) return -1;
+    }
+    S->overlap = on == 2 ? 2 : (on != 0 ? 1 : 0);
     srv_drop_graphs(S);
     return 0;
 }
@@ -1281,6 +1289,7 @@ int spiral_gpu_server_set_expand_shard(spiral_gpu_server* S, uint32_t rank, uint
     }
     if ((n_ranks & (n_ranks - 1)) || n_ranks > S->s.dim0 || rank >= n_ranks) return fail("expansion shard %u of %u: the rank count must be a power of two <= dim0", rank, n_ranks);
     if (S->p.direct_upload || S->s.stopround == 0) return fail("sharded expansion needs query compression with stopround > 0");
+    if (S->overlap == 2) return fail("sharded expansion and the split overlap schedule exclude each other");
     const uint32_t per = S->s.dim0 / n_ranks;
     if (S->j0 != rank * per || S->j1 != (rank + 1) * per) return fail("sharded expansion: this server must hold first-dimension block %u of %u, it holds [%u, %u)", rank, n_ranks, S->j0, S->j1);
     S->ex_shard = ExpandShard{rank, ceil_log2(n_ranks), S->p.nu1 - ceil_log2(n_ranks)};
@@ -1377,6 +1386,30 @@ int spiral_gpu_server_run_pre(spiral_gpu_server* S) {
     HIP_OK(hipSetDevice(S->device));
     if (!S->have_query || !S->have_pp) return fail("query and public parameters must be set first");
     if (!S->overlap) return run_group(S, 0, S->stream, [&]() { return expand_convert(S); });
+    if (S->overlap == 2) {
+        // split: [odd tree of the expansion + Regev->GSW + fold keys] on the side stream, forked HERE (it depends on the query only),
+        // [even tree + ScalToMat] on the main stream; the fold joins the side stream
+        if (srv_join_side(S)) return -1;
+        HIP_OK(hipEventRecord(S->ev_fork, S->stream));  // the previous query's fold has read its keys; the new query is uploaded
+        HIP_OK(hipStreamWaitEvent(S->side_stream, S->ev_fork, 0));
+        const spiral_gpu_params& p = S->p;
+        auto half = [&](uint32_t parity, hipStream_t st, uint64_t* raw, uint64_t* g) {
+            ExpandWork wk{raw, g};
+            run_expand(S->tb, S->cv.p, S->s.g, p.t_exp, S->w_left.p, p.t_exp_right, S->w_right.p, S->s.ell * p.nu2, S->s.stopround, wk, st, S->query.p, 0, 0xffffffffu,
+                       ExpandShard{}, parity);
+        };
+        if (run_group(S, 3, S->side_stream, [&]() {
+                half(2u, S->side_stream, S->ex_raw2.p, S->ex_g2.p);
+                return convert_gsw(S, S->side_stream);
+            }))
+            return -1;
+        HIP_OK(hipEventRecord(S->ev_join, S->side_stream));
+        S->side_pending = true;
+        return run_group(S, 0, S->stream, [&]() {
+            half(1u, S->stream, S->ex_raw.p, S->ex_g.p);
+            return convert_scal2mat(S, S->stream);
+        });
+    }
     // overlap mode: expansion + ScalToMat on the main stream (the sweep needs only these); the Regev->GSW conversion
     // is forked onto the side stream and joined by the fold
     if (srv_join_side(S)) return -1;
@@ -1398,6 +1431,11 @@ int spiral_gpu_server_run_query(spiral_gpu_server* S) {
     HIP_OK(hipSetDevice(S->device));
     if (!S->have_query || !S->have_pp) return fail("query and public parameters must be set first");
     if (!S->have_db) return fail("no database loaded");
+    if (S->overlap == 2) {  // the split schedule is three launch groups on two streams, not one graph
+        if (spiral_gpu_server_run_pre(S)) return -1;
+        if (spiral_gpu_server_first_dim(S)) return -1;
+        return spiral_gpu_server_run_post(S, 0);
+    }
     if (srv_join_side(S)) return -1;
     return run_group(S, 4, S->stream, [&]() {
         if (expand_convert(S)) return -1;

@@ -125,9 +125,11 @@ class Server:
     def use_graphs(self, on: bool = True):
         check(lib().spiral_gpu_server_use_graphs(self.h, 1 if on else 0))
 
-    def set_overlap(self, on: bool = True):
-        """run the Regev->GSW conversion on a side stream under the sweep (same results, different schedule)"""
-        check(lib().spiral_gpu_server_set_overlap(self.h, 1 if on else 0))
+    def set_overlap(self, on=True):
+        """1 / True: run the Regev->GSW conversion on a side stream under the sweep; 2: the split schedule -- the whole GSW side of the query (the
+        odd tree of the expansion + the conversion) as its own launch sequence on the side stream beside the even tree + ScalToMat + sweep
+        (same results, different schedule)"""
+        check(lib().spiral_gpu_server_set_overlap(self.h, int(on)))
 
     def run_pre(self):
         """expand + convert (one hipGraph replay when graphs are on)"""

@@ -24,6 +24,8 @@ for cfg in args or [""]:
     srv.set_pub_params(mk((s.n_left, 2, pg.t_exp)), mk((s.n_right, 2, pg.t_exp_right)), mk((3, 2 * pg.t_conv)), mk((3, 2 * pg.t_conv)))
     srv.set_query(mk((1, 2)))
     srv.use_graphs(True)
+    if "overlap" in opts:
+        srv.set_overlap(int(opts["overlap"]))
     out = {}
     for name, fn in (("pre", srv.run_pre), ("sweep", srv.first_dim), ("post", srv.run_post), ("query", srv.run_query)):
         for _ in range(5):
