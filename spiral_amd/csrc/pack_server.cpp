@@ -380,10 +380,8 @@ static int pk_front(spiral_gpu_pack_server* S, const uint64_t* query) {
     // Pair form (SPIRAL_FOLD_PAIR=0 keeps the reference's two products): folding_neg = gadget - F (:1027-1032), so
     // F_neg G^-1(L) + F G^-1(H) = L + F (G^-1(H) - G^-1(L)) -- the unsigned digits always recompose their value -- i.e. per round one lift
     // of the 2 np ciphertexts, ell digit-difference transforms per polynomial pair (LD_PDIFF) and a product of K = 2 ell terms + L.
-    static const bool pair = [] {
-        const char* e = getenv("SPIRAL_FOLD_PAIR");
-        return e ? atoi(e) != 0 : true;
-    }();
+    const char* pair_env = getenv("SPIRAL_FOLD_PAIR");  // (read per call: tests switch it inside one process)
+    const bool pair = pair_env ? atoi(pair_env) != 0 : true;
     uint64_t* out = S->fold_c.p;
     for (uint32_t cur = 0; cur < p.nu2; cur++) {
         np /= 2;
