@@ -224,7 +224,9 @@ int spiral_gpu_server_set_overlap(spiral_gpu_server *s, int on);
  * created from the one 2^r slots below it, src/spiral.cpp:1709), and with stopround > 0 the evens are the first-dimension ciphertexts and the
  * odds the GSW bits -- so the whole GSW side of a query (odd tree + regevToGSW + fold keys) runs as its own launch sequence on the side
  * stream, forked when the query is set, beside the even tree + scalToMat + sweep on the server stream; the folding joins it.  run_query then
- * issues three launch groups on two streams instead of one graph.  Needs query compression with stopround > 0 and an unsharded expansion. */
+ * issues three launch groups on two streams instead of one graph.  Needs query compression with stopround > 0 and an unsharded expansion.
+ * on = 3: the same side sequence forked after the even tree + scalToMat, i.e. under the sweep.  Measured (profiles/r04_split_overlap.txt): 2 is
+ * within noise of the in-order schedule, 3 is 15 % slower; both are off by default. */
 int spiral_gpu_server_run_post(spiral_gpu_server *s, int reduce_first);
 /* the whole single-GPU answer (run_pre, first_dim, run_post(0)) as one group: with use_graphs on, one hipGraph launch
  * per query and no host-visible seam between the stages */

@@ -1028,12 +1028,12 @@ int spiral_gpu_server_set_overlap(spiral_gpu_server* S, int on) {
     if (!S) return fail("null server");
     HIP_OK(hipSetDevice(S->device));
     if (srv_join_side(S)) return -1;
-    if (on == 2) {  // split: the odd tree needs its own work buffers, and evens / odds must be first-dimension / GSW ciphertexts
+    if (on == 2 || on == 3) {  // split: the odd tree needs its own work buffers, and evens / odds must be first-dimension / GSW ciphertexts
         if (S->p.direct_upload || S->s.g == 0 || S->s.stopround == 0 || S->ex_shard.g_log) return fail("split overlap needs query compression with stopround > 0 on an unsharded expansion");
         if (!S->ex_raw2.p && S->ex_raw2.alloc((size_t)S->n_cv * 2 * kN)) return -1;
         if (!S->ex_g2.p && S->ex_g2.alloc(expand_g_polys(S->s.g, S->p.t_exp, S->p.t_exp_right) * kN)) return -1;
     }
-    S->overlap = on == 2 ? 2 : (on != 0 ? 1 : 0);
+    S->overlap = (on == 2 || on == 3) ? on : (on != 0 ? 1 : 0);
     srv_drop_graphs(S);
     return 0;
 }
@@ -1289,7 +1289,7 @@ int spiral_gpu_server_set_expand_shard(spiral_gpu_server* S, uint32_t rank, uint
     }
     if ((n_ranks & (n_ranks - 1)) || n_ranks > S->s.dim0 || rank >= n_ranks) return fail("expansion shard %u of %u: the rank count must be a power of two <= dim0", rank, n_ranks);
     if (S->p.direct_upload || S->s.stopround == 0) return fail("sharded expansion needs query compression with stopround > 0");
-    if (S->overlap == 2) return fail("sharded expansion and the split overlap schedule exclude each other");
+    if (S->overlap >= 2) return fail("sharded expansion and the split overlap schedules exclude each other");
     const uint32_t per = S->s.dim0 / n_ranks;
     if (S->j0 != rank * per || S->j1 != (rank + 1) * per) return fail("sharded expansion: this server must hold first-dimension block %u of %u, it holds [%u, %u)", rank, n_ranks, S->j0, S->j1);
     S->ex_shard = ExpandShard{rank, ceil_log2(n_ranks), S->p.nu1 - ceil_log2(n_ranks)};
@@ -1386,13 +1386,23 @@ int spiral_gpu_server_run_pre(spiral_gpu_server* S) {
     HIP_OK(hipSetDevice(S->device));
     if (!S->have_query || !S->have_pp) return fail("query and public parameters must be set first");
     if (!S->overlap) return run_group(S, 0, S->stream, [&]() { return expand_convert(S); });
-    if (S->overlap == 2) {
-        // split: [odd tree of the expansion + Regev->GSW + fold keys] on the side stream, forked HERE (it depends on the query only),
-        // [even tree + ScalToMat] on the main stream; the fold joins the side stream
+    if (S->overlap >= 2) {
+        // split: [odd tree of the expansion + Regev->GSW + fold keys] on the side stream, [even tree + ScalToMat] on the main stream; the fold
+        // joins the side stream.  Mode 2 forks HERE (the side depends on the query only: it runs beside the even tree); mode 3 forks after the
+        // main group, so that the side runs UNDER the sweep (whose 16-wave workgroups of 65 VGPRs leave room for three transform workgroups per CU)
         if (srv_join_side(S)) return -1;
+        const spiral_gpu_params& p = S->p;
+        if (S->overlap == 3) {
+            if (run_group(S, 0, S->stream, [&]() {
+                    ExpandWork wk{S->ex_raw.p, S->ex_g.p};
+                    run_expand(S->tb, S->cv.p, S->s.g, p.t_exp, S->w_left.p, p.t_exp_right, S->w_right.p, S->s.ell * p.nu2, S->s.stopround, wk, S->stream, S->query.p, 0,
+                               0xffffffffu, ExpandShard{}, 1u);
+                    return convert_scal2mat(S, S->stream);
+                }))
+                return -1;
+        }
         HIP_OK(hipEventRecord(S->ev_fork, S->stream));  // the previous query's fold has read its keys; the new query is uploaded
         HIP_OK(hipStreamWaitEvent(S->side_stream, S->ev_fork, 0));
-        const spiral_gpu_params& p = S->p;
         auto half = [&](uint32_t parity, hipStream_t st, uint64_t* raw, uint64_t* g) {
             ExpandWork wk{raw, g};
             run_expand(S->tb, S->cv.p, S->s.g, p.t_exp, S->w_left.p, p.t_exp_right, S->w_right.p, S->s.ell * p.nu2, S->s.stopround, wk, st, S->query.p, 0, 0xffffffffu,
@@ -1405,6 +1415,7 @@ int spiral_gpu_server_run_pre(spiral_gpu_server* S) {
             return -1;
         HIP_OK(hipEventRecord(S->ev_join, S->side_stream));
         S->side_pending = true;
+        if (S->overlap == 3) return 0;
         return run_group(S, 0, S->stream, [&]() {
             half(1u, S->stream, S->ex_raw.p, S->ex_g.p);
             return convert_scal2mat(S, S->stream);
@@ -1431,7 +1442,7 @@ int spiral_gpu_server_run_query(spiral_gpu_server* S) {
     HIP_OK(hipSetDevice(S->device));
     if (!S->have_query || !S->have_pp) return fail("query and public parameters must be set first");
     if (!S->have_db) return fail("no database loaded");
-    if (S->overlap == 2) {  // the split schedule is three launch groups on two streams, not one graph
+    if (S->overlap >= 2) {  // the split schedules are three launch groups on two streams, not one graph
         if (spiral_gpu_server_run_pre(S)) return -1;
         if (spiral_gpu_server_first_dim(S)) return -1;
         return spiral_gpu_server_run_post(S, 0);

@@ -350,7 +350,7 @@ def test_fold_chain_schedules(sa, oracle, env, monkeypatch):
     srv.close()
 
 
-@pytest.mark.parametrize("graphs,overlap", [(True, False), (True, True), (False, True), (True, 2), (False, 2)])
+@pytest.mark.parametrize("graphs,overlap", [(True, False), (True, True), (False, True), (True, 2), (False, 2), (True, 3)])
 def test_graph_replay_matches_eager(sa, oracle, graphs, overlap):
     """run_pre / run_post captured into hipGraphs and replayed for several queries == the eager stages; in overlap
     mode the Regev->GSW conversion runs on the side stream under the sweep and the fold joins it"""
