@@ -631,7 +631,8 @@ __global__ __launch_bounds__(256, 8) void ntt_inverse_kernel(Tables t, InvParams
 // (polynomial, digit), every digit job repeating the inverse transform (the last rounds, which are latency-bound); the host
 // picks dpb per round so that a round is about as many blocks as the chip holds.
 // (register budget: 103 VGPRs = 4 workgroups per CU.  Forcing 5 or 6 through the launch bound spills 24 / 84 bytes per thread and
-// measured 0 / +30 us on the fold, profiles/r03_variants.txt; holding one twiddle row set instead of two does not lower the count.)
+// measured 0 / +30 us on the fold, profiles/r03_variants.txt; holding one twiddle row set instead of two does not lower the count.
+// Since round 4 this two-product form is the fallback of the pair form below: SPIRAL_FOLD_PAIR=0, gadget dimensions whose digits do not recompose.)
 __global__ __launch_bounds__(256) void fold_chain_kernel(Tables t, FoldChainParams p) {
     __shared__ uint64_t sh[kLdsWords];
     const uint32_t tid = threadIdx.x, b = blockIdx.x;
