@@ -65,6 +65,7 @@ struct FwdParams {
     IndexMap src_map;   // s -> source polynomial index
     IndexMap dst_map;   // b -> destination polynomial index (ST_PK / ST_REF)
     uint32_t n_digits;  // b -> (s = b / n_digits, k = b % n_digits)
+    uint32_t inv_n_digits, inv_te, inv_to;  // 2^32 / d + 1 for the three job-index divisors (filled in by launch_ntt_forward)
     uint32_t bits;      // digit width
     uint32_t ell;       // LD_SDIGIT: digits per value (t_GSW)
     uint32_t tinv;      // automorphism gather x -> x^t folded into the load: t^-1 mod 2N, 0 = none

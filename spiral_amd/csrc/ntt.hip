@@ -34,6 +34,25 @@ __device__ __forceinline__ uint64_t digit_of(uint64_t v, uint32_t k, uint32_t bi
     return sh >= 64 ? 0ull : ((v >> sh) & mask);  // a shift count >= 64 is UB in src/util.cpp:136; defined as 0
 }
 
+// unsigned digits k of a thread's 8 coefficients, digit width <= 27 bits: which word the digit starts in is wave-uniform, so the choice is
+// made once around the loop (inside it the compiler turns it into two selects per value)
+__device__ __forceinline__ void udigits8(const uint64_t* raw, uint32_t k, uint32_t bits, uint32_t* d) {
+    const uint32_t sh = k * bits, mask = (1u << bits) - 1u;
+    if (sh >= 64u) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) d[r] = 0;
+    } else if (sh >= 32u) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) d[r] = (hi32(raw[r]) >> (sh - 32u)) & mask;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; r++) d[r] = __builtin_amdgcn_alignbit(hi32(raw[r]), lo32(raw[r]), sh) & mask;
+    }
+}
+// b / d for a wave-uniform job index b and a small divisor (digit counts <= 56, b < 2^26) as one scalar multiply: inv = 2^32 / d + 1
+// (launch_ntt_forward fills it in); the plain division is a float reciprocal sequence on the vector ALU
+__device__ __forceinline__ uint32_t udiv_small(uint32_t b, uint32_t d, uint32_t inv) { return d == 1u ? b : __umulhi(b, inv); }
+
 // a gadget digit is < 2^bits <= 2^32 (bits = 32 only through the to_ntt_no_reduce seam, whose contract is
 // values < 2^29); the forward transform wants its inputs below 2m.
 // SMALL: the digit width is at most 27 bits -- every published parameter set (bits = floor(56/t) + 1 <= 15 for t >= 4; 29 only
@@ -199,7 +218,7 @@ template <uint32_t LOAD, uint32_t STORE>
 __global__ __launch_bounds__(256, 8) void ntt_forward_kernel(Tables t, FwdParams p) {
     __shared__ uint64_t sh[kLdsWords];
     const uint32_t tid = threadIdx.x, b = blockIdx.x;
-    uint32_t s = b / p.n_digits, k = b - s * p.n_digits;
+    uint32_t s = udiv_small(b, p.n_digits, p.inv_n_digits), k = b - s * p.n_digits;
     uint32_t lo[8], hi[8];
 
     if constexpr (LOAD == LD_DBGEN) {
@@ -261,27 +280,30 @@ __global__ __launch_bounds__(256, 8) void ntt_forward_kernel(Tables t, FwdParams
         uint64_t raw[8];  // all eight requested before the digit-width branch (inside it, the compiler waits for the first alone)
 #pragma unroll
         for (int r = 0; r < 8; r++) raw[r] = src[ix_a(tid, r)];
-        auto body = [&](auto small) {
+        if (p.bits <= kSmallDigitBits) {
+            udigits8(raw, k, p.bits, lo);
+#pragma unroll
+            for (int r = 0; r < 8; r++) hi[r] = lo[r];
+        } else {
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 uint32_t d = (uint32_t)digit_of(raw[r], k, p.bits, mask);
-                lo[r] = digit_residue<decltype(small)::value>(d, kP);
-                hi[r] = digit_residue<decltype(small)::value>(d, kB);
+                lo[r] = digit_residue<false>(d, kP);
+                hi[r] = digit_residue<false>(d, kB);
             }
-        };
-        DIGIT_WIDTH_DISPATCH(p.bits, body);
+        }
     } else if constexpr (LOAD == LD_EXPAND) {
         // job b -> (active ct a, digit k of automorph(c)[0])
         const uint32_t je = p.cnt_e * p.t_e;
         uint32_t a, tdim;
         if (b < je) {
             tdim = p.t_e;
-            a = b / tdim;
+            a = udiv_small(b, tdim, p.inv_te);
             k = b - a * tdim;
         } else {
             tdim = p.t_o;
             const uint32_t bb = b - je;
-            a = bb / tdim;
+            a = udiv_small(bb, tdim, p.inv_to);
             k = bb - a * tdim;
             a += p.cnt_e;
         }
@@ -290,16 +312,19 @@ __global__ __launch_bounds__(256, 8) void ntt_forward_kernel(Tables t, FwdParams
 #pragma unroll
         for (int r = 0; r < 8; r++) raw[r] = src[ix_a(tid, r)];
         const uint32_t bits = get_bits_per(tdim);
-        const uint64_t mask = (1ull << bits) - 1;
-        auto body = [&](auto small) {
+        if (bits <= kSmallDigitBits) {  // (the source is already automorphed by the inverse pass)
+            udigits8(raw, k, bits, lo);
+#pragma unroll
+            for (int r = 0; r < 8; r++) hi[r] = lo[r];
+        } else {
+            const uint64_t mask = (1ull << bits) - 1;
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                const uint32_t d = (uint32_t)digit_of(raw[r], k, bits, mask);  // already automorphed by the inverse pass
-                lo[r] = digit_residue<decltype(small)::value>(d, kP);
-                hi[r] = digit_residue<decltype(small)::value>(d, kB);
+                const uint32_t d = (uint32_t)digit_of(raw[r], k, bits, mask);
+                lo[r] = digit_residue<false>(d, kP);
+                hi[r] = digit_residue<false>(d, kB);
             }
-        };
-        DIGIT_WIDTH_DISPATCH(bits, body);
+        }
         s = b;
     } else if constexpr (LOAD == LD_SDIFF) {
         // pair form of a fold round from lifted ciphertexts (see fold_pair_kernel): source s = (pair i, r, c) over [np][3][2],
@@ -775,8 +800,13 @@ __global__ __launch_bounds__(256) void pk_to_ref_kernel(const uint64_t* pk, uint
         return;                                                                                         \
     }
 
-void launch_ntt_forward(const DeviceTables& t, const FwdParams& p, uint32_t load, uint32_t store, uint32_t nblocks, hipStream_t s) {
+void launch_ntt_forward(const DeviceTables& t, const FwdParams& p_in, uint32_t load, uint32_t store, uint32_t nblocks, hipStream_t s) {
     if (nblocks == 0) return;
+    FwdParams p = p_in;
+    auto inv = [](uint32_t d) { return d > 1u ? (uint32_t)((1ull << 32) / d + 1ull) : 0u; };  // udiv_small
+    p.inv_n_digits = inv(p.n_digits);
+    p.inv_te = inv(p.t_e);
+    p.inv_to = inv(p.t_o);
     Tables tb{t.fwd, t.inv};
     // Two digits per workgroup on one twiddle fetch (ntt_forward2_kernel) pay in steady state only -- 14-24 % from 16 k transforms up, nothing
     // at one or two generations of resident workgroups (profiles/r04_twiddle_sharing.txt): used from kFwd2Min transforms per launch.
