@@ -217,7 +217,13 @@ __device__ __forceinline__ void pk_load8_red(const uint64_t* poly, bool reduce, 
 template <uint32_t LOAD, uint32_t STORE>
 __global__ __launch_bounds__(256, 8) void ntt_forward_kernel(Tables t, FwdParams p) {
     __shared__ uint64_t sh[kLdsWords];
-    const uint32_t tid = threadIdx.x, b = blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+    uint32_t b = blockIdx.x;
+    // the ell digit jobs of a polynomial pair read the same 32 KiB of lifted coefficients: consecutive JOBS (not block ids, which are dealt
+    // round-robin to the 8 XCDs) go to one XCD, so that its L2 serves the re-reads (-3.5 us on the fold of config 2; the one-source digit
+    // launches measured +-0 with the same map in round 2 and +5 us on expand + convert now: they keep the plain order)
+    if constexpr (LOAD == LD_SDIFF || LOAD == LD_PDIFF)
+        if ((gridDim.x & 7u) == 0) b = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     uint32_t s = udiv_small(b, p.n_digits, p.inv_n_digits), k = b - s * p.n_digits;
     uint32_t lo[8], hi[8];
 
