@@ -163,7 +163,7 @@ def test_bench_two_rank_flow_on_one_gpu():
     import subprocess
 
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--backend", "gloo", "--shared-device", "--no-config3"]
+           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--backend", "gloo", "--shared-device", "--prewarm", "2", "--no-config3"]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
@@ -181,7 +181,7 @@ def test_bench_self_launch_without_launcher():
     import subprocess
 
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--backend", "gloo", "--shared-device", "--config3-steps", "2"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--backend", "gloo", "--shared-device", "--prewarm", "2", "--config3-steps", "2"]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
@@ -202,7 +202,7 @@ def test_bench_eight_ranks_on_one_gpu():
     import subprocess
 
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--shared-device", "--nu1", "7", "--nu2", "6", "--no-config3"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--shared-device", "--prewarm", "2", "--nu1", "7", "--nu2", "6", "--no-config3"]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
@@ -222,7 +222,7 @@ def test_bench_rccl_world_size_one(extra):
     import subprocess
 
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--force-dist", "--backend", "nccl", "--no-cpu-baseline", "--no-config3"] + extra
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--force-dist", "--prewarm", "2", "--backend", "nccl", "--no-cpu-baseline", "--no-config3"] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
@@ -237,14 +237,14 @@ def test_bench_pack_trial_shards():
     import subprocess
 
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-           str(_free_port()), os.path.join(ROOT, "bench.py"), "--workload", "pack", "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--shared-device"]
+           str(_free_port()), os.path.join(ROOT, "bench.py"), "--workload", "pack", "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--shared-device", "--prewarm", "2"]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["value"] > 0 and "trials x2 (8 per rank)" in out["config"]["parallelism"] and out["roofline"]["achieved"] > 0
     assert out["rccl"]["world_size"] == 2 and [x["rank"] for x in out["rccl"]["ranks_seen"]] == [0, 1] and out["collectives_us"]["all_gather_folded_trials"] > 0
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "pack", "--gpus", "1", "--steps", "3", "--warmup", "1", "--force-dist", "--backend", "nccl"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "pack", "--gpus", "1", "--steps", "3", "--warmup", "1", "--force-dist", "--prewarm", "2", "--backend", "nccl"]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
