@@ -61,9 +61,11 @@ struct spiral_gpu_server {
     // pair form of a chained fold round (fold_pair_kernel: out = C[i] + Q * NTT(G^-1(C[np+i]) - G^-1(C[i])), half the forward
     // transforms and half the product); SPIRAL_FOLD_PAIR=0 keeps the reference's two-product form (tests compare both)
     bool fold_pair = true;
-    // pair-form rounds with at least this many polynomial pairs run unchained (lift launch + LD_SDIFF digit launch + product); the
-    // narrower ones chain the lift into the digit transforms (one launch less).  SPIRAL_FOLD_UNCHAIN_MIN overrides.
-    uint32_t fold_unchain_min = 48;
+    // pair-form rounds with at least this many polynomial pairs run unchained (lift launch + LD_SDIFF digit launch + product); narrower
+    // ones would chain the lift into the digit transforms (fold_team_kernel / fold_pair_kernel: one launch less, the two inverse transforms
+    // repeated per digit chunk).  Measured equal within 1-2 us for the narrow rounds of config 2 and slower for the wide ones
+    // (profiles/r04_fold_pair.txt), so every round runs unchained by default; SPIRAL_FOLD_UNCHAIN_MIN selects the chained forms (tests, A/B).
+    uint32_t fold_unchain_min = 1;
     bool fold_team = true;  // SPIRAL_FOLD_TEAM=0: fold_pair_kernel (one 256-thread workgroup runs both inverse transforms)
     uint32_t fold_blocks = 768;
     uint32_t fold_g_log = 0;  // distributed fold over 2^fold_g_log ranks: the sweep groups its output by ii mod G

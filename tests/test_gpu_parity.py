@@ -311,7 +311,7 @@ def test_load_db_in_several_staging_passes(sa, oracle, monkeypatch):
     {"SPIRAL_FOLD_BLOCKS": "0"},         # pair form (fold_pair_kernel), one block per polynomial pair (all digits) every round
     {"SPIRAL_FOLD_BLOCKS": "1000000"},   # one block per (polynomial pair, digit) every round
     {"SPIRAL_FOLD_BLOCKS": "300"},       # mixed chunk sizes
-    {"SPIRAL_FOLD_UNCHAIN_MIN": "1"},                           # pair form, every round unchained (lift launch + LD_SDIFF digit launch)
+    {"SPIRAL_FOLD_UNCHAIN_MIN": "48"},                          # pair form, wide rounds unchained (the default is every round), narrow ones as 512-thread teams
     {"SPIRAL_FOLD_UNCHAIN_MIN": "1000000"},                     # pair form, every round chained (fold_team_kernel)
     {"SPIRAL_FOLD_UNCHAIN_MIN": "1000000", "SPIRAL_FOLD_BLOCKS": "0"},
     {"SPIRAL_FOLD_UNCHAIN_MIN": "1000000", "SPIRAL_FOLD_BLOCKS": "1000000"},
