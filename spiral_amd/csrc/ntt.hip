@@ -403,10 +403,19 @@ __global__ __launch_bounds__(256, 8) void ntt_forward_kernel(Tables t, FwdParams
                 }
             }
         };
-        if constexpr (LOAD == LD_RAW)
+        if constexpr (LOAD == LD_RAW) {
             body(std::false_type{});
-        else
+        } else if constexpr (LOAD == LD_DIGIT) {
+            if (p.bits <= kSmallDigitBits) {  // the word choice hoisted out of the loop (udigits8)
+                udigits8(raw, k, p.bits, lo);
+#pragma unroll
+                for (int r = 0; r < 8; r++) hi[r] = lo[r];
+            } else {
+                body(std::false_type{});
+            }
+        } else {
             DIGIT_WIDTH_DISPATCH(p.bits, body);
+        }
     }
 
     ntt_forward_block<false>(lo, hi, sh, t.fwd, tid);
