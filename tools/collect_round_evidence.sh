@@ -10,10 +10,10 @@ F="--no-cpu-baseline --no-config3 --lanes 1"
 python bench.py > $O/${R}_bench.json 2> $O/${R}_bench.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --steps 20 --warmup 3 $F > $O/${R}_bench_under_rocprof.log 2>&1
 cp $O/kt/*/*_kernel_stats.csv $O/${R}_bench_kernel_stats.csv
-# query 11 of the trace = timed step 6: a whole-query graph replay (steps 0, 5, 10, 15 are the sampled ones, whose hipEventRecords between the
-# stages show up as gaps); query 10 = timed step 5, a sampled step, kept beside it and labelled
+# the trace holds, in order: 2 priming queries, --prewarm (40) queries, 3 warm-up steps, 20 timed steps, then the standalone sweep launches.  Query 11 is a
+# pre-warm query = a whole-query graph replay (no gaps); query 50 is timed step 5, a SAMPLED step, whose hipEventRecords between the stages show up as gaps
 python tools/trace_summary.py $O/kt/*/*_kernel_trace.csv --timeline --query 11 > $O/${R}_one_query_timeline.txt
-python tools/trace_summary.py $O/kt/*/*_kernel_trace.csv --timeline --query 10 > $O/${R}_one_query_timeline_sampled_step.txt
+python tools/trace_summary.py $O/kt/*/*_kernel_trace.csv --timeline --query 50 > $O/${R}_one_query_timeline_sampled_step.txt
 python tools/kernel_avg.py $O/kt/*/*_kernel_trace.csv "" --by-grid > $O/${R}_kernel_avg_by_grid.txt
 rm -rf $O/kt
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 4 --warmup 1 $F --no-graphs > $O/pmc_fetch.log 2>&1
