@@ -292,8 +292,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prewarm", type=int, default=40, help="untimed queries run as part of the set-up before the W warm-up steps, to ramp the GPU's clocks (0 = none)")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
-    ap.add_argument("--overlap", type=int, default=0, help="1: Regev->GSW conversion on a side stream under the sweep (measured slower: the sweep loses "
-                    "more to the contention than the conversion it hides); 2: the split schedule -- the odd tree of the expansion and the Regev->GSW "
+    ap.add_argument("--overlap", type=int, default=0, choices=[0, 2], help="2: the split schedule -- the odd tree of the expansion and the Regev->GSW "
                     "conversion as their own launch sequence on a side stream beside the even tree + ScalToMat + sweep; 0: everything in order on one stream")
     ap.add_argument("--event-every", type=int, default=5, help="bracket the stages with HIP events on every n-th timed step only (1 = every step)")
     ap.add_argument("--root-fold", action="store_true", help="N > 1: plain reduce to rank 0, which lifts and folds alone")
@@ -624,12 +623,33 @@ def bench_base(args, ctx, workload, steps, warmup, primary):
                     pipelined["batched_sweep"][str(B)] = {"queries": n_b * B, "queries_per_s": round(n_b * B / dt_b, 1), "ms_per_query_amortised": round(dt_b * 1e3 / (n_b * B), 4)}
                 pipelined["batched_sweep"]["note"] = ("B queries per pass over the database (sweep_kernel<0, B>: the 112-byte groups a lane fetches are multiplied into B "
                                                       "accumulator sets); throughput only, every answer bit-identical to the single-query path")
+            if args.batched_sweep:
+                # whole queries batched: every launch of the answer carries the B queries of a batch (spiral_gpu_server_run_query_batch: the
+                # expansion / conversion / lift / fold launches take a query dimension, the sweep is the batched one), one hipGraph replay per batch
+                bq = {}
+                for name, groups in (("2", [[0, 1]]), ("4", [[0, 1, 2, 3]]), ("2x2", [[0, 1], [2, 3]])):
+                    groups = [[lanes[i][0] for i in g] for g in groups]
+                    for _ in range(2):  # graph capture, untimed
+                        for g in groups: sa.run_query_batch(g)
+                    torch.cuda.synchronize()
+                    per = sum(len(g) for g in groups)
+                    n_b = max(n_q // per, 3)
+                    t1 = time.perf_counter()
+                    for _ in range(n_b):
+                        for g in groups: sa.run_query_batch(g)
+                    torch.cuda.synchronize()
+                    dt_b = time.perf_counter() - t1
+                    bq[name] = {"queries": n_b * per, "queries_per_s": round(n_b * per / dt_b, 1), "ms_per_query_amortised": round(dt_b * 1e3 / (n_b * per), 4),
+                                "ms_per_batch": round(dt_b * 1e3 / n_b / len(groups), 4)}
+                bq["note"] = ("B whole queries (different lanes: own keys, own query) per launch sequence, every launch carrying all B (gridDim.z = B) and the sweep one pass "
+                              "over the database for all of them; '2x2' = two such batches of 2 in flight on two streams; throughput only -- a query's latency is ms_per_batch")
+                pipelined["batched_query"] = bq
             for lane, _ in lanes[1:]:
                 lane.close()
         # untimed: the reference's stage buckets (src/spiral.cpp:246-257) from one eager pass with HIP events
         detail = None
         if primary and world == 1:
-            srv.set_overlap(False)
+            srv.set_overlap(0)
             srv.use_graphs(False)
             detail = srv.answer_resident()
             detail = srv.answer_resident()
@@ -666,7 +686,7 @@ def bench_base(args, ctx, workload, steps, warmup, primary):
         "dtype": "u32 residues, 32x32->64-bit integer MAC (two 28-bit CRT primes)",
         "data": "synthetic",
         "config": {"workload": label + ", explicit DB generated on device, sharded by first-dimension index",
-                   "db_bytes_ntt_form": int(shp.dim0) * int(shp.num_per) * 4 * sa.N * 8, "schedule": "GSW conversion overlapped with the sweep (side stream)" if args.overlap else "in order, one stream",
+                   "db_bytes_ntt_form": int(shp.dim0) * int(shp.num_per) * 4 * sa.N * 8, "schedule": "split: the GSW side of the query on a side stream" if args.overlap else "in order, one stream",
                    "parallelism": (f"j-shard x{world}, reduce-scatter + distributed fold + all-gather" if sharded_fold else f"j-shard x{world} + 1 reduce")
                                   + (", sharded expansion + all-gather of the GSW bits" if shard_expand else "")
                                   + (" (overlapped with ScalToMat + sweep)" if best == "comm-overlap" else "")

@@ -208,6 +208,16 @@ int spiral_gpu_server_lift(spiral_gpu_server *s, int reduce_first); /* nttInvAnd
  * The lanes are ordered with hipEventRecord / hipStreamWaitEvent on their streams: call it OUTSIDE stream capture (none of the
  * lanes' streams may be capturing a hipGraph; run_pre / run_post capture and replay their own groups either side of it). */
 int spiral_gpu_server_first_dim_batch(spiral_gpu_server *const *servers, uint32_t n);
+/* The same idea for the WHOLE answer: n <= 4 queries -- one per server, an owner and its lanes (create_lane), equal parameters, each with its
+ * own client's public parameters and query -- as one launch sequence in which every launch carries all n queries: the expansion, conversion,
+ * lift, folding and switch kernels take a query dimension (the reference runs them once per query, src/spiral.cpp:1664-1743, 1850-2025,
+ * 1349-1410, inside process_crtd_query :2337-2406) and the sweep is first_dim_batch's.  A query's ~50 dependent launches outside the sweep are
+ * launch-bound (~5 us each whatever they carry), so n queries cost little more than one there.  Throughput only: each query's latency is the
+ * batch's.  Afterwards every server's buffers (accumulators, GSW matrices, final ciphertext, response) hold exactly what its own run_query
+ * would have left.  Runs on servers[0]'s stream -- one hipGraph replay per batch when servers[0] has use_graphs on -- with the other lanes'
+ * streams ordered around it by events (call it outside stream capture).  Needs the default schedule on every server: own accumulators, no
+ * keep_cts, no split / sharded / staged options; every server is checked before anything is launched.  n = 1 is run_query. */
+int spiral_gpu_server_run_query_batch(spiral_gpu_server *const *servers, uint32_t n);
 int spiral_gpu_server_fold(spiral_gpu_server *s);      /* foldOneFurtherDimension x nu2               */
 int spiral_gpu_server_finish(spiral_gpu_server *s);    /* response modulus switch, :1441-1447         */
 int spiral_gpu_server_sync(spiral_gpu_server *s);
@@ -216,17 +226,15 @@ int spiral_gpu_server_sync(spiral_gpu_server *s);
  * server stream (which must not be the default stream) and replayed afterwards. */
 int spiral_gpu_server_use_graphs(spiral_gpu_server *s, int on);
 int spiral_gpu_server_run_pre(spiral_gpu_server *s);
-/* overlap mode: run_pre runs expansion + scalToMat on the server stream and forks the regevToGSW conversion (whose
- * keys only the folding reads) onto an internal side stream, so that it executes under the HBM-bound first-dimension
- * sweep; fold / fold_local / fold_root / run_post / sync join it.  Results are identical, only the schedule changes. */
+/* Schedule option, on = 0 (default: one stream) or 2 (the split schedule; any other value is an error).  After round 0 the even-index and
+ * the odd-index trees of expandImproved never read each other (a ciphertext is created from the one 2^r slots below it,
+ * src/spiral.cpp:1709), and with stopround > 0 the evens are the first-dimension ciphertexts and the odds the GSW bits -- so the whole GSW
+ * side of a query (odd tree + regevToGSW + fold keys) runs as its own launch sequence on an internal side stream, forked when the query is
+ * set, beside the even tree + scalToMat + sweep on the server stream; fold / fold_local / fold_root / run_post / sync join it.  run_query
+ * then issues three launch groups on two streams instead of one graph.  Needs query compression with stopround > 0 and an unsharded
+ * expansion.  Results are identical, only the schedule changes; measured within noise of the in-order schedule
+ * (profiles/r04_split_overlap.txt; the forms that forked only the conversion, under the sweep, were slower and are gone). */
 int spiral_gpu_server_set_overlap(spiral_gpu_server *s, int on);
-/* on = 2, the split schedule: after round 0 the even-index and the odd-index trees of expandImproved never read each other (a ciphertext is
- * created from the one 2^r slots below it, src/spiral.cpp:1709), and with stopround > 0 the evens are the first-dimension ciphertexts and the
- * odds the GSW bits -- so the whole GSW side of a query (odd tree + regevToGSW + fold keys) runs as its own launch sequence on the side
- * stream, forked when the query is set, beside the even tree + scalToMat + sweep on the server stream; the folding joins it.  run_query then
- * issues three launch groups on two streams instead of one graph.  Needs query compression with stopround > 0 and an unsharded expansion.
- * on = 3: the same side sequence forked after the even tree + scalToMat, i.e. under the sweep.  Measured (profiles/r04_split_overlap.txt): 2 is
- * within noise of the in-order schedule, 3 is 15 % slower; both are off by default. */
 int spiral_gpu_server_run_post(spiral_gpu_server *s, int reduce_first);
 /* the whole single-GPU answer (run_pre, first_dim, run_post(0)) as one group: with use_graphs on, one hipGraph launch
  * per query and no host-visible seam between the stages */

@@ -91,6 +91,7 @@ PROTOTYPES = {
     "spiral_gpu_server_share_db": (C.c_int, [C.c_void_p, C.c_void_p]),
     "spiral_gpu_server_create_lane": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "spiral_gpu_server_first_dim_batch": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32]),
+    "spiral_gpu_server_run_query_batch": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32]),
     "spiral_gpu_response_wire_bytes": (C.c_size_t, [C.POINTER(Params), C.c_uint32]),
     "spiral_gpu_response_from_wire": (C.c_int, [C.POINTER(Params), C.c_uint32, C.c_void_p, U64P]),
     "spiral_gpu_server_read_response_wire": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

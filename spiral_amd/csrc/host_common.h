@@ -95,14 +95,29 @@ inline uint32_t inv_mod_2n(uint32_t t) {  // t odd, inverse modulo 2N = 4096
 struct DevBuf {
     uint64_t* p = nullptr;
     size_t words = 0;
+    bool carved = false;  // a piece of an Arena: not freed on its own
     int alloc(size_t w) {
         words = w ? w : 1;
+        carved = false;
         HIP_OK(hipMalloc(&p, words * sizeof(uint64_t)));
         return 0;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && !carved) (void)hipFree(p);
         p = nullptr;
+    }
+};
+// One allocation holding all per-query buffers of a server in a fixed order, so that two servers with the same parameters have the
+// same internal layout and lane q's buffer X is lane 0's X + (arena_q - arena_0): what lets one launch serve several query lanes
+// (kernels.h Lanes).  Two passes over the same carve sequence: base == nullptr sizes it, then the real base hands out the pieces.
+struct Arena {
+    uint64_t* base = nullptr;
+    size_t used = 0;
+    void carve(DevBuf& b, size_t w) {
+        b.words = w ? w : 1;
+        b.carved = true;
+        b.p = base ? base + used : nullptr;
+        used += (b.words + 31u) & ~(size_t)31u;  // 256-byte pieces
     }
 };
 
@@ -158,10 +173,11 @@ inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_
                 const uint64_t* query = nullptr,  // query: the packed query ciphertext when cv[0] does not hold it yet
                 uint32_t r_begin = 0, uint32_t r_end = 0xffffffffu,  // rounds [r_begin, min(r_end, g))
                 const ExpandShard& shard = ExpandShard{},
-                uint32_t parity = 3) {  // bit 0: the even-index ciphertexts, bit 1: the odd-index ones.  After round 0 the two trees never read each
-                                        // other (a ciphertext is created from the one num_in = 2^r slots below it: same parity for r >= 1, and in
-                                        // round 0 both come from the query), so with stopround > 0 -- evens = first-dimension ciphertexts, odds = GSW
-                                        // bits -- the two halves can run as independent launch sequences on their own work buffers
+                uint32_t parity = 3,  // bit 0: the even-index ciphertexts, bit 1: the odd-index ones.  After round 0 the two trees never read each
+                                      // other (a ciphertext is created from the one num_in = 2^r slots below it: same parity for r >= 1, and in
+                                      // round 0 both come from the query), so with stopround > 0 -- evens = first-dimension ciphertexts, odds = GSW
+                                      // bits -- the two halves can run as independent launch sequences on their own work buffers
+                const Lanes& lanes = Lanes{}) {  // query lanes: cv, w_left, w_right, wk, query are lane 0's (kernels.h)
     // active odd-index ciphertexts of round r (:1701-1702); the even ones are all 2^r
     auto odd_count = [&](uint32_t r) {
         const uint32_t num_in = 1u << r;
@@ -203,6 +219,7 @@ inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_
         ip.auto_t = t;
         ip.create_here = r == 0;
         ip.query = query;
+        ip.lanes = lanes;
         launch_ntt_inverse_expand(tb, ip, 2 * cnt, st);
         // 2) G^-1(automorph(c)[0]) digits (t_exp / t_exp_right per ct), one launch
         FwdParams fp{};
@@ -213,6 +230,7 @@ inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_
         fp.cnt_e = cnt_even;
         fp.t_e = t_exp;
         fp.t_o = t_exp_right;
+        fp.lanes = lanes;
         launch_ntt_forward(tb, fp, LD_EXPAND, ST_PK, cnt_even * t_exp + cnt_odd * t_exp_right, st);
         // 3) cv[i] += W * digits + (0, NTT(c'_1))
         ExpandMacParams mp{};
@@ -232,6 +250,7 @@ inline void run_expand(const DeviceTables& tb, uint64_t* cv, uint32_t g, uint32_
             mp.next_num_in = 2 * num_in;
             mp.next_cnt_o = odd_count(r + 1);
         }
+        mp.lanes = lanes;
         launch_expand_mac_round(mp, st);
     }
 }

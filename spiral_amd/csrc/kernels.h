@@ -13,6 +13,26 @@ struct IndexMap {
 };
 inline IndexMap identity_map() { return IndexMap{1u, 1u, 0u}; }
 
+// Query lanes of one launch (server.cpp run_query_batch).  The launch-bound stages of a query -- expansion, conversion, lift, folding: ~50
+// dependent launches that cost ~5 us each whatever they carry -- take a QUERY dimension: gridDim.z = n <= kMaxLanes queries, each with its own
+// keys, ciphertexts and scratch.  Every per-query buffer of a server lives in one arena with the same internal layout (srv_alloc), so lane q's
+// buffer is lane 0's pointer + off[q] words: a kernel shifts every non-table pointer of its parameters by off[blockIdx.z] and is otherwise
+// unchanged (n = 1, off = 0: the single-query launch).  The reference answers one query per process_crtd_query (src/spiral.cpp:2337-2406).
+constexpr uint32_t kMaxLanes = 4;
+struct Lanes {
+    uint32_t n = 1;
+    int64_t off[kMaxLanes] = {0, 0, 0, 0};  // u64 words from lane 0's arena to lane q's
+#ifdef __HIPCC__
+    __device__ __forceinline__ int64_t here() const { return off[blockIdx.z]; }
+#endif
+};
+#ifdef __HIPCC__
+template <class T>
+__device__ __forceinline__ void lane_shift(T*& p, int64_t words) {  // optional (null) pointers stay null
+    if (p) p = reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + (intptr_t)words * 8);
+}
+#endif
+
 struct DeviceTables {
     uint4* fwd = nullptr;      // [2048] forward twiddles {W_p, W'_p, W_b, W'_b}
     uint4* inv = nullptr;      // [2048] inverse twiddles psi^-i (row 1 times N^-1, row 0 = N^-1: the stages are unscaled, tables.cpp)
@@ -44,7 +64,7 @@ enum FwdLoad : uint32_t {
     LD_DBGEN1 = 7,  // SpiralPack database: 1 x 1 plaintext of (trial, item), centred lift (src/testing.cpp:845-869)
     LD_SDIFF = 8,   // fold round in pair form from lifted ciphertexts: difference of the balanced digits k of raw[np + i] and raw[i]
     LD_PDIFF = 9,   // SpiralPack fold round in pair form from lifted ciphertexts [trial][2 np][2]: difference of the unsigned digits k of
-                    // ct np + i and ct i, destination D'[trial][i][row + 2k]  (foldCiphertextsDim1 through the identity of fold_pair_kernel)
+                    // ct np + i and ct i, destination D'[trial][i][row + 2k]  (foldCiphertextsDim1 through the same identity as LD_SDIFF)
     LD_EXPAND = 5,  // one expansion round: digits of automorph(c)[0] and the reduced automorph(c)[1] of every
                     // active ciphertext, both parities, in one launch      (src/spiral.cpp:1711-1720)
 };
@@ -90,6 +110,7 @@ struct FwdParams {
     uint64_t seed, p_db;
     uint64_t item_base;                 // first item handled by this launch
     uint32_t num_per, dim0_shard, j0;   // DB geometry of this shard
+    Lanes lanes;                        // src, dst per query lane
 };
 void launch_ntt_forward(const DeviceTables& t, const FwdParams& p, uint32_t load, uint32_t store, uint32_t nblocks, hipStream_t s);
 
@@ -129,6 +150,7 @@ struct InvParams {
     uint32_t auto_t;  // the round's automorphism x -> x^t
     uint32_t create_here;  // 1: cts with i >= num_in do not exist yet (round 0); 0: the previous round's MAC wrote them
     const uint64_t* query;  // create_here only, optional: cv[0] is read from here (and written to cv) instead of from cv
+    Lanes lanes;            // src, dst, cv, query per query lane (neg1 / neg1s are shared tables)
 };
 void launch_ntt_inverse(const DeviceTables& t, const InvParams& p, uint32_t store, uint32_t nblocks, hipStream_t s);
 void launch_ntt_inverse_expand(const DeviceTables& t, const InvParams& p, uint32_t nblocks, hipStream_t s);
@@ -145,26 +167,14 @@ struct FoldChainParams {
     // SpiralPack fold (foldCiphertextsDim1): sources are [trial][2*np][2] 2 x 1 ciphertexts with a trial stride of src_stride
     // ciphertexts, unsigned digits, operand layout as LD_PDIGIT / PM_FOLD
     uint32_t pack, src_stride;
+    Lanes lanes;
 };
 void launch_fold_chain(const DeviceTables& t, const FoldChainParams& p, uint32_t n_src, hipStream_t s);
 
-// fold round on pairs (ntt.hip fold_pair_kernel): PK polynomials [2*np][3][2] -> for every pair (i, np + i) and polynomial
-// (r, c) the digit DIFFERENCES G^-1(C[np + i]) - G^-1(C[i]), transformed, in the layout D'[i][r + 3k][c] ([np][m2][2]); the
-// round's product is then out[i] = C[i] + Q * D'[i] (launch_fold_mac with an addend).  Exact only when the balanced digits
-// recompose their value (fold_pair_exact).
-struct FoldPairParams {
-    const uint64_t* src;
-    uint64_t* dst;
-    uint32_t ell, bits, fold_np;
-    uint32_t pre_reduce;  // 1: fields are lazy sums (< 2^32), reduce mod m first
-    uint32_t dpb;         // digits per block, 1 .. ell (every block repeats the two inverse transforms)
-    uint32_t lazy_out;    // 1: digit transforms left in [0, 2m)
-    uint32_t team;        // 1: fold_team_kernel -- 512-thread workgroups, one half per ciphertext of the pair, 2 dpb digits per block
-};
+// The fold round in pair form (ntt.hip LD_SDIFF + launch_fold_mac with an addend): out[i] = C[i] + Q * NTT(G^-1(C[np + i]) - G^-1(C[i])).
 // split_and_crt's digits recompose the value exactly -- no borrow is lost at the top of the second carry chain -- when the
 // digits cover at least 57 bits (values are below Q < 2^56) and every shift is a defined one
 constexpr bool fold_pair_exact(uint32_t ell) { return ell >= 2 && ell * get_bits_per(ell) >= 57 && (ell - 1) * get_bits_per(ell) < 64; }
-void launch_fold_pair(const DeviceTables& t, const FoldPairParams& p, uint32_t n_pairs, hipStream_t s);
 
 // ---- layout conversion at the C-ABI boundary -------------------------------------------------------
 // reference polynomial b <-> packed polynomial pk_map(b)
@@ -185,7 +195,7 @@ void launch_matmul(const MatmulParams& p, uint32_t batch, hipStream_t s);
 // key_stride: polynomials between the key's rows (K when the rows are K long; 2*m2 with K = m2 to take one half of [Q_neg | Q]);
 // addend: optional [np][3][2] PK polynomials added to the products (fields may be any u32: lazy sums are fine)
 void launch_fold_mac(const uint64_t* key, const uint64_t* d, uint64_t* out, uint32_t K, uint32_t np, hipStream_t s, uint32_t key_stride = 0,
-                     const uint64_t* addend = nullptr);
+                     const uint64_t* addend = nullptr, const Lanes& lanes = Lanes{});
 // out = (a + b) mod m ; out = single * a (src/poly.cpp:138,190)
 void launch_add(const uint64_t* a, const uint64_t* b, uint64_t* out, uint32_t npolys, hipStream_t s);
 void launch_mul_by_const(const uint64_t* single, const uint64_t* a, uint64_t* out, uint32_t npolys, hipStream_t s);
@@ -197,7 +207,8 @@ void launch_gadget_invert(const uint64_t* in, uint64_t* out, uint32_t mx, uint32
 // response modulus switch (src/poly.cpp:578-601, src/spiral.cpp:1441-1447)
 void launch_rescale(const uint64_t* in, uint64_t* out, uint32_t n, uint64_t inp_mod, uint64_t out_mod, hipStream_t s);
 void launch_response_wire(const uint64_t* in, uint64_t* out, uint32_t n0, uint32_t w0, uint32_t n1, uint32_t w1, hipStream_t s);
-void launch_rescale2(const uint64_t* in, uint64_t* out, uint32_t n0, uint32_t n, uint64_t inp_mod, uint64_t out_mod0, uint64_t out_mod1, hipStream_t s);
+void launch_rescale2(const uint64_t* in, uint64_t* out, uint32_t n0, uint32_t n, uint64_t inp_mod, uint64_t out_mod0, uint64_t out_mod1, hipStream_t s,
+                     const Lanes& lanes = Lanes{});
 
 // ---- expansion / conversion / fold specials ----------------------------------------------------------
 // the same for a whole round in one launch: active ct a < cnt_e even (W_left, t_e digits) else odd (W_right, t_o);
@@ -216,6 +227,7 @@ struct ExpandMacParams {
     const uint64_t* neg1n;
     const uint64_t* neg1ns;  // Shoup companions
     uint32_t next_num_in, next_cnt_o;
+    Lanes lanes;  // cv, w_e, w_o, g, a1 per query lane (neg1n / neg1ns are shared tables)
 };
 void launch_expand_mac_round(const ExpandMacParams& p, hipStream_t s);
 // scalToMat product: out[a][r][c] = sum_k W[r][2k+c] * G[a][k] + pad(cv[pos(a)][1])   (src/spiral.cpp:1850-1885)
@@ -228,6 +240,7 @@ struct Scal2MatParams {
     uint64_t* out;        // [count][3][2] PK or null
     uint32_t* qs;         // sweep query records [N][jm_total/2][12] u32 or null
     uint32_t t_conv, count, jm_total, j_base;
+    Lanes lanes;  // every pointer per query lane
 };
 void launch_scal2mat(const Scal2MatParams& p, hipStream_t s);
 // regevToGSW assembly for one dimension: gsw[r][3i] = sum_k V[r][k] * chat[i][k], gsw[r][3i+1+c] = scalToMat(cv_i)[r][c]
@@ -240,6 +253,7 @@ struct GswParams {
     uint64_t* gsw;         // [dims][3][3*ell] PK, dimension d stored at index (dims-1-d)  (src/spiral.cpp:2324)
     uint64_t* key;         // optional: the fold key of the same matrices, written in the same pass: key[d][r][0..m2) = G2 - gsw (= Q_neg, src/spiral.cpp:2361-2379), key[d][r][m2..2*m2) = gsw
     uint32_t t_conv, ell, dims;
+    Lanes lanes;  // every pointer per query lane
 };
 void launch_regev_to_gsw(const GswParams& p, hipStream_t s);
 // both conversion products in one launch when the record-writing ScalToMat applies (else the two launches)
@@ -259,7 +273,7 @@ void launch_sweep(const uint64_t* db, const uint32_t* qs, uint64_t* acc, uint32_
 bool sweep_stages_ok(uint32_t num_per, uint32_t jm_total, uint32_t g_log, uint32_t k_log);
 // n = 2 .. kSweepMaxBatch queries against one pass over the database (records qs[b] -> accumulators acc[b]); only where
 // sweep_batch_ok (the packed layout with at least 64 output columns: every published geometry but the smallest streaming ones)
-constexpr uint32_t kSweepMaxBatch = 4;
+constexpr uint32_t kSweepMaxBatch = kMaxLanes;
 bool sweep_batch_ok(uint32_t num_per, uint32_t jm_total);
 void launch_sweep_batch(const uint64_t* db, const uint32_t* const* qs, uint64_t* const* acc, uint32_t n, uint32_t num_per, uint32_t jm_total, uint32_t g_log,
                         hipStream_t s);

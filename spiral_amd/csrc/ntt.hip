@@ -1,5 +1,7 @@
 // Batched NTT / INTT kernels with fused pre- and post-operations, gfx950.
 // One 256-thread workgroup per output polynomial.  See ntt_device.h for the transform itself.
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -219,6 +221,11 @@ __global__ __launch_bounds__(256, 8) void ntt_forward_kernel(Tables t, FwdParams
     __shared__ uint64_t sh[kLdsWords];
     const uint32_t tid = threadIdx.x;
     uint32_t b = blockIdx.x;
+    if constexpr (STORE == ST_PK) {  // query lane blockIdx.z (kernels.h Lanes); the database loaders never take lanes
+        const int64_t lane = p.lanes.here();
+        lane_shift(p.src, lane);
+        lane_shift(p.dst, lane);
+    }
     // the ell digit jobs of a polynomial pair read the same 32 KiB of lifted coefficients: consecutive JOBS (not block ids, which are dealt
     // round-robin to the 8 XCDs) go to one XCD, so that its L2 serves the re-reads (-3.5 us on the fold of config 2; the one-source digit
     // launches measured +-0 with the same map in round 2 and +5 us on expand + convert now: they keep the plain order)
@@ -333,8 +340,12 @@ __global__ __launch_bounds__(256, 8) void ntt_forward_kernel(Tables t, FwdParams
         }
         s = b;
     } else if constexpr (LOAD == LD_SDIFF) {
-        // pair form of a fold round from lifted ciphertexts (see fold_pair_kernel): source s = (pair i, r, c) over [np][3][2],
-        // L = raw[i][r][c], H = raw[np + i][r][c]; the digit difference G^-1(H)_k - G^-1(L)_k as residues
+        // Pair form of a fold round (src/spiral.cpp:1349-1383 through an identity).  The reference folds L = C[i] and H = C[np + i] into
+        // Q_neg G^-1(L) + Q G^-1(H) with Q_neg = G2 - Q slot by slot (:2361-2379); in exact arithmetic mod p and mod b that is
+        // G2 G^-1(L) + Q (G^-1(H) - G^-1(L)), and G2 G^-1(L) recomposes L whenever split_and_crt's balanced digits (:270-330) sum back to
+        // the value (kernels.h fold_pair_exact).  Hence out[i] = L + Q NTT(G^-1(H) - G^-1(L)): half the forward transforms, half the operand.
+        // Source s = (pair i, r, c) over [np][3][2] of the lifted ciphertexts, L = raw[i][r][c], H = raw[np + i][r][c]; the digit
+        // difference G^-1(H)_k - G^-1(L)_k (an integer in (-1.5 B, 1.5 B)) as residues
         const uint32_t i = s / 6u, rc = s - i * 6u;
         const uint64_t* sl = p.src + ((size_t)i * 6u + rc) * kN;
         const uint64_t* sh_ = p.src + ((size_t)(p.fold_np + i) * 6u + rc) * kN;
@@ -489,6 +500,11 @@ template <uint32_t LOAD>
 __global__ __launch_bounds__(256) void ntt_forward2_kernel(Tables t, FwdParams p) {
     __shared__ uint64_t sh[2][kLdsWords];
     const uint32_t tid = threadIdx.x, b2 = blockIdx.x;
+    {
+        const int64_t lane = p.lanes.here();
+        lane_shift(p.src, lane);
+        lane_shift(p.dst, lane);
+    }
     uint32_t tdim, kk, ob;  // digits per source, pair index, job id of digit 0 of this source in ntt_forward_kernel's numbering
     const uint64_t* src;
     uint32_t bits;
@@ -556,6 +572,15 @@ template <uint32_t STORE, bool EXPAND = false>
 __global__ __launch_bounds__(256, 8) void ntt_inverse_kernel(Tables t, InvParams p) {
     __shared__ uint64_t sh[kLdsWords];
     const uint32_t tid = threadIdx.x, b = blockIdx.x;
+    {
+        const int64_t lane = p.lanes.here();
+        lane_shift(p.src, lane);
+        lane_shift(p.dst, lane);
+        if constexpr (EXPAND) {
+            lane_shift(p.cv, lane);
+            lane_shift(p.query, lane);
+        }
+    }
     uint32_t lo[8], hi[8];
     if constexpr (EXPAND) {
         const uint32_t a = b >> 1, row = b & 1u;
@@ -672,10 +697,15 @@ __global__ __launch_bounds__(256, 8) void ntt_inverse_kernel(Tables t, InvParams
 // picks dpb per round so that a round is about as many blocks as the chip holds.
 // (register budget: 103 VGPRs = 4 workgroups per CU.  Forcing 5 or 6 through the launch bound spills 24 / 84 bytes per thread and
 // measured 0 / +30 us on the fold, profiles/r03_variants.txt; holding one twiddle row set instead of two does not lower the count.
-// Since round 4 this two-product form is the fallback of the pair form below: SPIRAL_FOLD_PAIR=0, gadget dimensions whose digits do not recompose.)
+// Since round 4 this two-product form is the fallback of the pair form (LD_SDIFF): SPIRAL_FOLD_PAIR=0, gadget dimensions whose digits do not recompose.)
 __global__ __launch_bounds__(256) void fold_chain_kernel(Tables t, FoldChainParams p) {
     __shared__ uint64_t sh[kLdsWords];
     const uint32_t tid = threadIdx.x, b = blockIdx.x;
+    {
+        const int64_t lane = p.lanes.here();
+        lane_shift(p.src, lane);
+        lane_shift(p.dst, lane);
+    }
     const uint32_t cpp = (p.ell + p.dpb - 1u) / p.dpb;  // chunks per polynomial
     const uint32_t s = b / cpp, k0 = (b - s * cpp) * p.dpb, k1 = min(k0 + p.dpb, p.ell);
     uint32_t lo[8], hi[8];
@@ -720,81 +750,6 @@ __global__ __launch_bounds__(256) void fold_chain_kernel(Tables t, FoldChainPara
     }
 }
 
-// Fold round on PAIRS (src/spiral.cpp:1349-1383 computed through an identity).  The reference folds ciphertexts L = C[i] and
-// H = C[np + i] into  Q_neg G^-1(L) + Q G^-1(H)  with Q_neg = NTT(G2 - INTT(Q)), i.e. Q_neg = G2 - Q slot by slot (:2361-2379).
-// Everything is exact arithmetic mod p and mod b, so that is  G2 G^-1(L) + Q (G^-1(H) - G^-1(L)),  and G2 G^-1(L) recomposes L:
-// split_and_crt's balanced digits d_k (:270-330) satisfy sum_k 2^(bits k) d_k = value over the integers whenever the last digit
-// of the second carry chain never borrows, which holds for ell * bits >= 57 (the value is below Q < 2^56, so its top piece is at
-// most 2^(bits - 1); the host checks the condition and otherwise keeps the two-product form).  Hence
-//     out[i] = L + Q * NTT(G^-1(H) - G^-1(L))      -- L's own transform-domain words, which the round already has --
-// with the same canonical residues as the reference: HALF the forward transforms (ell per polynomial pair instead of 2 ell),
-// half the digit operand, a product of K = m2 terms against the Q half of the key instead of 2 m2.
-// A block takes polynomial (r, c) of pair i: both inverse transforms side by side on one twiddle fetch (ntt_inverse_block2),
-// both CRT lifts in registers, then for its dpb digits k the per-coefficient digit difference (an integer in (-1.5 B, 1.5 B),
-// stored as its residues) and one forward transform.  Operand layout D'[i][r + 3 k][c] ([np][m2][2]).
-__global__ __launch_bounds__(256) void fold_pair_kernel(Tables t, FoldPairParams p) {
-    __shared__ uint64_t sh[2][kLdsWords];
-    const uint32_t tid = threadIdx.x, b = blockIdx.x;
-    const uint32_t cpp = (p.ell + p.dpb - 1u) / p.dpb;
-    const uint32_t s = b / cpp, k0 = (b - s * cpp) * p.dpb, k1 = min(k0 + p.dpb, p.ell);
-    const uint32_t i = s / 6u, rc = s - i * 6u, row = rc >> 1, c = rc & 1u;
-    uint32_t lo[8], hi[8];
-    uint64_t vl[8], vh[8];
-    {
-        uint32_t lo1[8], hi1[8];
-        pk_load8_red(p.src + ((size_t)i * 6u + rc) * kN, p.pre_reduce != 0, tid, lo, hi);
-        pk_load8_red(p.src + ((size_t)(p.fold_np + i) * 6u + rc) * kN, p.pre_reduce != 0, tid, lo1, hi1);
-        ntt_inverse_block2<false>(lo, hi, lo1, hi1, sh[0], sh[1], t.inv, tid);
-        crt_lift8(lo, hi, vl);
-        crt_lift8(lo1, hi1, vh);
-    }
-    const uint32_t m2 = 3u * p.ell;
-    for (uint32_t k = k0; k < k1; k++) {
-        sdigit_diff8([&](int r) { return vh[r]; }, [&](int r) { return vl[r]; }, k, p.bits, p.ell, lo, hi);
-        if (k > k0) __syncthreads();  // the previous transform's last LDS reads
-        ntt_forward_block<false>(lo, hi, sh[0], t.fwd, tid);
-        if (!p.lazy_out) canonicalize8(lo, hi);
-        uint64_t x[8];
-        pk_pack8(lo, hi, x);
-        pk_store8(p.dst + ((size_t)(i * m2 + row + 3u * k) * 2u + c) * kN, tid, x);
-    }
-}
-
-// The same round with TWO 256-thread halves per workgroup (512 threads): half 0 inverse-transforms and lifts L, half 1 H, at
-// the same time and each in its own LDS tile; the lifted polynomials cross through the tiles (16 KiB each way), after which
-// each half transforms its own dpb of the block's 2 dpb digit differences.  No inverse transform is repeated when a pair's
-// digits all sit in one block (wide rounds: 1 + ell/2 transforms deep instead of 2 + ell), and the latency-bound rounds are
-// one inverse + one forward transform deep (dpb = 1) instead of two + one.  Every thread passes the same barriers: the digit
-// loop runs dpb times in both halves, a digit index beyond ell is computed on a clamped index and not stored.
-__global__ __launch_bounds__(512, 4) void fold_team_kernel(Tables t, FoldPairParams p) {
-    __shared__ uint64_t sh[2][kLdsWords];
-    __shared__ uint64_t vb[2][kN];  // the lifted polynomials L, H: read back per digit instead of held in 32 VGPRs
-    const uint32_t half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), tid = threadIdx.x & 255u, b = blockIdx.x;
-    uint64_t* mine = sh[half];
-    const uint32_t per_block = 2u * p.dpb, cpp = (p.ell + per_block - 1u) / per_block;
-    const uint32_t s = b / cpp, k0 = (b - s * cpp) * per_block + half * p.dpb;
-    const uint32_t i = s / 6u, rc = s - i * 6u, row = rc >> 1, c = rc & 1u;
-    uint32_t lo[8], hi[8];
-    pk_load8_red(p.src + ((size_t)(half * p.fold_np + i) * 6u + rc) * kN, p.pre_reduce != 0, tid, lo, hi);
-    ntt_inverse_block<false>(lo, hi, mine, t.inv, tid);
-#pragma unroll
-    for (int r = 0; r < 8; r++) vb[half][ix_a(tid, r)] = crt_compose_lazy(csub_min(lo[r], kP), hi[r]);
-    __syncthreads();  // both lifted polynomials are in vb; the inverse transforms' last tile reads are done
-    const uint32_t m2 = 3u * p.ell;
-    for (uint32_t it = 0; it < p.dpb; it++) {
-        const uint32_t kq = k0 + it, k = min(kq, p.ell - 1u);
-        sdigit_diff8([&](int r) { return vb[1][ix_a(tid, r)]; }, [&](int r) { return vb[0][ix_a(tid, r)]; }, k, p.bits, p.ell, lo, hi);  // H - L
-        if (it > 0) __syncthreads();  // the previous transform's last LDS reads
-        ntt_forward_block<false>(lo, hi, mine, t.fwd, tid);
-        if (!p.lazy_out) canonicalize8(lo, hi);
-        if (kq < p.ell) {
-            uint64_t x[8];
-            pk_pack8(lo, hi, x);
-            pk_store8(p.dst + ((size_t)(i * m2 + row + 3u * k) * 2u + c) * kN, tid, x);
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void ref_to_pk_kernel(const uint64_t* ref, uint64_t* pk, IndexMap pk_map) {
     const size_t poly = blockIdx.y;
     const uint32_t z = blockIdx.x * 256u + threadIdx.x;
@@ -811,7 +766,7 @@ __global__ __launch_bounds__(256) void pk_to_ref_kernel(const uint64_t* pk, uint
 
 #define FWD_CASE(L, S)                                                                                  \
     if (load == L && store == S) {                                                                      \
-        hipLaunchKernelGGL((ntt_forward_kernel<L, S>), dim3(nblocks), dim3(256), 0, s, tb, p);          \
+        hipLaunchKernelGGL((ntt_forward_kernel<L, S>), dim3(nblocks, 1, p.lanes.n), dim3(256), 0, s, tb, p);          \
         return;                                                                                         \
     }
 
@@ -824,19 +779,24 @@ void launch_ntt_forward(const DeviceTables& t, const FwdParams& p_in, uint32_t l
     p.inv_to = inv(p.t_o);
     Tables tb{t.fwd, t.inv};
     // Two digits per workgroup on one twiddle fetch (ntt_forward2_kernel) pay in steady state only -- 14-24 % from 16 k transforms up, nothing
-    // at one or two generations of resident workgroups (profiles/r04_twiddle_sharing.txt): used from kFwd2Min transforms per launch.
-    // SPIRAL_FWD2=0 / 1 forces it off / on (tests, A/B).
+    // at one or two generations of resident workgroups (profiles/r04_twiddle_sharing.txt): used from kFwd2Min transforms per launch (all
+    // query lanes together).  SPIRAL_FWD2=0 / 1 forces it off / on (read per call: tests, A/B).  Same results either way.
     constexpr uint32_t kFwd2Min = 8192;
-    static const int fwd2_env = getenv("SPIRAL_FWD2") ? atoi(getenv("SPIRAL_FWD2")) : -1;
-    const bool fwd2 = fwd2_env >= 0 ? fwd2_env != 0 : nblocks >= kFwd2Min;
+    const char* fwd2_env = getenv("SPIRAL_FWD2");
+    const bool fwd2 = (fwd2_env ? atoi(fwd2_env) != 0 : (uint64_t)nblocks * p.lanes.n >= kFwd2Min) && p.tinv == 0;  // (the two-digit loader has no automorphism gather)
+    // udiv_small is exact for job indices below 2^32 / d: far above any launch of the server, checked here because the seams take caller sizes
+    if ((uint64_t)nblocks * std::max({p.n_digits, p.t_e, p.t_o, 1u}) >= (1ull << 32)) {
+        fprintf(stderr, "launch_ntt_forward: %u jobs exceed the range of the job-index division\n", nblocks);
+        abort();
+    }
     if (fwd2 && store == ST_PK && load == LD_DIGIT && p.n_digits >= 2) {
         const uint32_t nsrc = nblocks / p.n_digits;
-        hipLaunchKernelGGL((ntt_forward2_kernel<LD_DIGIT>), dim3(nsrc * ((p.n_digits + 1u) / 2u)), dim3(256), 0, s, tb, p);
+        hipLaunchKernelGGL((ntt_forward2_kernel<LD_DIGIT>), dim3(nsrc * ((p.n_digits + 1u) / 2u), 1, p.lanes.n), dim3(256), 0, s, tb, p);
         return;
     }
     if (fwd2 && store == ST_PK && load == LD_EXPAND) {
         const uint32_t cnt_o = p.t_o ? (nblocks - p.cnt_e * p.t_e) / p.t_o : 0u;
-        hipLaunchKernelGGL((ntt_forward2_kernel<LD_EXPAND>), dim3(p.cnt_e * ((p.t_e + 1u) / 2u) + cnt_o * ((p.t_o + 1u) / 2u)), dim3(256), 0, s, tb, p);
+        hipLaunchKernelGGL((ntt_forward2_kernel<LD_EXPAND>), dim3(p.cnt_e * ((p.t_e + 1u) / 2u) + cnt_o * ((p.t_o + 1u) / 2u), 1, p.lanes.n), dim3(256), 0, s, tb, p);
         return;
     }
     FWD_CASE(LD_RAW, ST_PK)
@@ -857,14 +817,14 @@ void launch_ntt_forward(const DeviceTables& t, const FwdParams& p_in, uint32_t l
 void launch_ntt_inverse_expand(const DeviceTables& t, const InvParams& p, uint32_t nblocks, hipStream_t s) {
     if (nblocks == 0) return;
     Tables tb{t.fwd, t.inv};
-    hipLaunchKernelGGL((ntt_inverse_kernel<IST_CRT, true>), dim3(nblocks), dim3(256), 0, s, tb, p);
+    hipLaunchKernelGGL((ntt_inverse_kernel<IST_CRT, true>), dim3(nblocks, 1, p.lanes.n), dim3(256), 0, s, tb, p);
 }
 
 void launch_ntt_inverse(const DeviceTables& t, const InvParams& p, uint32_t store, uint32_t nblocks, hipStream_t s) {
     if (nblocks == 0) return;
     Tables tb{t.fwd, t.inv};
     if (store == IST_CRT)
-        hipLaunchKernelGGL((ntt_inverse_kernel<IST_CRT>), dim3(nblocks), dim3(256), 0, s, tb, p);
+        hipLaunchKernelGGL((ntt_inverse_kernel<IST_CRT>), dim3(nblocks, 1, p.lanes.n), dim3(256), 0, s, tb, p);
     else
         hipLaunchKernelGGL((ntt_inverse_kernel<IST_LIMBS>), dim3(nblocks), dim3(256), 0, s, tb, p);
 }
@@ -872,17 +832,7 @@ void launch_ntt_inverse(const DeviceTables& t, const InvParams& p, uint32_t stor
 void launch_fold_chain(const DeviceTables& t, const FoldChainParams& p, uint32_t n_src, hipStream_t s) {
     if (n_src == 0) return;
     Tables tb{t.fwd, t.inv};
-    hipLaunchKernelGGL(fold_chain_kernel, dim3(n_src * ((p.ell + p.dpb - 1u) / p.dpb)), dim3(256), 0, s, tb, p);
-}
-
-void launch_fold_pair(const DeviceTables& t, const FoldPairParams& p, uint32_t n_pairs, hipStream_t s) {
-    if (n_pairs == 0) return;
-    Tables tb{t.fwd, t.inv};
-    if (p.team) {
-        hipLaunchKernelGGL(fold_team_kernel, dim3(n_pairs * ((p.ell + 2u * p.dpb - 1u) / (2u * p.dpb))), dim3(512), 0, s, tb, p);
-        return;
-    }
-    hipLaunchKernelGGL(fold_pair_kernel, dim3(n_pairs * ((p.ell + p.dpb - 1u) / p.dpb)), dim3(256), 0, s, tb, p);
+    hipLaunchKernelGGL(fold_chain_kernel, dim3(n_src * ((p.ell + p.dpb - 1u) / p.dpb), 1, p.lanes.n), dim3(256), 0, s, tb, p);
 }
 
 void launch_ref_to_pk(const uint64_t* ref, uint64_t* pk, uint32_t npolys, IndexMap pk_map, hipStream_t s) {

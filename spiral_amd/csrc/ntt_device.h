@@ -454,44 +454,6 @@ __device__ __forceinline__ void ntt_forward_block2(uint32_t* lo0, uint32_t* hi0,
         }
     }
 }
-template <bool CANONICAL = true>
-__device__ __forceinline__ void ntt_inverse_block2(uint32_t* lo0, uint32_t* hi0, uint32_t* lo1, uint32_t* hi1, uint64_t* sh0, uint64_t* sh1,
-                                                   const uint4* tw, uint32_t tid) {
-    const TwTable tb(tw);
-    Tw7 wd = tw_load4x2(tb, 512 + 2 * tid, 1024 + 4 * tid);
-    Tw7 wc = tw_load8(tb, 64 + (tid >> 2), 128 + 2 * (tid >> 2), 256 + 4 * (tid >> 2));
-    gs_radix4x2_pre(lo0, hi0, wd);
-    gs_radix4x2_pre(lo1, hi1, wd);
-    lds_put<ix_d>(sh0, tid, lo0, hi0);
-    lds_put<ix_d>(sh1, tid, lo1, hi1);
-    __syncthreads();
-    lds_get<ix_c>(sh0, tid, lo0, hi0);
-    lds_get<ix_c>(sh1, tid, lo1, hi1);
-    Tw7 wb = tw_load8(tb, 8 + (tid >> 5), 16 + 2 * (tid >> 5), 32 + 4 * (tid >> 5));
-    gs_radix8_pre(lo0, hi0, wc);
-    gs_radix8_pre(lo1, hi1, wc);
-    lds_put<ix_c>(sh0, tid, lo0, hi0);
-    lds_put<ix_c>(sh1, tid, lo1, hi1);
-    __syncthreads();
-    lds_get<ix_b>(sh0, tid, lo0, hi0);
-    lds_get<ix_b>(sh1, tid, lo1, hi1);
-    Tw7 wa = tw_load8(tw, 1, 2, 4);
-    const uint4 ninv = tw[0];
-    gs_radix8_pre(lo0, hi0, wb);
-    gs_radix8_pre(lo1, hi1, wb);
-    lds_put<ix_b>(sh0, tid, lo0, hi0);
-    lds_put<ix_b>(sh1, tid, lo1, hi1);
-    __syncthreads();
-    lds_get<ix_a>(sh0, tid, lo0, hi0);
-    lds_get<ix_a>(sh1, tid, lo1, hi1);
-    gs_radix8_last(lo0, hi0, wa, ninv);
-    gs_radix8_last(lo1, hi1, wa, ninv);
-    if constexpr (CANONICAL) {
-        canonicalize8(lo0, hi0);
-        canonicalize8(lo1, hi1);
-    }
-}
-
 // CRT lift of a coefficient whose residues are (x mod p canonical, y mod b in [0, 2b)) to [0, Q): Garner form as
 // common.h crt_compose (src/poly.cpp:344-353), the product by p^-1 mod b as a Shoup product so that it takes three
 // multiplies instead of a 64-bit remainder, and the b-side consumed lazily.

@@ -50,12 +50,20 @@ struct FoldMacParams {
     uint32_t K;
     uint32_t ks;          // polynomials between key rows (>= K)
     const uint64_t* add;  // optional addend [np][3][2] (the pair form: out = C[i] + Q * D'), fields any u32
+    Lanes lanes;          // every pointer per query lane (each query folds with its own keys)
 };
 // B ciphertexts per workgroup share every key word loaded (the key is common to all ciphertexts of a round)
 template <uint32_t B>
 __global__ __launch_bounds__(kTpb) void fold_mac_kernel(FoldMacParams p) {
     __shared__ uint64_t sh[3][64][12 * B];
     const uint32_t zz = threadIdx.x & 63u, kg = threadIdx.x >> 6, z = blockIdx.x * 64u + zz, i0 = blockIdx.y * B;
+    {
+        const int64_t lane = p.lanes.here();
+        lane_shift(p.key, lane);
+        lane_shift(p.d, lane);
+        lane_shift(p.out, lane);
+        lane_shift(p.add, lane);
+    }
     const uint64_t* dp = p.d + (size_t)i0 * p.K * 2 * kN + z;
     const uint64_t* kp = p.key + z;
     Acc2 acc[B][3][2];
@@ -147,13 +155,14 @@ __global__ __launch_bounds__(kTpb) void fold_mac_kernel(FoldMacParams p) {
                 }
     }
 }
-void launch_fold_mac(const uint64_t* key, const uint64_t* d, uint64_t* out, uint32_t K, uint32_t np, hipStream_t s, uint32_t key_stride, const uint64_t* addend) {
+void launch_fold_mac(const uint64_t* key, const uint64_t* d, uint64_t* out, uint32_t K, uint32_t np, hipStream_t s, uint32_t key_stride, const uint64_t* addend,
+                     const Lanes& lanes) {
     if (np == 0) return;
-    FoldMacParams p{key, d, out, K, key_stride ? key_stride : K, addend};
+    FoldMacParams p{key, d, out, K, key_stride ? key_stride : K, addend, lanes};
     if (np >= 16 && np % 2 == 0)  // wide rounds: 2 ciphertexts per workgroup
-        hipLaunchKernelGGL(fold_mac_kernel<2>, dim3(kN / 64, np / 2), dim3(kTpb), 0, s, p);
+        hipLaunchKernelGGL(fold_mac_kernel<2>, dim3(kN / 64, np / 2, lanes.n), dim3(kTpb), 0, s, p);
     else
-        hipLaunchKernelGGL(fold_mac_kernel<1>, dim3(kN / 64, np), dim3(kTpb), 0, s, p);
+        hipLaunchKernelGGL(fold_mac_kernel<1>, dim3(kN / 64, np, lanes.n), dim3(kTpb), 0, s, p);
 }
 
 // ---- add / mul_by_const (src/poly.cpp:138-155, 190-211) ----------------------------------------------
@@ -217,8 +226,10 @@ __global__ __launch_bounds__(kTpb) void rescale_kernel(const uint64_t* in, uint6
 }
 // the response switch in one launch: elements [0, n0) -> out_mod0 (row 0 -> q'), [n0, n) -> out_mod1 (the rest -> 4p)
 __global__ __launch_bounds__(kTpb) void rescale2_kernel(const uint64_t* in, uint64_t* out, uint32_t n0, uint32_t n, uint64_t inp_mod, uint64_t out_mod0,
-                                                        uint64_t out_mod1) {
+                                                        uint64_t out_mod1, Lanes lanes) {
     const uint32_t i = blockIdx.x * kTpb + threadIdx.x;
+    lane_shift(in, lanes.here());
+    lane_shift(out, lanes.here());
     if (i < n) out[i] = rescale_dev(in[i] % kQ, inp_mod, i < n0 ? out_mod0 : out_mod1);
 }
 // wire form of a switched response (the bit stream write_arbitrary_bits builds, src/core.cpp:32-52, along modswitch's walk,
@@ -246,17 +257,27 @@ void launch_response_wire(const uint64_t* in, uint64_t* out, uint32_t n0, uint32
     const uint32_t words = n0 / 64u * w0 + n1 / 64u * w1;
     hipLaunchKernelGGL(response_wire_kernel, dim3((words + kTpb - 1) / kTpb), dim3(kTpb), 0, s, in, out, n0, w0, n1, w1);
 }
-void launch_rescale2(const uint64_t* in, uint64_t* out, uint32_t n0, uint32_t n, uint64_t inp_mod, uint64_t out_mod0, uint64_t out_mod1, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(rescale2_kernel, dim3((n + kTpb - 1) / kTpb), dim3(kTpb), 0, s, in, out, n0, n, inp_mod, out_mod0, out_mod1);
+void launch_rescale2(const uint64_t* in, uint64_t* out, uint32_t n0, uint32_t n, uint64_t inp_mod, uint64_t out_mod0, uint64_t out_mod1, hipStream_t s,
+                     const Lanes& lanes) {
+    if (n) hipLaunchKernelGGL(rescale2_kernel, dim3((n + kTpb - 1) / kTpb, 1, lanes.n), dim3(kTpb), 0, s, in, out, n0, n, inp_mod, out_mod0, out_mod1, lanes);
 }
 void launch_rescale(const uint64_t* in, uint64_t* out, uint32_t n, uint64_t inp_mod, uint64_t out_mod, hipStream_t s) {
     if (n) hipLaunchKernelGGL(rescale_kernel, dim3((n + kTpb - 1) / kTpb), dim3(kTpb), 0, s, in, out, n, inp_mod, out_mod);
 }
 
 // ---- coefficient expansion (src/spiral.cpp:1664-1743) -------------------------------------------------------
+__device__ __forceinline__ void expand_mac_lane(ExpandMacParams& p) {  // query lane blockIdx.z: every query has its own ciphertexts, keys and scratch
+    const int64_t lane = p.lanes.here();
+    lane_shift(p.cv, lane);
+    lane_shift(p.w_e, lane);
+    lane_shift(p.w_o, lane);
+    lane_shift(p.g, lane);
+    lane_shift(p.a1, lane);
+}
 // whole-round MAC: 64 slots x 4 k-groups per workgroup, partial sums combined through LDS
 __global__ __launch_bounds__(kTpb) void expand_mac_round_kernel(ExpandMacParams p) {
     __shared__ uint64_t sh[3][64][4];
+    expand_mac_lane(p);
     const uint32_t zz = threadIdx.x & 63u, kg = threadIdx.x >> 6, z = blockIdx.x * 64u + zz, a = blockIdx.y;
     const bool odd = a >= p.cnt_e;
     const uint32_t tdim = odd ? p.t_o : p.t_e;
@@ -320,6 +341,7 @@ __global__ __launch_bounds__(kTpb) void expand_mac_round_kernel(ExpandMacParams 
 typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(kTpb) void expand_mac_round_wide_kernel(ExpandMacParams p) {
     __shared__ uint64_t sh[3][64][8];
+    expand_mac_lane(p);
     const uint32_t zz = threadIdx.x & 63u, kg = threadIdx.x >> 6, z = (blockIdx.x * 64u + zz) * 2u, a = blockIdx.y;
     const bool odd = a >= p.cnt_e;
     const uint32_t tdim = odd ? p.t_o : p.t_e;
@@ -396,6 +418,7 @@ __global__ __launch_bounds__(kTpb) void expand_mac_round_wide_kernel(ExpandMacPa
 template <int CT>
 __global__ __launch_bounds__(kTpb) void expand_mac_round_batch_kernel(ExpandMacParams p) {
     __shared__ uint64_t sh[4][CT][8][64];
+    expand_mac_lane(p);
     const uint32_t zz = threadIdx.x & 63u, kg = threadIdx.x >> 6, z = (blockIdx.x * 64u + zz) * 2u;
     const uint32_t groups_e = (p.cnt_e + CT - 1) / CT;
     const bool odd = blockIdx.y >= groups_e;
@@ -501,13 +524,13 @@ void launch_expand_mac_round(const ExpandMacParams& p, hipStream_t s) {
         return e ? (uint32_t)strtoul(e, nullptr, 10) : 128u;
     }();
     if (cnt >= ct4_min)
-        hipLaunchKernelGGL(expand_mac_round_batch_kernel<4>, dim3(kN / 128, (p.cnt_e + 3) / 4 + (p.cnt_o + 3) / 4), dim3(kTpb), 0, s, p);
+        hipLaunchKernelGGL(expand_mac_round_batch_kernel<4>, dim3(kN / 128, (p.cnt_e + 3) / 4 + (p.cnt_o + 3) / 4, p.lanes.n), dim3(kTpb), 0, s, p);
     else if (cnt >= ct2_min)
-        hipLaunchKernelGGL(expand_mac_round_batch_kernel<2>, dim3(kN / 128, (p.cnt_e + 1) / 2 + (p.cnt_o + 1) / 2), dim3(kTpb), 0, s, p);
+        hipLaunchKernelGGL(expand_mac_round_batch_kernel<2>, dim3(kN / 128, (p.cnt_e + 1) / 2 + (p.cnt_o + 1) / 2, p.lanes.n), dim3(kTpb), 0, s, p);
     else if (cnt >= wide_min)
-        hipLaunchKernelGGL(expand_mac_round_wide_kernel, dim3(kN / 128, cnt), dim3(kTpb), 0, s, p);
+        hipLaunchKernelGGL(expand_mac_round_wide_kernel, dim3(kN / 128, cnt, p.lanes.n), dim3(kTpb), 0, s, p);
     else
-        hipLaunchKernelGGL(expand_mac_round_kernel, dim3(kN / 64, cnt), dim3(kTpb), 0, s, p);
+        hipLaunchKernelGGL(expand_mac_round_kernel, dim3(kN / 64, cnt, p.lanes.n), dim3(kTpb), 0, s, p);
 }
 
 // ---- scalToMat (src/spiral.cpp:1834-1885) ----------------------------------------------------------------------
@@ -551,7 +574,25 @@ __device__ __forceinline__ void scal2mat_slot(const uint64_t* w, const uint64_t*
             out[r][c] = v;
         }
 }
+__device__ __forceinline__ void scal2mat_lane(Scal2MatParams& p) {  // query lane blockIdx.z
+    const int64_t lane = p.lanes.here();
+    lane_shift(p.w, lane);
+    lane_shift(p.g, lane);
+    lane_shift(p.cv, lane);
+    lane_shift(p.out, lane);
+    lane_shift(p.qs, lane);  // (u32 records in a u64-word arena: the shift is in bytes)
+}
+__device__ __forceinline__ void gsw_lane(GswParams& p) {
+    const int64_t lane = p.lanes.here();
+    lane_shift(p.w, lane);
+    lane_shift(p.v, lane);
+    lane_shift(p.chat, lane);
+    lane_shift(p.cv, lane);
+    lane_shift(p.gsw, lane);
+    lane_shift(p.key, lane);
+}
 __global__ __launch_bounds__(kTpb) void scal2mat_kernel(Scal2MatParams p) {
+    scal2mat_lane(p);
     const uint32_t z = blockIdx.x * kTpb + threadIdx.x, a = blockIdx.y;
     const uint64_t cv1 = p.cv[((size_t)p.cv_pos(a) * 2 + 1) * kN + z];
     uint64_t out[3][2];
@@ -663,18 +704,24 @@ static uint32_t scal2mat_wide_min() {
     }();
     return v;
 }
-__global__ __launch_bounds__(kTpb) void scal2mat_rec4_kernel(Scal2MatParams p) { scal2mat_rec4_body(p, blockIdx.x, blockIdx.y); }
-__global__ __launch_bounds__(kTpb) void scal2mat_rec_kernel(Scal2MatParams p) { scal2mat_rec_body(p, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(kTpb) void scal2mat_rec4_kernel(Scal2MatParams p) {
+    scal2mat_lane(p);
+    scal2mat_rec4_body(p, blockIdx.x, blockIdx.y);
+}
+__global__ __launch_bounds__(kTpb) void scal2mat_rec_kernel(Scal2MatParams p) {
+    scal2mat_lane(p);
+    scal2mat_rec_body(p, blockIdx.x, blockIdx.y);
+}
 static bool scal2mat_rec_ok(const Scal2MatParams& p) { return p.count && p.count % 16 == 0 && p.qs && !p.out; }
 void launch_scal2mat(const Scal2MatParams& p, hipStream_t s) {
     if (scal2mat_rec_ok(p)) {
         if (p.t_conv >= scal2mat_wide_min())
-            hipLaunchKernelGGL(scal2mat_rec4_kernel, dim3(kN / 64, p.count / 16), dim3(kTpb), 0, s, p);
+            hipLaunchKernelGGL(scal2mat_rec4_kernel, dim3(kN / 64, p.count / 16, p.lanes.n), dim3(kTpb), 0, s, p);
         else
-            hipLaunchKernelGGL(scal2mat_rec_kernel, dim3(kN / 16, p.count / 16), dim3(kTpb), 0, s, p);
+            hipLaunchKernelGGL(scal2mat_rec_kernel, dim3(kN / 16, p.count / 16, p.lanes.n), dim3(kTpb), 0, s, p);
         return;
     }
-    if (p.count) hipLaunchKernelGGL(scal2mat_kernel, dim3(kBpp, p.count), dim3(kTpb), 0, s, p);
+    if (p.count) hipLaunchKernelGGL(scal2mat_kernel, dim3(kBpp, p.count, p.lanes.n), dim3(kTpb), 0, s, p);
 }
 
 // ---- regevToGSW (src/spiral.cpp:1985-2025) ------------------------------------------------------------------------
@@ -713,11 +760,16 @@ __device__ __forceinline__ void regev_to_gsw_body(const GswParams& p, uint32_t b
         }
     }
 }
-__global__ __launch_bounds__(kTpb) void regev_to_gsw_kernel(GswParams p) { regev_to_gsw_body(p, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(kTpb) void regev_to_gsw_kernel(GswParams p) {
+    gsw_lane(p);
+    regev_to_gsw_body(p, blockIdx.x, blockIdx.y);
+}
 // the two conversion products are independent: one launch, the first n1 blocks ScalToMat, the rest Regev->GSW
 template <bool WIDE>
 __global__ __launch_bounds__(kTpb) void convert_products_kernel(Scal2MatParams sp, GswParams gp, uint32_t n1) {
     const uint32_t b = blockIdx.x;
+    scal2mat_lane(sp);
+    gsw_lane(gp);
     if (b < n1) {
         if constexpr (WIDE)
             scal2mat_rec4_body(sp, b % (kN / 64u), b / (kN / 64u));
@@ -733,16 +785,16 @@ void launch_convert_products(const Scal2MatParams& sp, const GswParams& gp, hipS
         const bool wide = sp.t_conv >= scal2mat_wide_min();
         const uint32_t n1 = (kN / (wide ? 64u : 16u)) * (sp.count / 16u), n2 = kBpp * gp.dims * gp.ell;
         if (wide)
-            hipLaunchKernelGGL(convert_products_kernel<true>, dim3(n1 + n2), dim3(kTpb), 0, s, sp, gp, n1);
+            hipLaunchKernelGGL(convert_products_kernel<true>, dim3(n1 + n2, 1, sp.lanes.n), dim3(kTpb), 0, s, sp, gp, n1);
         else
-            hipLaunchKernelGGL(convert_products_kernel<false>, dim3(n1 + n2), dim3(kTpb), 0, s, sp, gp, n1);
+            hipLaunchKernelGGL(convert_products_kernel<false>, dim3(n1 + n2, 1, sp.lanes.n), dim3(kTpb), 0, s, sp, gp, n1);
     } else {
         launch_scal2mat(sp, s);
         launch_regev_to_gsw(gp, s);
     }
 }
 void launch_regev_to_gsw(const GswParams& p, hipStream_t s) {
-    if (p.dims) hipLaunchKernelGGL(regev_to_gsw_kernel, dim3(kBpp, p.dims * p.ell), dim3(kTpb), 0, s, p);
+    if (p.dims) hipLaunchKernelGGL(regev_to_gsw_kernel, dim3(kBpp, p.dims * p.ell, p.lanes.n), dim3(kTpb), 0, s, p);
 }
 
 // ---- fold key from the reference's reoriented matrices (the resident path writes its keys in regev_to_gsw_kernel) --------

@@ -32,6 +32,9 @@ struct spiral_gpu_server {
     // expanded-ciphertext positions inside cv: first-dim j at j*pos_stride + pos_first, rest i at i*pos_stride + pos_rest
     uint32_t pos_stride = 1, pos_first = 0, pos_rest = 0, n_cv = 0;
 
+    // every per-query buffer below except the lazily allocated ones (ex_raw2, ex_g2, cts_keep, stage, wire) is a piece of `arena`, carved in one
+    // fixed order (srv_alloc): servers with equal parameters and shard have equal layouts, which is what run_query_batch relies on
+    DevBuf arena;
     DevBuf db, w_left, w_right, w, v, query, cv, ex_raw, ex_g, ex_raw2, ex_g2;  // (the second work set: the odd tree of a split expansion)
     DevBuf cv_raw, cv_g, gsw, key, cts_keep;
     uint64_t *gs_raw_p = nullptr, *gs_chat_p = nullptr;  // the Regev->GSW halves of cv_raw / cv_g
@@ -45,34 +48,32 @@ struct spiral_gpu_server {
     hipGraphExec_t graph[13] = {};  // [12] = ScalToMat alone  // [8] = sharded expansion + pack, [9] = unpack + convert + sweep, [10] = ScalToMat + sweep, [11] = unpack + Regev->GSW
     const void *cap_chunk = nullptr, *cap_gathered = nullptr;
     void* cap_ct = nullptr;  // the caller's buffers captured into graphs 5 and 6
-    // overlap mode: run_pre forks the Regev->GSW conversion (needed only by the folding) onto side_stream so that it
-    // runs under the HBM-bound sweep; the fold entry points join it
     // overlap 2 ("split"): the whole GSW side of the query -- the odd-index tree of the expansion AND the Regev->GSW conversion -- runs as its
-    // own launch sequence on side_stream, beside the even tree + ScalToMat + sweep on the main stream; only the folding needs it
+    // own launch sequence on side_stream, beside the even tree + ScalToMat + sweep on the main stream; only the folding needs it.
+    // (Modes 1 and 3 -- only the conversion forked, under the sweep -- measured slower and were removed in round 5, HISTORY.md.)
     int overlap = 0;
     bool side_pending = false;
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_batch = nullptr;  // first_dim_batch: this lane's records are ready / the shared sweep is done
-    // fold chain (fold_chain_kernel): a block lifts one source polynomial and transforms dpb of its digits; dpb is halved
-    // from ell until the round has at least fold_blocks blocks.  SPIRAL_FOLD_CHAIN=0 (separate lift + digit transforms) and
-    // SPIRAL_FOLD_BLOCKS override (tuning / tests).
+    // Fold round forms.  Default: the pair form, unchained (lift launch + LD_SDIFF digit-difference launch + product with addend).
+    // fold_pair = false (SPIRAL_FOLD_PAIR=0) or a gadget dimension whose digits do not recompose (!fold_pair_exact): the reference's
+    // two-product form, lift chained into the digit transforms (fold_chain_kernel: a block lifts one source polynomial and transforms
+    // dpb of its digits; dpb is halved from ell until the round has at least fold_blocks blocks, SPIRAL_FOLD_BLOCKS) or, with
+    // SPIRAL_FOLD_CHAIN=0, as separate lift + LD_SDIGIT launches.  (The chained pair forms fold_pair_kernel / fold_team_kernel tied
+    // with the unchained one and were removed in round 5; HISTORY.md has the numbers and the commit.)
     bool fold_chain = true;
-    // pair form of a chained fold round (fold_pair_kernel: out = C[i] + Q * NTT(G^-1(C[np+i]) - G^-1(C[i])), half the forward
-    // transforms and half the product); SPIRAL_FOLD_PAIR=0 keeps the reference's two-product form (tests compare both)
     bool fold_pair = true;
-    // pair-form rounds with at least this many polynomial pairs run unchained (lift launch + LD_SDIFF digit launch + product); narrower
-    // ones would chain the lift into the digit transforms (fold_team_kernel / fold_pair_kernel: one launch less, the two inverse transforms
-    // repeated per digit chunk).  Measured equal within 1-2 us for the narrow rounds of config 2 and slower for the wide ones
-    // (profiles/r04_fold_pair.txt), so every round runs unchained by default; SPIRAL_FOLD_UNCHAIN_MIN selects the chained forms (tests, A/B).
-    uint32_t fold_unchain_min = 1;
-    bool fold_team = true;  // SPIRAL_FOLD_TEAM=0: fold_pair_kernel (one 256-thread workgroup runs both inverse transforms)
     uint32_t fold_blocks = 768;
     uint32_t fold_g_log = 0;  // distributed fold over 2^fold_g_log ranks: the sweep groups its output by ii mod G
     uint32_t sweep_k_log = 0; // pipelined sweep in 2^sweep_k_log stages (set_sweep_stages): accumulators laid out [stage][rank][ct]
     ExpandShard ex_shard{};   // sharded expansion (set_expand_shard): what this rank expands itself
     const void* cap_bits_out = nullptr;  // the caller's exchange buffers captured into graphs 8 and 9
     const void* cap_bits_in = nullptr;
+    // run_query_batch with this server as lane 0: the captured launch sequence and the lane set it was captured for
+    hipGraphExec_t graph_batch = nullptr;
+    const uint64_t* batch_key[kMaxLanes] = {};  // the lanes' arenas: every pointer the capture holds is one of them plus a fixed offset
+    uint32_t batch_n = 0;
 };
 
 namespace {
@@ -101,36 +102,44 @@ int srv_alloc(spiral_gpu_server* S, const spiral_gpu_server* db_owner) {
     } else if (S->db.alloc(db_device_words((uint32_t)nic, S->dim0_shard))) {
         return -1;
     }
-    if (S->w_left.alloc((size_t)s.n_left * 2 * p.t_exp * kN)) return -1;
-    if (S->w_right.alloc((size_t)s.n_right * 2 * p.t_exp_right * kN)) return -1;
-    if (S->w.alloc((size_t)3 * 2 * p.t_conv * kN)) return -1;
-    if (S->v.alloc((size_t)3 * 2 * p.t_conv * kN)) return -1;
-    if (S->query.alloc((size_t)s.n_query_cts * 2 * kN)) return -1;
     S->n_cv = p.direct_upload ? s.n_bits : (1u << s.g);
-    if (S->cv.alloc((size_t)S->n_cv * 2 * kN)) return -1;
-    HIP_OK(hipMemset(S->cv.p, 0, S->cv.words * sizeof(uint64_t)));
-    if (!p.direct_upload) {
-        if (S->ex_raw.alloc((size_t)S->n_cv * 2 * kN)) return -1;
-        if (S->ex_g.alloc(expand_g_polys(s.g, p.t_exp, p.t_exp_right) * kN)) return -1;
-    }
-    // conversion scratch: the ScalToMat sources/digits followed by the Regev->GSW ones, so both sets go through one lift
-    // launch and one digit-transform launch
     const size_t ngs = (size_t)p.nu2 * s.ell;
-    if (S->cv_raw.alloc(((size_t)S->dim0_shard + ngs * 2) * kN)) return -1;
-    if (S->cv_g.alloc(((size_t)S->dim0_shard + ngs * 2) * p.t_conv * kN)) return -1;
+    const size_t half = s.num_per > 1 ? s.num_per / 2 : 1;
+    auto layout = [&](Arena& a) {
+        a.carve(S->w_left, (size_t)s.n_left * 2 * p.t_exp * kN);
+        a.carve(S->w_right, (size_t)s.n_right * 2 * p.t_exp_right * kN);
+        a.carve(S->w, (size_t)3 * 2 * p.t_conv * kN);
+        a.carve(S->v, (size_t)3 * 2 * p.t_conv * kN);
+        a.carve(S->query, (size_t)s.n_query_cts * 2 * kN);
+        a.carve(S->cv, (size_t)S->n_cv * 2 * kN);
+        if (!p.direct_upload) {
+            a.carve(S->ex_raw, (size_t)S->n_cv * 2 * kN);
+            a.carve(S->ex_g, expand_g_polys(s.g, p.t_exp, p.t_exp_right) * kN);
+        }
+        // conversion scratch: the ScalToMat sources/digits followed by the Regev->GSW ones, so both sets go through one lift
+        // launch and one digit-transform launch
+        a.carve(S->cv_raw, ((size_t)S->dim0_shard + ngs * 2) * kN);
+        a.carve(S->cv_g, ((size_t)S->dim0_shard + ngs * 2) * p.t_conv * kN);
+        a.carve(S->gsw, (size_t)p.nu2 * 3 * s.m2 * kN);
+        a.carve(S->key, (size_t)p.nu2 * 3 * 2 * s.m2 * kN);
+        a.carve(S->qs, (size_t)kN * S->dim0_shard * 6);  // 12 u32 per (z, j)
+        a.carve(S->acc_own, (size_t)s.num_per * 6 * kN);
+        a.carve(S->raw, (size_t)s.num_per * 6 * kN);
+        a.carve(S->fold_d, half * 2 * s.m2 * 2 * kN);
+        a.carve(S->fold_c, half * 6 * kN);
+        a.carve(S->fold_c2, half * 6 * kN);
+        a.carve(S->resp, (size_t)6 * kN);
+    };
+    Arena sizing;
+    layout(sizing);
+    if (S->arena.alloc(sizing.used)) return -1;
+    Arena real;
+    real.base = S->arena.p;
+    layout(real);
+    HIP_OK(hipMemset(S->cv.p, 0, S->cv.words * sizeof(uint64_t)));
     S->gs_raw_p = S->cv_raw.p + (size_t)S->dim0_shard * kN;
     S->gs_chat_p = S->cv_g.p + (size_t)S->dim0_shard * p.t_conv * kN;
-    if (S->gsw.alloc((size_t)p.nu2 * 3 * s.m2 * kN)) return -1;
-    if (S->key.alloc((size_t)p.nu2 * 3 * 2 * s.m2 * kN)) return -1;
-    if (S->qs.alloc((size_t)kN * S->dim0_shard * 6)) return -1;  // 12 u32 per (z, j)
-    if (S->acc_own.alloc((size_t)s.num_per * 6 * kN)) return -1;
     S->acc = S->acc_own.p;
-    if (S->raw.alloc((size_t)s.num_per * 6 * kN)) return -1;
-    const size_t half = s.num_per > 1 ? s.num_per / 2 : 1;
-    if (S->fold_d.alloc(half * 2 * s.m2 * 2 * kN)) return -1;
-    if (S->fold_c.alloc(half * 6 * kN)) return -1;
-    if (S->fold_c2.alloc(half * 6 * kN)) return -1;
-    if (S->resp.alloc((size_t)6 * kN)) return -1;
     return 0;
 }
 
@@ -140,6 +149,9 @@ void srv_drop_graphs(spiral_gpu_server* S) {
             (void)hipGraphExecDestroy(g);
             g = nullptr;
         }
+    if (S->graph_batch) (void)hipGraphExecDestroy(S->graph_batch);
+    S->graph_batch = nullptr;
+    S->batch_n = 0;
 }
 
 void srv_free(spiral_gpu_server* S, bool keep_db = false) {
@@ -151,7 +163,7 @@ void srv_free(spiral_gpu_server* S, bool keep_db = false) {
     }
     DevBuf* all[] = {&S->db, &S->w_left, &S->w_right, &S->w, &S->v, &S->query, &S->cv, &S->ex_raw, &S->ex_g, &S->ex_raw2, &S->ex_g2, &S->cv_raw,
                      &S->cv_g, &S->gsw, &S->key, &S->cts_keep, &S->qs, &S->acc_own, &S->raw, &S->fold_d, &S->fold_c, &S->fold_c2,
-                     &S->resp, &S->stage, &S->wire};
+                     &S->resp, &S->stage, &S->wire, &S->arena};  // (the arena after its pieces)
     if (S->db_shared) S->db.p = nullptr;
     for (DevBuf* b : all) b->release();
     for (auto& e : S->ev)
@@ -645,8 +657,6 @@ static int srv_create(const spiral_gpu_params* p, int device, uint32_t j_begin, 
     S->dim0_shard = j_end - j_begin;
     if (const char* e = getenv("SPIRAL_FOLD_CHAIN")) S->fold_chain = atoi(e) != 0;
     if (const char* e = getenv("SPIRAL_FOLD_PAIR")) S->fold_pair = atoi(e) != 0;
-    if (const char* e = getenv("SPIRAL_FOLD_TEAM")) S->fold_team = atoi(e) != 0;
-    if (const char* e = getenv("SPIRAL_FOLD_UNCHAIN_MIN")) S->fold_unchain_min = (uint32_t)strtoul(e, nullptr, 10);
     if (const char* e = getenv("SPIRAL_FOLD_BLOCKS")) S->fold_blocks = (uint32_t)strtoul(e, nullptr, 10);
     if (p->direct_upload || s.stopround == 0) {
         S->pos_stride = 1;
@@ -916,20 +926,32 @@ int spiral_gpu_server_set_query(spiral_gpu_server* S, const uint64_t* query) {
     return 0;
 }
 
+}  // extern "C"
+
+namespace {
+// expandImproved for the query lanes `lanes` of S (lane 0 = S itself)
+int expand_lanes(spiral_gpu_server* S, const Lanes& lanes) {
+    const spiral_gpu_params& p = S->p;
+    if (p.direct_upload || S->s.g == 0) {  // nothing to expand: the query ciphertexts are the expanded ones
+        const size_t n = p.direct_upload ? (size_t)S->s.n_bits * 2 : 2;
+        for (uint32_t q = 0; q < lanes.n; q++)
+            HIP_OK(hipMemcpyAsync(S->cv.p + lanes.off[q], S->query.p + lanes.off[q], n * kPolyBytes, hipMemcpyDeviceToDevice, S->stream));
+        return 0;
+    }
+    ExpandWork wk{S->ex_raw.p, S->ex_g.p};
+    run_expand(S->tb, S->cv.p, S->s.g, p.t_exp, S->w_left.p, p.t_exp_right, S->w_right.p, S->s.ell * p.nu2, S->s.stopround, wk, S->stream, S->query.p, 0, 0xffffffffu,
+               S->ex_shard, 3, lanes);
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
 int spiral_gpu_server_expand(spiral_gpu_server* S) {
     if (!S) return fail("null server");
     HIP_OK(hipSetDevice(S->device));
     if (!S->have_query || !S->have_pp) return fail("query and public parameters must be set before expand");
-    const spiral_gpu_params& p = S->p;
-    if (p.direct_upload) {
-        HIP_OK(hipMemcpyAsync(S->cv.p, S->query.p, (size_t)S->s.n_bits * 2 * kPolyBytes, hipMemcpyDeviceToDevice, S->stream));
-        return 0;
-    }
-    ExpandWork wk{S->ex_raw.p, S->ex_g.p};
-    run_expand(S->tb, S->cv.p, S->s.g, p.t_exp, S->w_left.p, p.t_exp_right, S->w_right.p, S->s.ell * p.nu2, S->s.stopround, wk, S->stream,
-               S->s.g ? S->query.p : nullptr, 0, 0xffffffffu, S->ex_shard);
-    if (S->s.g == 0) HIP_OK(hipMemcpyAsync(S->cv.p, S->query.p, 2 * kPolyBytes, hipMemcpyDeviceToDevice, S->stream));
-    return 0;
+    return expand_lanes(S, Lanes{});
 }
 
 }  // extern "C"
@@ -940,7 +962,7 @@ namespace {
 // Regev->GSW part (the nu2 further dimensions + fold keys, src/spiral.cpp:2315-2331, 2361-2386), or both with the lifts and
 // the digit transforms of the two parts merged into one launch each (their scratch is contiguous).
 enum ConvertWhat : uint32_t { CONV_S2M = 1, CONV_GSW = 2, CONV_BOTH = 3 };
-int convert_part(spiral_gpu_server* S, uint32_t what, hipStream_t st, bool mark_split = false) {
+int convert_part(spiral_gpu_server* S, uint32_t what, hipStream_t st, bool mark_split = false, const Lanes& lanes = Lanes{}) {
     const spiral_gpu_params& p = S->p;
     const spiral_gpu_shape& s = S->s;
     const uint32_t ps = S->pos_stride, ngs = p.nu2 * s.ell;
@@ -956,6 +978,7 @@ int convert_part(spiral_gpu_server* S, uint32_t what, hipStream_t st, bool mark_
     ip.split = (n1 && n2) ? n1 : 0;
     ip.src_map2 = map2;
     ip.dst_map = identity_map();
+    ip.lanes = lanes;
     launch_ntt_inverse(S->tb, ip, IST_CRT, n1 + n2, st);
     FwdParams fp{};
     fp.src = ip.dst;
@@ -964,6 +987,7 @@ int convert_part(spiral_gpu_server* S, uint32_t what, hipStream_t st, bool mark_
     fp.n_digits = p.t_conv;
     fp.bits = get_bits_per(p.t_conv);
     fp.lazy_out = lazy_ok(2 * p.t_conv) ? 1 : 0;  // read only by the conversion products, which sum at most 2 * t_conv terms per accumulator
+    fp.lanes = lanes;
     launch_ntt_forward(S->tb, fp, LD_DIGIT, ST_PK, (n1 + n2) * p.t_conv, st);
     Scal2MatParams sp{};
     sp.w = S->w.p;
@@ -976,6 +1000,7 @@ int convert_part(spiral_gpu_server* S, uint32_t what, hipStream_t st, bool mark_
     sp.count = S->dim0_shard;
     sp.jm_total = 2 * S->dim0_shard;
     sp.j_base = 0;
+    sp.lanes = lanes;
     GswParams gp{};
     gp.w = S->w.p;
     gp.v = S->v.p;
@@ -987,6 +1012,7 @@ int convert_part(spiral_gpu_server* S, uint32_t what, hipStream_t st, bool mark_
     gp.ell = s.ell;
     gp.dims = p.nu2;
     gp.key = S->key.p;  // fold keys in the same pass
+    gp.lanes = lanes;
     if (what == CONV_BOTH && !mark_split) {  // the two products are independent: one launch
         launch_convert_products(sp, gp, st);
         return 0;
@@ -1029,13 +1055,14 @@ int spiral_gpu_server_convert(spiral_gpu_server* S) {
 int spiral_gpu_server_set_overlap(spiral_gpu_server* S, int on) {
     if (!S) return fail("null server");
     HIP_OK(hipSetDevice(S->device));
+    if (on != 0 && on != 2) return fail("overlap mode %d: only 0 (one stream) and 2 (split: the GSW side on a side stream) exist", on);
     if (srv_join_side(S)) return -1;
-    if (on == 2 || on == 3) {  // split: the odd tree needs its own work buffers, and evens / odds must be first-dimension / GSW ciphertexts
+    if (on == 2) {  // the odd tree needs its own work buffers, and evens / odds must be first-dimension / GSW ciphertexts
         if (S->p.direct_upload || S->s.g == 0 || S->s.stopround == 0 || S->ex_shard.g_log) return fail("split overlap needs query compression with stopround > 0 on an unsharded expansion");
         if (!S->ex_raw2.p && S->ex_raw2.alloc((size_t)S->n_cv * 2 * kN)) return -1;
         if (!S->ex_g2.p && S->ex_g2.alloc(expand_g_polys(S->s.g, S->p.t_exp, S->p.t_exp_right) * kN)) return -1;
     }
-    S->overlap = (on == 2 || on == 3) ? on : (on != 0 ? 1 : 0);
+    S->overlap = on;
     srv_drop_graphs(S);
     return 0;
 }
@@ -1150,8 +1177,14 @@ namespace {
 // finish: the folded ciphertext is the answer; follow with the response modulus switch (spiral_gpu_server_finish).
 // raw_addend: with src_pk == nullptr, the transform-domain words of the ciphertexts lifted in S->raw, when the caller still has them
 // (the stage API's fold after lift: the accumulators) -- the first round can then take the pair form too (LD_SDIFF on S->raw).
+// lanes: the same rounds for every query lane in the same launches (all pointers are lane 0's, kernels.h Lanes).
+int finish_lanes(spiral_gpu_server* S, const Lanes& lanes) {
+    // row 0 -> q', rows 1.. -> 4*p_db (src/spiral.cpp:1441-1447)
+    launch_rescale2(S->raw.p, S->resp.p, 2 * kN, 6 * kN, kQ, S->s.qprime, 4 * S->p.p_db, S->stream, lanes);
+    return 0;
+}
 int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t rounds, const uint64_t* src_pk, bool pre_reduce, bool finish = false,
-                    const uint64_t* raw_addend = nullptr) {
+                    const uint64_t* raw_addend = nullptr, const Lanes& lanes = Lanes{}) {
     const spiral_gpu_shape& s = S->s;
     S->raw_from_acc = false;  // S->raw ends up holding the folded ciphertext
     uint32_t np = np0;
@@ -1161,6 +1194,7 @@ int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t ro
         ip.dst = S->raw.p;
         ip.src_map = ip.dst_map = identity_map();
         ip.pre_reduce = pre_reduce ? 1 : 0;
+        ip.lanes = lanes;
         launch_ntt_inverse(S->tb, ip, IST_CRT, npolys, S->stream);
         src_pk = nullptr;
     };
@@ -1171,7 +1205,7 @@ int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t ro
         const uint64_t* key = S->key.p + (size_t)d * 3 * 2 * s.m2 * kN;
         if (src_pk == out_pk) out_pk = out_pk == S->fold_c.p ? S->fold_c2.p : S->fold_c.p;  // the pair form's product reads its source
         const bool from_raw = !src_pk && raw_addend && S->fold_pair && fold_pair_exact(s.ell);  // lifted already, transform-domain words at hand
-        if (from_raw || (src_pk && S->fold_chain && S->fold_pair && fold_pair_exact(s.ell) && n_src / 2 >= S->fold_unchain_min)) {
+        if (from_raw || (src_pk && S->fold_chain && S->fold_pair && fold_pair_exact(s.ell))) {
             // wide round: the lift of all 2 np ciphertexts as one full-occupancy launch, then one digit-difference transform per
             // workgroup (LD_SDIFF) -- no inverse transform is repeated, both kernels run 8 workgroups per CU
             const uint64_t* low = from_raw ? raw_addend : src_pk;
@@ -1181,6 +1215,7 @@ int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t ro
                 ip.dst = S->raw.p;
                 ip.src_map = ip.dst_map = identity_map();
                 ip.pre_reduce = pre_reduce ? 1 : 0;
+                ip.lanes = lanes;
                 launch_ntt_inverse(S->tb, ip, IST_CRT, n_src, S->stream);
             }
             raw_addend = nullptr;
@@ -1193,32 +1228,9 @@ int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t ro
             fp.ell = s.ell;
             fp.fold_np = np;
             fp.lazy_out = lazy_ok(3 * s.ell + 1) ? 1 : 0;
+            fp.lanes = lanes;
             launch_ntt_forward(S->tb, fp, LD_SDIFF, ST_PK, (n_src / 2) * s.ell, S->stream);
-            launch_fold_mac(key + (size_t)s.m2 * kN, S->fold_d.p, out_pk, s.m2, np, S->stream, 2 * s.m2, low);
-            src_pk = out_pk;
-            pre_reduce = false;
-            continue;
-        }
-        if (src_pk && S->fold_chain && S->fold_pair && fold_pair_exact(s.ell)) {
-            FoldPairParams pp{};
-            pp.src = src_pk;
-            pp.dst = S->fold_d.p;
-            pp.ell = s.ell;
-            pp.bits = get_bits_per(s.ell);
-            pp.fold_np = np;
-            pp.pre_reduce = pre_reduce ? 1 : 0;
-            pp.team = S->fold_team ? 1 : 0;
-            if (pp.team) {  // a block = two halves of dpb digits each; halve dpb until the round has about fold_blocks halves
-                uint32_t dpb = (s.ell + 1) / 2;
-                while (dpb > 1 && (n_src / 2) * 2 * ((s.ell + 2 * dpb - 1) / (2 * dpb)) < S->fold_blocks) dpb = (dpb + 1) / 2;
-                pp.dpb = dpb;
-            } else {
-                pp.dpb = fold_dpb(S, n_src / 2);
-            }
-            pp.lazy_out = lazy_ok(3 * s.ell + 1) ? 1 : 0;  // fold_mac sums m2 = 3 ell products and the addend per accumulator
-            launch_fold_pair(S->tb, pp, n_src / 2, S->stream);
-            // out[i] = C[i] + Q * D'[i]: the Q half of the key rows [Q_neg | Q], the low ciphertexts as the addend
-            launch_fold_mac(key + (size_t)s.m2 * kN, S->fold_d.p, out_pk, s.m2, np, S->stream, 2 * s.m2, src_pk);
+            launch_fold_mac(key + (size_t)s.m2 * kN, S->fold_d.p, out_pk, s.m2, np, S->stream, 2 * s.m2, low, lanes);
             src_pk = out_pk;
             pre_reduce = false;
             continue;
@@ -1233,6 +1245,7 @@ int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t ro
             cp.pre_reduce = pre_reduce ? 1 : 0;
             cp.dpb = fold_dpb(S, n_src);
             cp.lazy_out = lazy_ok(6 * s.ell) ? 1 : 0;  // fold_mac sums 2 * m2 = 6 ell products per accumulator
+            cp.lanes = lanes;
             launch_fold_chain(S->tb, cp, n_src, S->stream);
         } else {
             if (src_pk) lift(n_src);
@@ -1244,15 +1257,16 @@ int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t ro
             fp.bits = get_bits_per(s.ell);
             fp.ell = s.ell;
             fp.fold_np = np;
+            fp.lanes = lanes;
             launch_ntt_forward(S->tb, fp, LD_SDIGIT, ST_PK, n_src * s.ell, S->stream);
         }
-        launch_fold_mac(key, S->fold_d.p, out_pk, 2 * s.m2, np, S->stream);
+        launch_fold_mac(key, S->fold_d.p, out_pk, 2 * s.m2, np, S->stream, 0, nullptr, lanes);
         src_pk = out_pk;
         pre_reduce = false;
     }
     if (src_pk) lift(np * 6);
     // (the switch is its own launch: fused into the 6-workgroup lift it serialises 8 coefficients per thread and is slower)
-    return finish ? spiral_gpu_server_finish(S) : 0;
+    return finish ? finish_lanes(S, lanes) : 0;
 }
 }  // namespace
 
@@ -1291,7 +1305,7 @@ int spiral_gpu_server_set_expand_shard(spiral_gpu_server* S, uint32_t rank, uint
     }
     if ((n_ranks & (n_ranks - 1)) || n_ranks > S->s.dim0 || rank >= n_ranks) return fail("expansion shard %u of %u: the rank count must be a power of two <= dim0", rank, n_ranks);
     if (S->p.direct_upload || S->s.stopround == 0) return fail("sharded expansion needs query compression with stopround > 0");
-    if (S->overlap >= 2) return fail("sharded expansion and the split overlap schedules exclude each other");
+    if (S->overlap) return fail("sharded expansion and the split overlap schedule exclude each other");
     const uint32_t per = S->s.dim0 / n_ranks;
     if (S->j0 != rank * per || S->j1 != (rank + 1) * per) return fail("sharded expansion: this server must hold first-dimension block %u of %u, it holds [%u, %u)", rank, n_ranks, S->j0, S->j1);
     S->ex_shard = ExpandShard{rank, ceil_log2(n_ranks), S->p.nu1 - ceil_log2(n_ranks)};
@@ -1321,9 +1335,7 @@ int spiral_gpu_server_gsw_bits_unpack(spiral_gpu_server* S, const void* gathered
 int spiral_gpu_server_finish(spiral_gpu_server* S) {
     if (!S) return fail("null server");
     HIP_OK(hipSetDevice(S->device));
-    // row 0 -> q', rows 1.. -> 4*p_db (src/spiral.cpp:1441-1447)
-    launch_rescale2(S->raw.p, S->resp.p, 2 * kN, 6 * kN, kQ, S->s.qprime, 4 * S->p.p_db, S->stream);
-    return 0;
+    return finish_lanes(S, Lanes{});
 }
 
 int spiral_gpu_server_sync(spiral_gpu_server* S) {
@@ -1377,6 +1389,7 @@ int run_group(spiral_gpu_server* S, int slot, hipStream_t st, F body) {
     }
     HIP_OK(hipGraphLaunch(S->graph[slot], st));
     if (slot == 0 || slot == 4 || slot == 7 || slot == 9 || slot == 10 || slot == 12) S->have_records = true;  // the groups that hold ScalToMat
+    if (slot == 4 || slot == 7 || slot == 9 || slot == 10) S->raw_from_acc = false;  // the groups that hold the sweep: a replay overwrites the accumulators (the eager calls clear it themselves)
     return 0;
 }
 }  // namespace
@@ -1388,55 +1401,28 @@ int spiral_gpu_server_run_pre(spiral_gpu_server* S) {
     HIP_OK(hipSetDevice(S->device));
     if (!S->have_query || !S->have_pp) return fail("query and public parameters must be set first");
     if (!S->overlap) return run_group(S, 0, S->stream, [&]() { return expand_convert(S); });
-    if (S->overlap >= 2) {
-        // split: [odd tree of the expansion + Regev->GSW + fold keys] on the side stream, [even tree + ScalToMat] on the main stream; the fold
-        // joins the side stream.  Mode 2 forks HERE (the side depends on the query only: it runs beside the even tree); mode 3 forks after the
-        // main group, so that the side runs UNDER the sweep (whose 16-wave workgroups of 65 VGPRs leave room for three transform workgroups per CU)
-        if (srv_join_side(S)) return -1;
-        const spiral_gpu_params& p = S->p;
-        if (S->overlap == 3) {
-            if (run_group(S, 0, S->stream, [&]() {
-                    ExpandWork wk{S->ex_raw.p, S->ex_g.p};
-                    run_expand(S->tb, S->cv.p, S->s.g, p.t_exp, S->w_left.p, p.t_exp_right, S->w_right.p, S->s.ell * p.nu2, S->s.stopround, wk, S->stream, S->query.p, 0,
-                               0xffffffffu, ExpandShard{}, 1u);
-                    return convert_scal2mat(S, S->stream);
-                }))
-                return -1;
-        }
-        HIP_OK(hipEventRecord(S->ev_fork, S->stream));  // the previous query's fold has read its keys; the new query is uploaded
-        HIP_OK(hipStreamWaitEvent(S->side_stream, S->ev_fork, 0));
-        auto half = [&](uint32_t parity, hipStream_t st, uint64_t* raw, uint64_t* g) {
-            ExpandWork wk{raw, g};
-            run_expand(S->tb, S->cv.p, S->s.g, p.t_exp, S->w_left.p, p.t_exp_right, S->w_right.p, S->s.ell * p.nu2, S->s.stopround, wk, st, S->query.p, 0, 0xffffffffu,
-                       ExpandShard{}, parity);
-        };
-        if (run_group(S, 3, S->side_stream, [&]() {
-                half(2u, S->side_stream, S->ex_raw2.p, S->ex_g2.p);
-                return convert_gsw(S, S->side_stream);
-            }))
-            return -1;
-        HIP_OK(hipEventRecord(S->ev_join, S->side_stream));
-        S->side_pending = true;
-        if (S->overlap == 3) return 0;
-        return run_group(S, 0, S->stream, [&]() {
-            half(1u, S->stream, S->ex_raw.p, S->ex_g.p);
-            return convert_scal2mat(S, S->stream);
-        });
-    }
-    // overlap mode: expansion + ScalToMat on the main stream (the sweep needs only these); the Regev->GSW conversion
-    // is forked onto the side stream and joined by the fold
+    // split: [odd tree of the expansion + Regev->GSW + fold keys] on the side stream, [even tree + ScalToMat] on the main stream, forked
+    // HERE (the side depends on the query only: it runs beside the even tree); the fold joins the side stream
     if (srv_join_side(S)) return -1;
-    if (run_group(S, 0, S->stream, [&]() {
-            if (spiral_gpu_server_expand(S)) return -1;
-            return convert_scal2mat(S, S->stream);
+    const spiral_gpu_params& p = S->p;
+    HIP_OK(hipEventRecord(S->ev_fork, S->stream));  // the previous query's fold has read its keys; the new query is uploaded
+    HIP_OK(hipStreamWaitEvent(S->side_stream, S->ev_fork, 0));
+    auto half = [&](uint32_t parity, hipStream_t st, uint64_t* raw, uint64_t* g) {
+        ExpandWork wk{raw, g};
+        run_expand(S->tb, S->cv.p, S->s.g, p.t_exp, S->w_left.p, p.t_exp_right, S->w_right.p, S->s.ell * p.nu2, S->s.stopround, wk, st, S->query.p, 0, 0xffffffffu,
+                   ExpandShard{}, parity);
+    };
+    if (run_group(S, 3, S->side_stream, [&]() {
+            half(2u, S->side_stream, S->ex_raw2.p, S->ex_g2.p);
+            return convert_gsw(S, S->side_stream);
         }))
         return -1;
-    HIP_OK(hipEventRecord(S->ev_fork, S->stream));
-    HIP_OK(hipStreamWaitEvent(S->side_stream, S->ev_fork, 0));
-    if (run_group(S, 3, S->side_stream, [&]() { return convert_gsw(S, S->side_stream); })) return -1;
     HIP_OK(hipEventRecord(S->ev_join, S->side_stream));
     S->side_pending = true;
-    return 0;
+    return run_group(S, 0, S->stream, [&]() {
+        half(1u, S->stream, S->ex_raw.p, S->ex_g.p);
+        return convert_scal2mat(S, S->stream);
+    });
 }
 
 int spiral_gpu_server_run_query(spiral_gpu_server* S) {
@@ -1444,7 +1430,7 @@ int spiral_gpu_server_run_query(spiral_gpu_server* S) {
     HIP_OK(hipSetDevice(S->device));
     if (!S->have_query || !S->have_pp) return fail("query and public parameters must be set first");
     if (!S->have_db) return fail("no database loaded");
-    if (S->overlap >= 2) {  // the split schedules are three launch groups on two streams, not one graph
+    if (S->overlap) {  // the split schedule is three launch groups on two streams, not one graph
         if (spiral_gpu_server_run_pre(S)) return -1;
         if (spiral_gpu_server_first_dim(S)) return -1;
         return spiral_gpu_server_run_post(S, 0);
@@ -1455,6 +1441,93 @@ int spiral_gpu_server_run_query(spiral_gpu_server* S) {
         if (spiral_gpu_server_first_dim(S)) return -1;
         return run_fold_rounds(S, S->s.num_per, 0, S->p.nu2, S->acc, false, true);
     });
+}
+
+// B <= kMaxLanes whole queries -- one per server: an owner and its lanes (create_lane), all with the same parameters, each with its own
+// client's keys and query -- as ONE launch sequence: every launch of expansion, conversion, lift, folding and the switch carries all B queries
+// (gridDim.z = B, kernels.h Lanes), and the sweep makes one pass over the database for all of them (sweep_kernel<0, B>).  The reference
+// answers one query per process_crtd_query (src/spiral.cpp:2337-2406); this is throughput, not latency: a query's ~50 launch-bound launches
+// cost the same ~5 us whether they carry one query or four.  Every lane's buffers end up exactly as after its own run_query.
+// The sequence runs on servers[0]'s stream (captured once per lane set into a hipGraph when servers[0] has use_graphs on); the other
+// lanes' streams are ordered before and after it with events, as in first_dim_batch.
+int spiral_gpu_server_run_query_batch(spiral_gpu_server* const* servers, uint32_t n) {
+    if (!servers || n == 0) return fail("no servers");
+    for (uint32_t b = 0; b < n; b++)
+        if (!servers[b]) return fail("null server");
+    spiral_gpu_server* S = servers[0];
+    if (n == 1) return spiral_gpu_server_run_query(S);
+    if (n > kMaxLanes) return fail("at most %u queries per batch", kMaxLanes);
+    HIP_OK(hipSetDevice(S->device));
+    Lanes lanes;
+    lanes.n = n;
+    for (uint32_t b = 0; b < n; b++) {  // every lane is validated before anything is launched
+        spiral_gpu_server* L = servers[b];
+        if (!L->have_query || !L->have_pp) return fail("run_query_batch: server %u needs its query and public parameters set first", b);
+        if (!L->have_db) return fail("run_query_batch: server %u has no database", b);
+        if (memcmp(&L->p, &S->p, sizeof(S->p)) != 0 || L->device != S->device || L->j0 != S->j0 || L->dim0_shard != S->dim0_shard || L->arena.words != S->arena.words)
+            return fail("run_query_batch: server %u differs from server 0 in parameters, device or shard", b);
+        if (L->db.p != S->db.p) return fail("run_query_batch: server %u does not sweep server 0's database image (create_lane / share_db)", b);
+        if (L->acc != L->acc_own.p || L->keep_cts || L->overlap || L->fold_g_log || L->sweep_k_log || L->ex_shard.g_log || L->side_pending || L->fold_pair != S->fold_pair ||
+            L->fold_chain != S->fold_chain)
+            return fail("run_query_batch: server %u has an external accumulator, keep_cts, a split / sharded / staged schedule or other fold options set", b);
+        for (uint32_t c = 0; c < b; c++)
+            if (servers[c] == L) return fail("run_query_batch: server %u listed twice", b);
+        lanes.off[b] = L->arena.p - S->arena.p;
+    }
+    for (uint32_t b = 1; b < n; b++) {  // the lanes' uploads (and whatever else their streams still hold) come first
+        HIP_OK(hipEventRecord(servers[b]->ev_batch, servers[b]->stream));
+        HIP_OK(hipStreamWaitEvent(S->stream, servers[b]->ev_batch, 0));
+    }
+    auto body = [&]() {
+        if (expand_lanes(S, lanes)) return -1;
+        if (convert_part(S, CONV_BOTH, S->stream, false, lanes)) return -1;
+        if (sweep_batch_ok(S->s.num_per, 2 * S->dim0_shard)) {
+            const uint32_t* qs[kMaxLanes];
+            uint64_t* acc[kMaxLanes];
+            for (uint32_t b = 0; b < n; b++) {
+                qs[b] = (const uint32_t*)(S->qs.p + lanes.off[b]);
+                acc[b] = S->acc + lanes.off[b];
+            }
+            launch_sweep_batch(S->db.p, qs, acc, n, S->s.num_per, 2 * S->dim0_shard, 0, S->stream);
+        } else {  // geometries the batched kernel does not cover (fewer than 64 output columns, tiny first dimensions): one sweep per lane
+            for (uint32_t b = 0; b < n; b++)
+                launch_sweep(S->db.p, (const uint32_t*)(S->qs.p + lanes.off[b]), S->acc + lanes.off[b], S->s.num_per, 2 * S->dim0_shard, 0, S->stream);
+        }
+        return run_fold_rounds(S, S->s.num_per, 0, S->p.nu2, S->acc, false, true, nullptr, lanes);
+    };
+    int rc = 0;
+    if (!S->use_graphs) {
+        rc = body();
+    } else {
+        bool same = S->graph_batch && S->batch_n == n;
+        for (uint32_t b = 0; same && b < n; b++) same = S->batch_key[b] == servers[b]->arena.p;
+        if (!same) {
+            if (S->graph_batch) (void)hipGraphExecDestroy(S->graph_batch);
+            S->graph_batch = nullptr;
+            HIP_OK(hipStreamBeginCapture(S->stream, hipStreamCaptureModeRelaxed));
+            rc = body();
+            hipGraph_t g = nullptr;
+            const hipError_t e = hipStreamEndCapture(S->stream, &g);
+            if (rc || e != hipSuccess) {
+                if (g) (void)hipGraphDestroy(g);
+                return rc ? rc : fail("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+            }
+            const hipError_t e2 = hipGraphInstantiate(&S->graph_batch, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e2 != hipSuccess) return fail("hipGraphInstantiate failed: %s", hipGetErrorString(e2));
+            S->batch_n = n;
+            for (uint32_t b = 0; b < n; b++) S->batch_key[b] = servers[b]->arena.p;
+        }
+        HIP_OK(hipGraphLaunch(S->graph_batch, S->stream));
+    }
+    if (rc) return rc;
+    for (uint32_t b = 0; b < n; b++) {
+        servers[b]->have_records = true;
+        servers[b]->raw_from_acc = false;
+    }
+    HIP_OK(hipEventRecord(S->ev_batch, S->stream));
+    for (uint32_t b = 1; b < n; b++) HIP_OK(hipStreamWaitEvent(servers[b]->stream, S->ev_batch, 0));
+    return 0;
 }
 
 // The two halves of a distributed fold.  With use_graphs on they replay as hipGraphs too; the buffers the caller hands
@@ -1757,6 +1830,7 @@ int spiral_gpu_server_time_sweep(spiral_gpu_server* S, int iters, float* avg_ms)
     HIP_OK(hipSetDevice(S->device));
     HIP_OK(hipEventRecord(S->ev[0], S->stream));
     for (int i = 0; i < iters; i++) launch_sweep(S->db.p, (const uint32_t*)S->qs.p, S->acc, S->s.num_per, 2 * S->dim0_shard, S->fold_g_log, S->stream, S->sweep_k_log);
+    S->raw_from_acc = false;
     HIP_OK(hipEventRecord(S->ev[1], S->stream));
     HIP_OK(hipStreamSynchronize(S->stream));
     float ms = 0;

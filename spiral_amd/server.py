@@ -25,6 +25,12 @@ def first_dim_batch(servers):
     check(lib().spiral_gpu_server_first_dim_batch(arr, len(servers)))
 
 
+def run_query_batch(servers):
+    """the whole answer for the queries of up to four servers sharing one image, every launch carrying all of them; see include/spiral_gpu.h"""
+    arr = (C.c_void_p * len(servers))(*[s.h for s in servers])
+    check(lib().spiral_gpu_server_run_query_batch(arr, len(servers)))
+
+
 class Server:
     def __init__(self, params: Params, device: int = 0, j_begin: int = 0, j_end: int = 0, share_db_of: "Server | None" = None):
         """share_db_of: make this server a query lane of that one -- same parameters, device and shard, sweeping ITS database
@@ -125,10 +131,9 @@ class Server:
     def use_graphs(self, on: bool = True):
         check(lib().spiral_gpu_server_use_graphs(self.h, 1 if on else 0))
 
-    def set_overlap(self, on=True):
-        """1 / True: run the Regev->GSW conversion on a side stream under the sweep; 2: the split schedule -- the whole GSW side of the query (the
-        odd tree of the expansion + the conversion) as its own launch sequence on the side stream beside the even tree + ScalToMat + sweep
-        (same results, different schedule)"""
+    def set_overlap(self, on=2):
+        """0: one stream; 2: the split schedule -- the whole GSW side of the query (the odd tree of the expansion + the conversion) as its own
+        launch sequence on the side stream beside the even tree + ScalToMat + sweep (same results, different schedule)"""
         check(lib().spiral_gpu_server_set_overlap(self.h, int(on)))
 
     def run_pre(self):

@@ -306,29 +306,25 @@ def test_load_db_in_several_staging_passes(sa, oracle, monkeypatch):
     srv.close()
 
 
-@pytest.mark.parametrize("env", [
-    {"SPIRAL_FOLD_CHAIN": "0"},          # separate lift + digit transforms every round
-    {"SPIRAL_FOLD_BLOCKS": "0"},         # pair form (fold_pair_kernel), one block per polynomial pair (all digits) every round
-    {"SPIRAL_FOLD_BLOCKS": "1000000"},   # one block per (polynomial pair, digit) every round
-    {"SPIRAL_FOLD_BLOCKS": "300"},       # mixed chunk sizes
-    {"SPIRAL_FOLD_UNCHAIN_MIN": "48"},                          # pair form, wide rounds unchained (the default is every round), narrow ones as 512-thread teams
-    {"SPIRAL_FOLD_UNCHAIN_MIN": "1000000"},                     # pair form, every round chained (fold_team_kernel)
-    {"SPIRAL_FOLD_UNCHAIN_MIN": "1000000", "SPIRAL_FOLD_BLOCKS": "0"},
-    {"SPIRAL_FOLD_UNCHAIN_MIN": "1000000", "SPIRAL_FOLD_BLOCKS": "1000000"},
-    {"SPIRAL_FOLD_TEAM": "0"},                                  # pair form, one 256-thread workgroup per pair (fold_pair_kernel)
-    {"SPIRAL_FOLD_TEAM": "0", "SPIRAL_FOLD_BLOCKS": "0"},
-    {"SPIRAL_FOLD_TEAM": "0", "SPIRAL_FOLD_BLOCKS": "1000000"},
-    {"SPIRAL_FOLD_PAIR": "0"},                                  # the reference's two-product form Q_neg G^-1(L) + Q G^-1(H) (fold_chain_kernel)
-    {"SPIRAL_FOLD_PAIR": "0", "SPIRAL_FOLD_BLOCKS": "0"},
-    {"SPIRAL_FOLD_PAIR": "0", "SPIRAL_FOLD_BLOCKS": "1000000"},
-    {"SPIRAL_FOLD_PAIR": "0", "SPIRAL_FOLD_BLOCKS": "300"},
+@pytest.mark.parametrize("env,t_gsw", [
+    ({}, 8),                                    # default: pair form, unchained (lift launch + LD_SDIFF launch + product with addend)
+    ({"SPIRAL_FOLD_PAIR": "0"}, 8),             # the reference's two-product form Q_neg G^-1(L) + Q G^-1(H), lift chained (fold_chain_kernel)
+    ({"SPIRAL_FOLD_PAIR": "0", "SPIRAL_FOLD_BLOCKS": "0"}, 8),        # one block per polynomial (all digits)
+    ({"SPIRAL_FOLD_PAIR": "0", "SPIRAL_FOLD_BLOCKS": "1000000"}, 8),  # one block per (polynomial, digit)
+    ({"SPIRAL_FOLD_PAIR": "0", "SPIRAL_FOLD_BLOCKS": "300"}, 8),      # mixed chunk sizes
+    ({"SPIRAL_FOLD_CHAIN": "0"}, 8),            # two-product form as separate lift + LD_SDIGIT launches
+    ({}, 14),                                   # NO environment: ell = 14 has (ell - 1) * bits = 65 >= 64, fold_pair_exact(14) is false, so the server
+    ({}, 17),                                   # itself falls back to the two-product form (kernels.h fold_pair_exact); likewise ell = 17
+    ({"SPIRAL_FWD2": "1"}, 8),                  # every digit launch through the two-digits-per-workgroup kernel (default only from 8192 transforms)
+    ({"SPIRAL_FWD2": "0"}, 8),
 ])
-def test_fold_chain_schedules(sa, oracle, env, monkeypatch):
-    """the fold's schedule variants (read from the environment when the server is created) all give the oracle's answer"""
+def test_fold_chain_schedules(sa, oracle, env, t_gsw, monkeypatch):
+    """the fold's forms (read from the environment when the server is created, or chosen by the server from the gadget dimension) and the two
+    digit-transform kernels all give the oracle's answer"""
     O = oracle
     for k, val in env.items():
         monkeypatch.setenv(k, val)
-    kw = dict(t_gsw=8)  # (t_gsw = 4 is bit-exact too but too noisy to decode at nu2 = 6)
+    kw = dict(t_gsw=t_gsw)  # (t_gsw = 4 is bit-exact too but too noisy to decode at nu2 = 6)
     po, pg = O.make_params(3, 6, **kw), sa.make_params(3, 6, **kw)
     cl = O.Client(po, seed=17)
     wl, wr, w, v = cl.pub_params()
@@ -350,10 +346,10 @@ def test_fold_chain_schedules(sa, oracle, env, monkeypatch):
     srv.close()
 
 
-@pytest.mark.parametrize("graphs,overlap", [(True, False), (True, True), (False, True), (True, 2), (False, 2), (True, 3)])
+@pytest.mark.parametrize("graphs,overlap", [(True, 0), (False, 0), (True, 2), (False, 2)])
 def test_graph_replay_matches_eager(sa, oracle, graphs, overlap):
-    """run_pre / run_post captured into hipGraphs and replayed for several queries == the eager stages; in overlap
-    mode the Regev->GSW conversion runs on the side stream under the sweep and the fold joins it"""
+    """run_pre / run_post captured into hipGraphs and replayed for several queries == the eager stages; with the split schedule
+    (overlap 2) the GSW side of the query runs on the side stream and the fold joins it"""
     O = oracle
     from spiral_amd import server as SV
 
@@ -622,6 +618,85 @@ def test_batched_sweep_equals_single_sweeps(sa, oracle, nu1, nu2, n):
         assert_eq(lane.read(SV.BUF_FINAL), O.answer(po, q, pp[0], pp[1], pp[2], pp[3], db), "a lane answers after its owner was closed")
     for srv in lanes[1:]:
         srv.close()
+
+
+@pytest.mark.parametrize("nu1,nu2,n,kw,graphs", [
+    (3, 6, 2, dict(t_gsw=8), True), (3, 6, 4, dict(t_gsw=8), True), (5, 6, 2, dict(t_gsw=8), False), (5, 6, 4, dict(t_gsw=8), True),
+    (5, 3, 3, dict(t_gsw=4), True),                                                       # fewer than 64 output columns: one sweep per lane inside the sequence
+    (2, 2, 4, dict(t_gsw=5, t_exp=2, qprime_bits=19, direct_upload=1), True),             # no expansion (SpiralStream form), plain database layout
+    (4, 5, 3, dict(t_gsw=14), True),                                                      # a gadget whose digits do not recompose: the two-product fold (fold_chain_kernel) with lanes
+    (2, 1, 2, {}, False),                                                                  # stopround == 0
+])
+def test_run_query_batch_equals_single_queries(sa, oracle, nu1, nu2, n, kw, graphs):
+    """run_query_batch: n whole queries (different clients: own keys, own query) in one launch sequence whose every launch carries all of them
+    (gridDim.z = n; the reference answers one per process_crtd_query, src/spiral.cpp:2337-2406).  Every lane's expanded ciphertexts, GSW
+    matrices, accumulators, final ciphertext and response equal the oracle's for ITS inputs, and the lane's own run_query reproduces them."""
+    O = oracle
+    from spiral_amd import server as SV
+
+    po, pg = O.make_params(nu1, nu2, **kw), sa.make_params(nu1, nu2, **kw)
+    s = O.shape_of(po)
+    db = O.gen_db(po, 77)
+    owner = sa.Server(pg)
+    owner.gen_db(77)
+    lanes = [owner] + [sa.Server(pg, share_db_of=owner) for _ in range(n - 1)]
+    clients = [O.Client(po, seed=70 + b) for b in range(n)]
+    pps = [cl.pub_params() for cl in clients]
+    for srv, pp in zip(lanes, pps):
+        srv.set_pub_params(*pp)
+        srv.use_graphs(graphs)
+    total = s.dim0 * s.num_per
+    decodes = kw.get("t_gsw", 8) >= 8 or nu2 <= 3  # (small gadgets are bit-exact too but too noisy to decode at large nu2)
+    for rnd in range(3):  # round 0 captures the graph, 1 and 2 replay it on new queries
+        idxs = [(29 * rnd + 11 * b + 3) % total for b in range(n)]
+        qs = [cl.query(i) for cl, i in zip(clients, idxs)]
+        for srv, q in zip(lanes, qs):
+            srv.set_query(q)
+        sa.run_query_batch(lanes)
+        for srv in lanes:
+            srv.sync()
+        for b, (srv, cl, pp, q, idx) in enumerate(zip(lanes, clients, pps, qs, idxs)):
+            what = f"round {rnd} lane {b} of {n}"
+            cv = O.stage_expand(po, q, pp[0], pp[1])
+            assert_eq(srv.read(SV.BUF_EXPANDED), cv, f"{what}: expanded ciphertexts")
+            cts, gsw = O.stage_convert(po, cv, pp[2], pp[3])
+            assert_eq(srv.read(SV.BUF_GSW), gsw, f"{what}: regevToGSW outputs")
+            want_acc = O.multiply_query_by_database(O.reorient_ciphertexts(cts), db, s.dim0, s.num_per)
+            assert_eq(srv.read(SV.BUF_ACC), want_acc, f"{what}: accumulators")
+            fin = O.stage_fold(po, O.from_ntt(want_acc), gsw)
+            assert_eq(srv.read(SV.BUF_FINAL), fin, f"{what}: final ciphertext")
+            resp = srv.read(SV.BUF_RESPONSE)
+            assert_eq(resp, O.stage_rescale(po, fin), f"{what}: response")
+            if decodes:
+                assert_eq(cl.decode(resp), O.db_item(po, 77, idx), f"{what}: decoded plaintext")
+    # the lanes stay ordinary servers: a lane's own run_query after a batch gives the same answer again
+    last = [(srv.read(SV.BUF_FINAL).copy(), srv.read(SV.BUF_RESPONSE).copy()) for srv in lanes]
+    for srv, (fin, resp) in zip(lanes, last):
+        srv.run_query()
+        srv.sync()
+        assert_eq(srv.read(SV.BUF_FINAL), fin, "single run_query after the batch: final ciphertext")
+        assert_eq(srv.read(SV.BUF_RESPONSE), resp, "single run_query after the batch: response")
+    # a different lane set re-captures; a sub-batch answers the same
+    if n >= 3:
+        sa.run_query_batch(lanes[1:])
+        for srv, (fin, resp) in zip(lanes[1:], last[1:]):
+            srv.sync()
+            assert_eq(srv.read(SV.BUF_FINAL), fin, "sub-batch led by another lane: final ciphertext")
+    with pytest.raises(RuntimeError, match="listed twice"):
+        sa.run_query_batch([lanes[0], lanes[0]])
+    other = sa.Server(pg)
+    other.gen_db(77)  # same contents, another image
+    other.set_pub_params(*pps[0])
+    other.set_query(clients[0].query(0))
+    with pytest.raises(RuntimeError, match="database image"):
+        sa.run_query_batch([lanes[0], other])
+    other.close()
+    lanes[-1].keep_cts(True)
+    with pytest.raises(RuntimeError, match="keep_cts"):
+        sa.run_query_batch(lanes)
+    for srv in lanes[1:]:
+        srv.close()
+    owner.close()
 
 
 def test_sharded_first_dim_sums_to_unsharded(sa, oracle):
