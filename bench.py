@@ -42,6 +42,85 @@ def synth_residues(rng, np, shape):
     return np.stack([rng.integers(0, m, size=shape + (sa.N,), dtype=np.uint64) for m in (sa.P, sa.B)], axis=-2)
 
 
+def synth_inputs(np, sa, pg, shp):
+    """the benchmark's synthetic public parameters and query: uniform canonical residues from default_rng(1), the same on every rank
+    (tests/test_gpu_fullsize.py rebuilds exactly these to put the oracle's answer next to the timed graph's)"""
+    rng = np.random.default_rng(1)
+    pub = (synth_residues(rng, np, (max(shp.n_left, 1), 2, pg.t_exp)), synth_residues(rng, np, (max(shp.n_right, 1), 2, pg.t_exp_right)),
+           synth_residues(rng, np, (3, 2 * pg.t_conv)), synth_residues(rng, np, (3, 2 * pg.t_conv)))
+    query = synth_residues(rng, np, (shp.n_query_cts, 2))
+    return pub, query
+
+
+DB_SEED = 1234  # the explicit database every leg generates on the device (gen_db)
+
+
+def answer_hash(np, final_ct, response):
+    """sha256 over the folded ciphertext (3 x 2 x 2048 u64, little endian) followed by the switched response: what `answer_sha256` in the
+    line is, and what the full-size GPU test computes from the oracle's answer on the same inputs"""
+    import hashlib
+
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(final_ct, dtype="<u8").tobytes())
+    h.update(np.ascontiguousarray(response, dtype="<u8").tobytes())
+    return h.hexdigest()
+
+
+class Progress:
+    """The line-so-far and a watchdog.  The first multi-GPU run may be the only one: after every schedule and every leg the line as it
+    stands (same keys, "partial": true) goes to stderr and to bench_partial.json, and a watchdog thread per phase turns a hang (an RCCL
+    collective that never completes, say) into that line on stdout and a non-zero exit instead of a lost run.  No process is re-exec'd."""
+
+    def __init__(self, rank, seconds):
+        import threading
+
+        self.rank, self.seconds = rank, seconds
+        self.line, self.where, self.deadline = None, "set-up", None
+        self.lock = threading.Lock()
+        self.wrap = lambda line: line  # the secondary leg nests its line under the primary's `also`
+        t = threading.Thread(target=self._watch, daemon=True)
+        t.start()
+
+    def arm(self, where, factor=1.0):
+        with self.lock:
+            self.where, self.deadline = where, (time.monotonic() + self.seconds * factor) if self.seconds > 0 else None
+
+    def disarm(self):
+        with self.lock:
+            self.deadline = None
+
+    def update(self, line):
+        """record the line-so-far; rank 0 also writes it to stderr and to bench_partial.json (cwd), marked partial"""
+        line = dict(self.wrap(line), partial=True)
+        with self.lock:
+            self.line = line
+        if self.rank == 0:
+            txt = json.dumps(line)
+            print("bench.py partial: " + txt, file=sys.stderr, flush=True)
+            try:
+                with open(os.environ.get("SPIRAL_BENCH_PARTIAL", "bench_partial.json"), "w") as f:
+                    f.write(txt + "\n")
+            except OSError:
+                pass
+
+    def _watch(self):
+        while True:
+            time.sleep(0.25)
+            with self.lock:
+                late = self.deadline is not None and time.monotonic() > self.deadline
+                line, where = self.line, self.where
+            if late:
+                if self.rank == 0:
+                    out = dict(line or {"metric": "server ms/query + DB GB/s vs HBM roofline", "value": None}, partial=True, hung_in=where,
+                               watchdog_s=self.seconds)
+                    sys.stdout.write(json.dumps(out) + "\n")
+                    sys.stdout.flush()
+                else:
+                    time.sleep(10)  # rank 0 goes first: the launcher tears every rank down as soon as one exits
+                print(f"bench.py: rank {self.rank} made no progress in '{where}' for {self.seconds} s; giving up (exit 3)", file=sys.stderr, flush=True)
+                os._exit(3)  # the main thread is stuck in a collective or a synchronize: no clean way out
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -290,6 +369,8 @@ def parse_args(argv=None):
     ap.add_argument("--nu1", type=int, default=None, help="override the workload's first-dimension size (tuning)")
     ap.add_argument("--nu2", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--watchdog", type=float, default=float(os.environ.get("SPIRAL_BENCH_WATCHDOG_S", "120")), help="seconds a schedule / phase may take before the line-so-far "
+                    "is printed (partial: true, hung_in) and the process exits 3; 0 = off")
     ap.add_argument("--prewarm", type=int, default=40, help="untimed queries run as part of the set-up before the W warm-up steps, to ramp the GPU's clocks (0 = none)")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     ap.add_argument("--overlap", type=int, default=0, choices=[0, 2], help="2: the split schedule -- the odd tree of the expansion and the Regev->GSW "
@@ -393,13 +474,14 @@ class Ctx:
             self.dist.destroy_process_group()
 
 
-def bench_base(args, ctx, workload, steps, warmup, primary):
+def bench_base(args, ctx, workload, steps, warmup, primary, prog):
     """one leg: `steps` timed queries of `workload` through the base server on ctx.world ranks.  primary: the headline leg, which
-    also carries the throughput leg, the transform roofline and the reference-bucket detail."""
+    also carries the throughput leg, the transform roofline and the reference-bucket detail.  prog: the line-so-far + watchdog."""
     import numpy as np
 
     import spiral_amd as sa
     from spiral_amd import dist as sdist
+    from spiral_amd import server as SV
 
     torch, dist = ctx.torch, ctx.dist
     world, rank, local_rank, dev, use_dist = ctx.world, ctx.rank, ctx.local_rank, ctx.dev, ctx.use_dist
@@ -414,15 +496,13 @@ def bench_base(args, ctx, workload, steps, warmup, primary):
     shp = sa.get_shape(pg)
     j0, j1 = sdist.shard_range(rank, world, shp.dim0)
 
+    prog.arm(f"{workload}/set-up", 3.0)
     srv = sa.Server(pg, local_rank, j0, j1)
     stream = torch.cuda.Stream(device=dev)  # a real (capturable) stream shared by the library and RCCL
     srv.set_stream(stream.cuda_stream)
-    srv.gen_db(1234)  # explicit database generated on the device, this rank's j-shard
-    rng = np.random.default_rng(1)  # same synthetic inputs on every rank
-    pub = (synth_residues(rng, np, (max(shp.n_left, 1), 2, pg.t_exp)), synth_residues(rng, np, (max(shp.n_right, 1), 2, pg.t_exp_right)),
-           synth_residues(rng, np, (3, 2 * pg.t_conv)), synth_residues(rng, np, (3, 2 * pg.t_conv)))
+    srv.gen_db(DB_SEED)  # explicit database generated on the device, this rank's j-shard
+    pub, query = synth_inputs(np, sa, pg, shp)  # same synthetic inputs on every rank
     srv.set_pub_params(*pub)
-    query = synth_residues(rng, np, (shp.n_query_cts, 2))
     srv.set_query(query)
     acc = torch.zeros(shp.num_per * 6 * sa.N, dtype=torch.int64, device=dev)
     srv.set_acc(acc.data_ptr())
@@ -447,6 +527,7 @@ def bench_base(args, ctx, workload, steps, warmup, primary):
     can_overlap = shard_expand and sharded_fold
     n_stages = min(max(1, args.sweep_stages), srv.max_sweep_stages()) if can_overlap else 1
     while n_stages & (n_stages - 1): n_stages -= 1
+    # the schedules are timed safest first (in-order, comm-overlap, pipelined): a failure in a later one leaves the earlier numbers in the line
     if not can_overlap:
         schedules = ["in-order"]
     elif args.schedule in ("all", "both"):  # at world size 1 there is nothing to hide: the comparison is for real multi-rank runs (and the self-tests)
@@ -468,10 +549,17 @@ def bench_base(args, ctx, workload, steps, warmup, primary):
 
     whole = world == 1 and not use_dist and not args.no_graphs and not args.overlap and args.event_every > 1
 
+    cur_stages = [1]
+
     def configure(sch):
-        # the pipelined schedule lays the accumulators out [stage][rank][ct]; the others need the single-stage layout (one reduce-scatter)
-        if can_overlap and n_stages > 1:
-            srv.set_sweep_stages(n_stages if sch == "pipelined" else 1)
+        # the pipelined schedule lays the accumulators out [stage][rank][ct]; the others need the single-stage layout (one reduce-scatter).
+        # (changing the layout drops the captured graphs, so it is only touched when the stage count really changes)
+        want = n_stages if sch == "pipelined" else 1
+        if can_overlap and n_stages > 1 and want != cur_stages[0]:
+            srv.set_sweep_stages(want)
+            cur_stages[0] = want
+
+    inject_hang = os.environ.get("SPIRAL_BENCH_INJECT_HANG", "")  # test hook: the named schedule (or "<workload>/<schedule>") never returns
 
     def step(e=None, overlap_comm=False, staged=False):
         # one query: [expand, convert] -> sweep -> [reduce over ranks] -> [lift, fold, response switch]
@@ -548,33 +636,126 @@ def bench_base(args, ctx, workload, steps, warmup, primary):
                 srv.run_post(reduce_first=use_dist)
         if e: e[3].record(stream)
 
-    timed = {}
+    def timed_loop(sch, evs):
+        """W warm-up steps, then exactly `steps` timed steps between two fences; ms per step, max over ranks.  evs: the events of the sampled steps"""
+        ov, st = sch == "comm-overlap", sch == "pipelined"
+        for i in range(warmup):
+            step(None, ov, st)
+        ctx.fence()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            # the stage events belong to the in-order flavour (with the others the stages interleave); every schedule still runs exactly `steps` steps
+            step(evs[k] if (evs and k in sampled) else None, ov, st)
+        ctx.fence()
+        return ctx.max_over_ranks(time.perf_counter() - t0) * 1e3 / steps
+
+    timed, hashes, no_prewarm, ev_done = {}, {}, None, [False]
+    names = ["expand_convert", "sweep", "reduce_lift_fold_switch"]  # the last bucket includes the collective(s)
+
+    def make_out(extra=None):
+        """the JSON line from what has been measured so far (called after every schedule, and at the end with everything else)"""
+        # N > 1: the headline is ONE fixed schedule (comm-overlap where it applies), not the best of several -- a minimum over noisy
+        # timings is biased low and would not compare like with like between rounds; the others are reported beside it in `schedules`
+        fastest = min(timed, key=timed.get)
+        best = "comm-overlap" if "comm-overlap" in timed else ("in-order" if "in-order" in timed else fastest)
+        ms_per_step = timed[best]
+        have_ev = ev_done[0] and bool(sampled)  # the stage events have been recorded (an in-order pass ran)
+        stages = {n: sum(ev[k][i].elapsed_time(ev[k][i + 1]) for k in sampled) / len(sampled) * 1e3 for i, n in enumerate(names)} if have_ev else None
+        coll = {}
+        if use_dist and have_ev:
+            pairs = ([("all_gather_gsw_bits", 4, 5)] if shard_expand else []) + ([("reduce_scatter_accumulators", 6, 7), ("all_gather_folded_cts", 8, 9)] if sharded_fold else [("reduce_accumulators", 6, 7)])
+            coll = {n: round(sum(ev[k][a].elapsed_time(ev[k][b]) for k in sampled) / len(sampled) * 1e3, 1) for n, a, b in pairs}
+        bytes_sweep = srv.sweep_bytes()
+        traffic, traffic_src = pmc_traffic(world, nu1, nu2)
+        out = {
+            "metric": "server ms/query + DB GB/s vs HBM roofline" + (", 2^20 x 256B" if workload == "config2" else f" ({workload})"),
+            "value": round(ms_per_step, 4),
+            "unit": "ms/query",
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": False,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "u32 residues, 32x32->64-bit integer MAC (two 28-bit CRT primes)",
+            "data": "synthetic",
+            "config": {"workload": label + ", explicit DB generated on device, sharded by first-dimension index",
+                       "db_bytes_ntt_form": int(shp.dim0) * int(shp.num_per) * 4 * sa.N * 8, "schedule": "split: the GSW side of the query on a side stream" if args.overlap else "in order, one stream",
+                       "parallelism": (f"j-shard x{world}, reduce-scatter + distributed fold + all-gather" if sharded_fold else f"j-shard x{world} + 1 reduce")
+                                      + (", sharded expansion + all-gather of the GSW bits" if shard_expand else "")
+                                      + (" (overlapped with ScalToMat + sweep)" if best == "comm-overlap" else "")
+                                      + (f" (sweep pipelined with its reduce-scatter in {n_stages} stages)" if best == "pipelined" else "")},
+            "queries_per_s": round(1e3 / ms_per_step, 2),
+            "prewarm_queries": args.prewarm,
+            "value_no_prewarm": no_prewarm,
+            "answer_sha256": hashes.get(best) or (next(iter(hashes.values())) if hashes else None),
+            "stages_us": {k: round(v, 1) for k, v in stages.items()} if stages else None,
+        }
+        if stages:
+            sweep_ms = stages["sweep"] / 1e3
+            achieved = bytes_sweep / (sweep_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "sweep_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                               "frac": round(achieved / HBM_PEAK_GBPS, 4), "frac_device_bytes": round(srv.sweep_device_bytes() / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(bytes_sweep),
+                               "avg_launch_ms": round(sweep_ms, 4),
+                               "device_bytes_per_launch": int(srv.sweep_device_bytes()), "achieved_device_bytes": round(srv.sweep_device_bytes() / (sweep_ms * 1e-3) / 1e9, 1),
+                               "note": "achieved / frac = SURVEY 8d algorithmic bytes (8 B per database word) / launch time measured in THIS run with HIP events on the launch stream; "
+                                       "the device keeps a word's two 28-bit residues in 7 bytes, so a launch physically moves device_bytes_per_launch: achieved_device_bytes / "
+                                       "frac_device_bytes are the HBM utilisation in physical bytes.  `traffic` is NOT measured in this run: it is the rocprofv3 PMC figure "
+                                       "(FETCH_SIZE / WRITE_SIZE passes) read from the committed file named in traffic_source, valid for configs[1] on one GPU only (null otherwise)",
+                               "launches_timed": len(sampled), "shard": f"j in [{j0},{j1}) on rank 0"}
+        if use_dist:
+            out["schedules"] = {"ms_per_query": {k: round(v, 4) for k, v in timed.items()}, "chosen": best, "fastest": fastest, "sweep_stages": n_stages if "pipelined" in timed else None,
+                                "answer_sha256": dict(hashes), "requested": list(schedules),
+                                "note": "each schedule timed over the same K steps after W warm-up steps, max over ranks, safest first (a later schedule that fails leaves the earlier ones in the line); "
+                                        "value = the `chosen` one, fixed in advance (comm-overlap where the sharded expansion and the distributed fold apply), `fastest` names the minimum; "
+                                        "answer_sha256: rank 0's answer after each schedule's last step (equal: the schedules compute the same function)"}
+            out["collectives_us"] = coll
+            out["rccl"] = ctx.rccl
+        if extra:
+            for k, v in extra.items():
+                if isinstance(v, dict) and isinstance(out.get(k), dict):
+                    out[k].update(v)
+                else:
+                    out[k] = v
+        return out
+
+    def read_answer():
+        """rank 0: sha256 of the folded ciphertext + response the last step left (the stream is idle: every caller fenced)"""
+        return answer_hash(np, srv.read(SV.BUF_FINAL), srv.read(SV.BUF_RESPONSE)) if rank == 0 else None
+
     with torch.cuda.stream(stream):
-        for sch in schedules:
+        for n_sch, sch in enumerate(schedules):
+            prog.arm(f"{workload}/{sch}")
             ov, st = sch == "comm-overlap", sch == "pipelined"
-            configure(sch)  # (changing the accumulator layout drops the captured graphs)
+            configure(sch)
             if not args.no_graphs:  # priming, not a step of the run: each step flavour once, so that no hipGraph is captured in the timed region
                 if sch == "in-order": step(new_events())
                 step(None, ov, st)
+            if inject_hang in (sch, f"{workload}/{sch}"):
+                print(f"bench.py: SPIRAL_BENCH_INJECT_HANG={inject_hang}: rank {rank} stops here", file=sys.stderr, flush=True)
+                time.sleep(10 ** 6)
+            if n_sch == 0 and args.prewarm > 0:
+                # the round-3 protocol, for comparison across rounds: W warm-up + K timed steps straight after the set-up, no clock pre-warm
+                no_prewarm = {"value": round(timed_loop(sch, {k: new_events() for k in sampled} if sch == "in-order" else None), 4), "unit": "ms/query", "schedule": sch,
+                              "note": "the same K timed steps after W warm-up steps but BEFORE the pre-warm queries (the protocol of rounds 1-3): the GPU's clocks are still ramping"}
             # clock pre-warm, part of the set-up like the priming above (reported as `prewarm_queries`): the GPU's clocks ramp over the first tens of
             # milliseconds of work after the host-side set-up, and the latency-bound stages of the first ~30 queries run 3-5 % slower than the steady
             # state this benchmark is about (profiles/r04_bench_warmup.txt); the W warm-up steps and the K timed steps follow unchanged
             for i in range(args.prewarm):
                 step(None, ov, st)
-            for i in range(warmup):
-                step(None, ov, st)
-            ctx.fence()
-            t0 = time.perf_counter()
-            for k in range(steps):
-                # the stage events belong to the in-order flavour (with the others the stages interleave); every schedule still runs exactly `steps` steps
-                step(ev[k] if (k in sampled and sch == "in-order") else None, ov, st)
-            ctx.fence()
-            timed[sch] = ctx.max_over_ranks(time.perf_counter() - t0) * 1e3 / steps
+            timed[sch] = timed_loop(sch, ev if sch == "in-order" else None)
+            if sch == "in-order": ev_done[0] = True
+            hashes[sch] = read_answer()
+            prog.update(make_out())
+        prog.arm(f"{workload}/after the timed schedules", 3.0)
         if "in-order" not in timed:  # a single other schedule was asked for: the stage split still comes from a few in-order steps, outside the timed region
             configure("in-order")
+            step(None)  # untimed, unsampled: the graphs the layout change dropped are re-captured here, not inside a sampled step
             for k in sampled:
                 step(ev[k])
             ctx.fence()
+            ev_done[0] = True
         configure("in-order")
         # throughput leg (outside the timed region, reported beside `value`, never as it): `lanes` queries in flight on one database
         # image, one server handle and one stream per lane, each replaying the whole-query graph
@@ -627,6 +808,7 @@ def bench_base(args, ctx, workload, steps, warmup, primary):
                 # whole queries batched: every launch of the answer carries the B queries of a batch (spiral_gpu_server_run_query_batch: the
                 # expansion / conversion / lift / fold launches take a query dimension, the sweep is the batched one), one hipGraph replay per batch
                 bq = {}
+                srv.set_acc(0)  # (back to the server's own accumulators: the lanes of a batch address their buffers relative to one another)
                 for name, groups in (("2", [[0, 1]]), ("4", [[0, 1, 2, 3]]), ("2x2", [[0, 1], [2, 3]])):
                     groups = [[lanes[i][0] for i in g] for g in groups]
                     for _ in range(2):  # graph capture, untimed
@@ -654,67 +836,16 @@ def bench_base(args, ctx, workload, steps, warmup, primary):
             detail = srv.answer_resident()
             detail = srv.answer_resident()
 
-    # N > 1: the headline is ONE fixed schedule (comm-overlap where it applies), not the best of several -- a minimum over noisy
-    # timings is biased low and would not compare like with like between rounds; the others are reported beside it in `schedules`
-    fastest = min(timed, key=timed.get)
-    best = "comm-overlap" if "comm-overlap" in timed else ("in-order" if "in-order" in timed else fastest)
-    ms_per_step = timed[best]
-    names = ["expand_convert", "sweep", "reduce_lift_fold_switch"]  # the last bucket includes the collective(s)
-    stages = {n: sum(ev[k][i].elapsed_time(ev[k][i + 1]) for k in sampled) / len(sampled) * 1e3 for i, n in enumerate(names)}
-    coll = {}
-    if use_dist:
-        pairs = ([("all_gather_gsw_bits", 4, 5)] if shard_expand else []) + ([("reduce_scatter_accumulators", 6, 7), ("all_gather_folded_cts", 8, 9)] if sharded_fold else [("reduce_accumulators", 6, 7)])
-        coll = {n: round(sum(ev[k][a].elapsed_time(ev[k][b]) for k in sampled) / len(sampled) * 1e3, 1) for n, a, b in pairs}
-    sweep_ms = stages["sweep"] / 1e3
+    prog.arm(f"{workload}/standalone kernels", 3.0)
+    extra = {"reference_buckets_us_eager": ({k: round(v, 1) for k, v in detail.items() if k != "scaltomat_us"} if detail else None)}
     # the same kernel timed over 24 back-to-back launches on the server stream, outside the timed region (spiral_gpu_server_time_sweep): the
     # in-loop figure averages only the sampled steps (steps / event_every launches) and moves +-4 % with them; both are printed
     sweep_ms_24 = srv.time_sweep(24) if world == 1 else None
-    bytes_sweep = srv.sweep_bytes()
-    achieved = bytes_sweep / (sweep_ms * 1e-3) / 1e9
-    traffic, traffic_src = pmc_traffic(world, nu1, nu2)
-    out = {
-        "metric": "server ms/query + DB GB/s vs HBM roofline" + (", 2^20 x 256B" if workload == "config2" else f" ({workload})"),
-        "value": round(ms_per_step, 4),
-        "unit": "ms/query",
-        "n_gpus": world,
-        "steps": steps,
-        "warmup": warmup,
-        "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": False,
-        "scaling": "strong",
-        "vs_baseline": None,
-        "dtype": "u32 residues, 32x32->64-bit integer MAC (two 28-bit CRT primes)",
-        "data": "synthetic",
-        "config": {"workload": label + ", explicit DB generated on device, sharded by first-dimension index",
-                   "db_bytes_ntt_form": int(shp.dim0) * int(shp.num_per) * 4 * sa.N * 8, "schedule": "split: the GSW side of the query on a side stream" if args.overlap else "in order, one stream",
-                   "parallelism": (f"j-shard x{world}, reduce-scatter + distributed fold + all-gather" if sharded_fold else f"j-shard x{world} + 1 reduce")
-                                  + (", sharded expansion + all-gather of the GSW bits" if shard_expand else "")
-                                  + (" (overlapped with ScalToMat + sweep)" if best == "comm-overlap" else "")
-                                  + (f" (sweep pipelined with its reduce-scatter in {n_stages} stages)" if best == "pipelined" else "")},
-        "queries_per_s": round(1e3 / ms_per_step, 2),
-        "prewarm_queries": args.prewarm,
-        "stages_us": {k: round(v, 1) for k, v in stages.items()},
-        "reference_buckets_us_eager": ({k: round(v, 1) for k, v in detail.items() if k != "scaltomat_us"} if detail else None),
-        "roofline": {"bound": "hbm", "kernel": "sweep_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "frac_device_bytes": round(srv.sweep_device_bytes() / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(bytes_sweep),
-                     "avg_launch_ms": round(sweep_ms, 4),
-                     "device_bytes_per_launch": int(srv.sweep_device_bytes()), "achieved_device_bytes": round(srv.sweep_device_bytes() / (sweep_ms * 1e-3) / 1e9, 1),
-                     "note": "achieved / frac = SURVEY 8d algorithmic bytes (8 B per database word) / launch time measured in THIS run with HIP events on the launch stream; "
-                             "the device keeps a word's two 28-bit residues in 7 bytes, so a launch physically moves device_bytes_per_launch: achieved_device_bytes / "
-                             "frac_device_bytes are the HBM utilisation in physical bytes.  `traffic` is NOT measured in this run: it is the rocprofv3 PMC figure "
-                             "(FETCH_SIZE / WRITE_SIZE passes) read from the committed file named in traffic_source, valid for configs[1] on one GPU only (null otherwise)",
-                     "launches_timed": len(sampled), "shard": f"j in [{j0},{j1}) on rank 0",
-                     "standalone_24_launches": ({"avg_launch_ms": round(sweep_ms_24, 4), "achieved": round(bytes_sweep / (sweep_ms_24 * 1e-3) / 1e9, 1),
-                                                 "frac": round(bytes_sweep / (sweep_ms_24 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                                                 "note": "24 back-to-back launches of the same kernel on the same inputs after the timed region (HIP events on the launch stream)"}
-                                                if sweep_ms_24 else None)},
-    }
-    if use_dist:
-        out["schedules"] = {"ms_per_query": {k: round(v, 4) for k, v in timed.items()}, "chosen": best, "fastest": fastest, "sweep_stages": n_stages if "pipelined" in timed else None,
-                            "note": "each schedule timed over the same K steps after W warm-up steps, max over ranks; value = the `chosen` one, fixed in advance "
-                                    "(comm-overlap where the sharded expansion and the distributed fold apply), `fastest` names the minimum"}
-        out["collectives_us"] = coll
-        out["rccl"] = ctx.rccl
+    if sweep_ms_24:
+        bytes_sweep = srv.sweep_bytes()
+        extra["roofline"] = {"standalone_24_launches": {"avg_launch_ms": round(sweep_ms_24, 4), "achieved": round(bytes_sweep / (sweep_ms_24 * 1e-3) / 1e9, 1),
+                                                        "frac": round(bytes_sweep / (sweep_ms_24 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                                        "note": "24 back-to-back launches of the same kernel on the same inputs after the timed region (HIP events on the launch stream)"}}
     # the transform kernels against their VALU bound (they are the rest of the query: ~29 k limb-pair transforms at config 2).
     # Bound: the bare Harvey / Shoup butterfly = 3 integer multiplies (4.45 cycles each per wave instruction per SIMD, measured,
     # profiles/r02_ubench_valu.txt) + 4 add / sub (2.9) = 25 cycles x 88 limb-butterflies per thread, 4 waves per polynomial on
@@ -723,13 +854,16 @@ def bench_base(args, ctx, workload, steps, warmup, primary):
         fwd_ms, inv_ms = sa.time_ntt(16384, 10)
         ns_f, ns_i = fwd_ms * 1e6 / 16384, inv_ms * 1e6 / 16384
         ns_d = sa.time_ntt_digits(2048, 8, 10) * 1e6 / 16384
-        out["roofline_ntt"] = {"bound": "valu", "unit": "ns per limb-pair transform (2048 points x 2 primes)", "peak": 3.6,
-                               "forward_to_ntt": round(ns_f, 2), "inverse_from_ntt": round(ns_i, 2), "forward_digits": round(ns_d, 2),
-                               "frac_forward": round(3.6 / ns_f, 3), "frac_inverse": round(3.6 / ns_i, 3), "frac_forward_digits": round(3.6 / ns_d, 3),
-                               "batch": 16384, "note": "standalone launches of 16384 transforms, HIP events: to_ntt (reduce mod p, b + forward) and from_ntt (inverse + CRT lift) "
-                                                       "each read and write 16 KiB of HBM per transform; forward_digits is the launch the stages are built from (8 gadget digits "
-                                                       "of each of 2048 polynomials: the source is re-read from cache, every transform writes its 16 KiB)"}
-    if pipelined: out["pipelined"] = pipelined
+        extra["roofline_ntt"] = {"bound": "valu", "unit": "ns per limb-pair transform (2048 points x 2 primes)", "peak": 3.6,
+                                 "forward_to_ntt": round(ns_f, 2), "inverse_from_ntt": round(ns_i, 2), "forward_digits": round(ns_d, 2),
+                                 "frac_forward": round(3.6 / ns_f, 3), "frac_inverse": round(3.6 / ns_i, 3), "frac_forward_digits": round(3.6 / ns_d, 3),
+                                 "batch": 16384, "note": "standalone launches of 16384 transforms, HIP events: to_ntt (reduce mod p, b + forward) and from_ntt (inverse + CRT lift) "
+                                                         "each read and write 16 KiB of HBM per transform; forward_digits is the launch the stages are built from (8 gadget digits "
+                                                         "of each of 2048 polynomials: the source is re-read from cache, every transform writes its 16 KiB)"}
+    if pipelined: extra["pipelined"] = pipelined
+    out = make_out(extra)
+    prog.update(out)
+    prog.disarm()
     srv.close()
     del acc
     torch.cuda.empty_cache()
@@ -746,16 +880,29 @@ def main(argv=None):
 
     import numpy as np
 
+    prog = Progress(int(os.environ.get("RANK", "0")), args.watchdog)
+    prog.arm("process group set-up", 3.0)
     ctx = Ctx(args)
-    out, params_kw = bench_base(args, ctx, args.workload, args.steps, args.warmup, primary=True)
+    out, params_kw = bench_base(args, ctx, args.workload, args.steps, args.warmup, True, prog)
     if args.workload == "config2" and not args.no_config3 and (args.nu1, args.nu2) == (None, None):
-        # secondary leg: configs[2]'s geometry, where the sweep is ~70 % of the query and the j-shard scales; the headline stays configs[1]
-        o3, _ = bench_base(args, ctx, "config3", args.config3_steps, min(args.warmup, 2), primary=False)
-        out["also"] = {"config3": {k: o3[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "stages_us", "queries_per_s", "schedules", "collectives_us", "pipelined") if k in o3}}
-        out["also"]["config3"]["workload"] = o3["config"]["workload"]
-        out["also"]["config3"]["parallelism"] = o3["config"]["parallelism"]
-        out["also"]["config3"]["roofline"] = {k: o3["roofline"][k] for k in ("achieved", "frac", "frac_device_bytes", "avg_launch_ms", "algorithmic_bytes_per_launch", "shard")}
+        # secondary leg, LAST: configs[2]'s geometry, where the sweep is ~70 % of the query and the j-shard scales; the headline stays configs[1]
+        # and is complete (and in the line-so-far) before this leg starts
+        def nest(o3):
+            c3 = {k: o3[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "stages_us", "queries_per_s", "schedules", "collectives_us", "pipelined", "answer_sha256", "value_no_prewarm") if k in o3}
+            c3["workload"] = o3["config"]["workload"]
+            c3["parallelism"] = o3["config"]["parallelism"]
+            if "roofline" in o3:
+                c3["roofline"] = {k: o3["roofline"][k] for k in ("achieved", "frac", "frac_device_bytes", "avg_launch_ms", "algorithmic_bytes_per_launch", "shard")}
+            return dict(out, also={"config3": c3})
+
+        prog.wrap = nest
+        o3, _ = bench_base(args, ctx, "config3", args.config3_steps, min(args.warmup, 2), False, prog)
+        prog.wrap = lambda line: line
+        out = nest(o3)
+    prog.update(out)
+    prog.arm("process group tear-down", 1.0)
     ctx.close()
+    prog.disarm()
     if ctx.rank == 0:
         if ctx.world == 1 and not args.no_cpu_baseline and args.workload == "config2":  # (the larger workloads' 32 / 64 GiB host databases are not built for a baseline)
             out["cpu_baseline"] = cpu_baseline(params_kw, np, args.workload)

@@ -23,7 +23,12 @@ struct Lanes {
     uint32_t n = 1;
     int64_t off[kMaxLanes] = {0, 0, 0, 0};  // u64 words from lane 0's arena to lane q's
 #ifdef __HIPCC__
-    __device__ __forceinline__ int64_t here() const { return off[blockIdx.z]; }
+    // (a select chain on constant indices: indexing the by-value kernel argument with blockIdx.z would make the compiler keep the whole
+    // parameter struct in scratch memory -- 232 bytes per lane and transforms twice as slow, measured)
+    __device__ __forceinline__ int64_t here() const {
+        const uint32_t z = blockIdx.z;
+        return z == 0 ? 0 : (z == 1 ? off[1] : (z == 2 ? off[2] : off[3]));
+    }
 #endif
 };
 #ifdef __HIPCC__

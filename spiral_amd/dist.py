@@ -22,11 +22,21 @@ def shard_range(rank: int, world: int, dim0: int) -> tuple[int, int]:
     return rank * per, (rank + 1) * per
 
 
+def _check(name, t, numel=None):
+    """what every collective here assumes of its tensors: int64 words (the packed fields are summed as integers), contiguous, of the
+    expected size -- a wrong view would not fail inside RCCL, it would silently reduce the wrong bytes (or hang on a size mismatch)"""
+    import torch
+
+    if t.dtype != torch.int64 or not t.is_contiguous() or (numel is not None and t.numel() != numel):
+        raise ValueError(f"{name}: expected a contiguous int64 tensor" + (f" of {numel} words" if numel is not None else "") + f", got {t.dtype}, {tuple(t.shape)}, contiguous={t.is_contiguous()}")
+
+
 def reduce_accumulators(acc, dst: int = 0, group=None):
     """sum the ranks' packed accumulators into rank `dst` (one collective).  `acc` is an int64 tensor
     viewing the words the sweep wrote; the fields never carry into each other (see module docstring)."""
     import torch.distributed as dist
 
+    _check("reduce_accumulators: acc", acc)
     dist.reduce(acc, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return acc
 
@@ -37,6 +47,8 @@ def reduce_scatter_accumulators(chunk, acc, group=None, async_op=False):
     gloo (CPU tests) does not, there the same result is an all-reduce followed by a slice."""
     import torch.distributed as dist
 
+    _check("reduce_scatter_accumulators: acc", acc)
+    _check("reduce_scatter_accumulators: chunk", chunk, acc.numel() // dist.get_world_size(group))
     if dist.get_backend(group) == "gloo":
         tmp = acc.clone()
         dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group)
@@ -60,6 +72,8 @@ def reduce_scatter_stages(chunk, acc, n_stages: int, group=None, async_op=False,
     """the pipelined form: stage s's contiguous 1/K of `acc` is reduce-scattered into rows [s L/K, (s+1) L/K) of `chunk`.
     after_stage(s), when given, is called before stage s's collective is issued (the caller launches the sweep of stage s there);
     async_op: returns the Work handles (None entries on gloo, where the collective is synchronous)."""
+    if acc.numel() % n_stages or chunk.numel() % n_stages:
+        raise ValueError(f"reduce_scatter_stages: {acc.numel()} / {chunk.numel()} words do not split into {n_stages} stages")
     al, cl = acc.numel() // n_stages, chunk.numel() // n_stages
     works = []
     for s in range(n_stages):
@@ -73,6 +87,8 @@ def all_gather_cts(gathered, ct, group=None):
     """collect the ranks' locally folded ciphertexts in rank order (96 KiB each)"""
     import torch.distributed as dist
 
+    _check("all_gather_cts: ct", ct)
+    _check("all_gather_cts: gathered", gathered, ct.numel() * dist.get_world_size(group))
     dist.all_gather_into_tensor(gathered, ct, group=group)
     return gathered
 
@@ -88,6 +104,8 @@ def all_gather_gsw_bits(gathered, mine, group=None, async_op=False):
     current stream has enqueued so far) and work.wait() makes the current stream wait for it"""
     import torch.distributed as dist
 
+    _check("all_gather_gsw_bits: mine", mine)
+    _check("all_gather_gsw_bits: gathered", gathered, mine.numel() * dist.get_world_size(group))
     work = dist.all_gather_into_tensor(gathered, mine, group=group, async_op=async_op)
     return work if async_op else gathered
 

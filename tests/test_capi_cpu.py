@@ -6,6 +6,7 @@ import hashlib
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -139,3 +140,25 @@ def test_bench_self_launch_command_and_cpu_quota(monkeypatch):
     assert 1 <= bench.cpu_quota_cores() <= (os.cpu_count() or 1)
     a = bench.parse_args(["--comm-overlap"])
     assert a.schedule == "comm-overlap" and bench.parse_args([]).schedule == "all" and bench.parse_args([]).sweep_stages == 4
+
+
+def test_bench_watchdog_prints_the_line_so_far():
+    """bench.py's Progress (no GPU involved): a phase that outlives the watchdog ends the process with exit code 3 and the line-so-far on stdout,
+    marked partial with the phase it hung in; the same line was written to the partial file when it was recorded"""
+    import json
+    import subprocess
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "p.json")
+        code = ("import sys, time; sys.path.insert(0, %r); import bench; p = bench.Progress(0, 1.0); "
+                "p.update({'metric': 'm', 'value': 0.5, 'schedules': {'ms_per_query': {'in-order': 0.5}}}); p.arm('config2/pipelined'); time.sleep(30)") % ROOT
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60, env=dict(os.environ, SPIRAL_BENCH_PARTIAL=path))
+        assert r.returncode == 3
+        out = json.loads(r.stdout.strip().splitlines()[-1])
+        assert out["partial"] is True and out["hung_in"] == "config2/pipelined" and out["schedules"]["ms_per_query"]["in-order"] == 0.5
+        assert json.load(open(path))["value"] == 0.5 and "bench.py partial: " in r.stderr
+        # a disarmed watchdog never fires, and non-zero ranks never print the line
+        code2 = ("import sys, time; sys.path.insert(0, %r); import bench; p = bench.Progress(1, 0.5); p.update({'value': 1}); p.arm('x'); p.disarm(); time.sleep(1.5); print('alive')") % ROOT
+        r2 = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=60, env=dict(os.environ, SPIRAL_BENCH_PARTIAL=path))
+        assert r2.returncode == 0 and r2.stdout.strip() == "alive" and "partial" not in r2.stderr

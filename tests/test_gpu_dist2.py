@@ -212,6 +212,34 @@ def test_bench_eight_ranks_on_one_gpu():
     assert "j-shard x8" in out["config"]["parallelism"] and out["value"] > 0
 
 
+def test_bench_watchdog_keeps_the_finished_schedules(tmp_path):
+    """a hang in the last (and least hardware-tested) schedule must not lose the run: with SPIRAL_BENCH_INJECT_HANG=pipelined both ranks stop inside
+    that schedule; the watchdog prints the line-so-far -- in-order and comm-overlap timed, what the communicator saw, the collective times -- on
+    stdout, marked partial, and the job exits non-zero within the watchdog's time; the same line is in the partial file"""
+    import json
+    import subprocess
+    import time
+
+    partial = tmp_path / "partial.json"
+    env = dict({k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")},
+               SPIRAL_BENCH_INJECT_HANG="pipelined", SPIRAL_BENCH_WATCHDOG_S="20", SPIRAL_BENCH_PARTIAL=str(partial))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--backend", "gloo", "--shared-device", "--prewarm", "2", "--nu1", "7", "--nu2", "6", "--no-config3"]
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
+    assert r.returncode != 0, "the injected hang must end in a non-zero exit"
+    assert time.time() - t0 < 300
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["partial"] is True and out["hung_in"] == "config2/pipelined" and out["n_gpus"] == 2
+    assert set(out["schedules"]["ms_per_query"]) == {"in-order", "comm-overlap"} and out["schedules"]["requested"] == ["in-order", "comm-overlap", "pipelined"]
+    assert out["value"] == out["schedules"]["ms_per_query"]["comm-overlap"] > 0
+    assert out["rccl"]["world_size"] == 2 and set(out["collectives_us"]) == {"all_gather_gsw_bits", "reduce_scatter_accumulators", "all_gather_folded_cts"}
+    assert out["roofline"]["achieved"] > 0 and len(out["answer_sha256"]) == 64
+    assert out["schedules"]["answer_sha256"]["in-order"] == out["schedules"]["answer_sha256"]["comm-overlap"]
+    on_disk = json.loads(partial.read_text())
+    assert on_disk["partial"] is True and on_disk["schedules"]["ms_per_query"] == out["schedules"]["ms_per_query"]
+    assert "bench.py partial: " in r.stderr
+
+
 @pytest.mark.parametrize("extra", [[], ["--root-fold"]])
 def test_bench_rccl_world_size_one(extra):
     """RCCL itself on hardware: bench.py with torch.distributed initialised on the nccl (= RCCL) backend and a world of one
@@ -228,6 +256,12 @@ def test_bench_rccl_world_size_one(extra):
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["roofline"]["achieved"] > 0
     assert ("1 reduce" in out["config"]["parallelism"]) == bool(extra)
+    if not extra:
+        # all three schedules ran through RCCL, the pipelined one with its K asynchronous reduce-scatters (async_op=True) interleaved with the
+        # sweep stages on the library's stream -- and every schedule left the same answer
+        assert set(out["schedules"]["ms_per_query"]) == {"in-order", "comm-overlap", "pipelined"} and out["schedules"]["sweep_stages"] == 4
+        assert len(set(out["schedules"]["answer_sha256"].values())) == 1 and out["rccl"]["backend"] == "nccl"
+    assert "partial" not in out and len(out["answer_sha256"]) == 64
 
 
 def test_bench_pack_trial_shards():

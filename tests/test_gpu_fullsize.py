@@ -125,6 +125,59 @@ def test_config2_every_stage_bit_exact(sa, oracle_mt, request):
         assert_eq(srv.read(SV.BUF_RESPONSE), resp, "run_query graph: response")
     srv.use_graphs(False)
 
+    # bench.py's own synthetic inputs (uniform residues from default_rng(1), database seed 1234): the oracle's answer for exactly what the timed
+    # hipGraph computes, as the hash bench.py prints -- BENCH_rNN.json's answer_sha256 must equal this line
+    import bench
+
+    pub_b, q_b = bench.synth_inputs(np, sa, pg, s)
+    assert bench.DB_SEED == 1234 and bench.WORKLOADS["config2"]["nu1"] == 8 and bench.WORKLOADS["config2"]["nu2"] == 7
+    assert all(getattr(sa.make_params(**{k: v for k, v in bench.WORKLOADS["config2"].items() if k != "label"}), f) == getattr(pg, f)
+               for f in ("nu1", "nu2", "t_gsw", "t_conv", "t_exp", "t_exp_right", "qprime_bits", "p_db", "direct_upload"))
+    fin_b = M.answer(po, q_b, *pub_b, db)
+    resp_b = M.stage_rescale(po, fin_b)
+    srv.use_graphs(True)
+    srv.set_pub_params(*pub_b)
+    srv.set_query(q_b)
+    for rep in range(3):
+        srv.run_query()
+    srv.sync()
+    assert_eq(srv.read(SV.BUF_FINAL), fin_b, "bench.py's inputs: folded ciphertext of the replayed whole-query graph")
+    assert_eq(srv.read(SV.BUF_RESPONSE), resp_b, "bench.py's inputs: response")
+    record(request, f"bench.py config2 inputs (default_rng(1) residues, gen_db(1234)): oracle answer_sha256 {bench.answer_hash(np, fin_b, resp_b)} == device "
+                    f"{bench.answer_hash(np, srv.read(SV.BUF_FINAL), srv.read(SV.BUF_RESPONSE))}")
+    srv.use_graphs(False)
+    srv.set_pub_params(wl, wr, w, v)
+
+    # four whole queries in one launch sequence (run_query_batch, every launch carrying all four; three more clients with their own keys on lanes
+    # of the same database image): every lane's accumulators, folded ciphertext and response against the oracle's for ITS inputs
+    lanes = [srv] + [sa.Server(pg, share_db_of=srv) for _ in range(3)]
+    clients = [cl] + [M.Client(po, seed=100 + b) for b in range(3)]
+    pps = [(wl, wr, w, v)] + [c.pub_params() for c in clients[1:]]
+    idxs = [idx, 0, (1 << 15) - 1, 7777]
+    qs_b = [c.query(i) for c, i in zip(clients, idxs)]
+    for ln, pp, qq in zip(lanes, pps, qs_b):
+        ln.set_pub_params(*pp)
+        ln.set_query(qq)
+        ln.use_graphs(True)
+    for n_b in (4, 2):
+        for rep in range(2):  # capture, then a replay
+            sa.run_query_batch(lanes[:n_b])
+        for b, (ln, c, pp, qq, i2) in enumerate(zip(lanes[:n_b], clients, pps, qs_b, idxs)):
+            ln.sync()
+            cv_b = M.stage_expand(po, qq, pp[0], pp[1])
+            cts_b, gsw_b = M.stage_convert(po, cv_b, pp[2], pp[3])
+            acc_b = M.multiply_query_by_database(M.reorient_ciphertexts(cts_b), db, s.dim0, s.num_per)
+            fin_l = M.stage_fold(po, M.from_ntt(acc_b), gsw_b)
+            assert_eq(ln.read(SV.BUF_ACC), acc_b, f"batch of {n_b}, lane {b}: accumulators")
+            assert_eq(ln.read(SV.BUF_FINAL), fin_l, f"batch of {n_b}, lane {b}: folded ciphertext")
+            got_r = ln.read(SV.BUF_RESPONSE)
+            assert_eq(got_r, M.stage_rescale(po, fin_l), f"batch of {n_b}, lane {b}: response")
+            assert_eq(c.decode(got_r), M.db_item(po, 1234, i2), f"batch of {n_b}, lane {b}: decoded plaintext")
+    record(request, "config 2 run_query_batch: 4 and 2 queries per launch sequence (own keys per lane), every lane's accumulators / folded ciphertext / response bit-exact")
+    for ln in lanes[1:]:
+        ln.close()
+    srv.use_graphs(False)
+
     # the same database uploaded in the reference's NTT layout (load_db), then ingested from raw plaintext bytes
     assert_eq(srv.read_db_slots(5, 2).reshape(2, -1), db.reshape(N, -1)[5:7], "device-generated database, slots 5..6")
     srv.load_db(db)
