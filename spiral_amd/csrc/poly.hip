@@ -159,7 +159,7 @@ void launch_fold_mac(const uint64_t* key, const uint64_t* d, uint64_t* out, uint
                      const Lanes& lanes) {
     if (np == 0) return;
     FoldMacParams p{key, d, out, K, key_stride ? key_stride : K, addend, lanes};
-    if (np >= 16 && np % 2 == 0)  // wide rounds: 2 ciphertexts per workgroup
+    if (np * lanes.n >= 16 && np % 2 == 0)  // wide rounds (all query lanes together): 2 ciphertexts per workgroup
         hipLaunchKernelGGL(fold_mac_kernel<2>, dim3(kN / 64, np / 2, lanes.n), dim3(kTpb), 0, s, p);
     else
         hipLaunchKernelGGL(fold_mac_kernel<1>, dim3(kN / 64, np, lanes.n), dim3(kTpb), 0, s, p);
@@ -523,11 +523,14 @@ void launch_expand_mac_round(const ExpandMacParams& p, hipStream_t s) {
         const char* e = getenv("SPIRAL_MAC_CT4_MIN");  // tuning only
         return e ? (uint32_t)strtoul(e, nullptr, 10) : 128u;
     }();
-    if (cnt >= ct4_min)
+    // (the thresholds count the ciphertexts of all query lanes: what matters is how many workgroups the launch has; the groups of a batch kernel
+    // still come from one lane -- they share that lane's W)
+    const uint32_t eff = cnt * p.lanes.n;
+    if (eff >= ct4_min && cnt >= 8)
         hipLaunchKernelGGL(expand_mac_round_batch_kernel<4>, dim3(kN / 128, (p.cnt_e + 3) / 4 + (p.cnt_o + 3) / 4, p.lanes.n), dim3(kTpb), 0, s, p);
-    else if (cnt >= ct2_min)
+    else if (eff >= ct2_min && cnt >= 4)
         hipLaunchKernelGGL(expand_mac_round_batch_kernel<2>, dim3(kN / 128, (p.cnt_e + 1) / 2 + (p.cnt_o + 1) / 2, p.lanes.n), dim3(kTpb), 0, s, p);
-    else if (cnt >= wide_min)
+    else if (eff >= wide_min)
         hipLaunchKernelGGL(expand_mac_round_wide_kernel, dim3(kN / 128, cnt, p.lanes.n), dim3(kTpb), 0, s, p);
     else
         hipLaunchKernelGGL(expand_mac_round_kernel, dim3(kN / 64, cnt, p.lanes.n), dim3(kTpb), 0, s, p);

@@ -132,9 +132,13 @@ int srv_alloc(spiral_gpu_server* S, const spiral_gpu_server* db_owner) {
     };
     Arena sizing;
     layout(sizing);
-    if (S->arena.alloc(sizing.used)) return -1;
+    // experiment hook: lane k's pieces start skew * k bytes into its allocation, so that the same buffer of different lanes does not sit at the same
+    // offset modulo the memory system's interleaving
+    size_t skew = 0;
+    if (const char* e = getenv("SPIRAL_ARENA_SKEW")) skew = (strtoull(e, nullptr, 10) / 256 * 256 / 8) * (db_owner ? db_owner->n_lanes : 0);
+    if (S->arena.alloc(sizing.used + skew)) return -1;
     Arena real;
-    real.base = S->arena.p;
+    real.base = S->arena.p + skew;
     layout(real);
     HIP_OK(hipMemset(S->cv.p, 0, S->cv.words * sizeof(uint64_t)));
     S->gs_raw_p = S->cv_raw.p + (size_t)S->dim0_shard * kN;
@@ -1464,7 +1468,7 @@ int spiral_gpu_server_run_query_batch(spiral_gpu_server* const* servers, uint32_
         spiral_gpu_server* L = servers[b];
         if (!L->have_query || !L->have_pp) return fail("run_query_batch: server %u needs its query and public parameters set first", b);
         if (!L->have_db) return fail("run_query_batch: server %u has no database", b);
-        if (memcmp(&L->p, &S->p, sizeof(S->p)) != 0 || L->device != S->device || L->j0 != S->j0 || L->dim0_shard != S->dim0_shard || L->arena.words != S->arena.words)
+        if (memcmp(&L->p, &S->p, sizeof(S->p)) != 0 || L->device != S->device || L->j0 != S->j0 || L->dim0_shard != S->dim0_shard || L->cv.words != S->cv.words)
             return fail("run_query_batch: server %u differs from server 0 in parameters, device or shard", b);
         if (L->db.p != S->db.p) return fail("run_query_batch: server %u does not sweep server 0's database image (create_lane / share_db)", b);
         if (L->acc != L->acc_own.p || L->keep_cts || L->overlap || L->fold_g_log || L->sweep_k_log || L->ex_shard.g_log || L->side_pending || L->fold_pair != S->fold_pair ||
@@ -1472,16 +1476,21 @@ int spiral_gpu_server_run_query_batch(spiral_gpu_server* const* servers, uint32_
             return fail("run_query_batch: server %u has an external accumulator, keep_cts, a split / sharded / staged schedule or other fold options set", b);
         for (uint32_t c = 0; c < b; c++)
             if (servers[c] == L) return fail("run_query_batch: server %u listed twice", b);
-        lanes.off[b] = L->arena.p - S->arena.p;
+        lanes.off[b] = L->w_left.p - S->w_left.p;  // (the first piece of the arena)
     }
     for (uint32_t b = 1; b < n; b++) {  // the lanes' uploads (and whatever else their streams still hold) come first
         HIP_OK(hipEventRecord(servers[b]->ev_batch, servers[b]->stream));
         HIP_OK(hipStreamWaitEvent(S->stream, servers[b]->ev_batch, 0));
     }
+    uint32_t parts = 7;  // tuning hook: which parts of the sequence run (1 = expansion + conversion, 2 = sweep, 4 = folding), for timelines of one part
+    if (const char* e = getenv("SPIRAL_BATCH_PARTS")) parts = (uint32_t)atoi(e);
     auto body = [&]() {
-        if (expand_lanes(S, lanes)) return -1;
-        if (convert_part(S, CONV_BOTH, S->stream, false, lanes)) return -1;
-        if (sweep_batch_ok(S->s.num_per, 2 * S->dim0_shard)) {
+        if (parts & 1u) {
+            if (expand_lanes(S, lanes)) return -1;
+            if (convert_part(S, CONV_BOTH, S->stream, false, lanes)) return -1;
+        }
+        if (!(parts & 2u)) {
+        } else if (sweep_batch_ok(S->s.num_per, 2 * S->dim0_shard)) {
             const uint32_t* qs[kMaxLanes];
             uint64_t* acc[kMaxLanes];
             for (uint32_t b = 0; b < n; b++) {
@@ -1493,6 +1502,7 @@ int spiral_gpu_server_run_query_batch(spiral_gpu_server* const* servers, uint32_
             for (uint32_t b = 0; b < n; b++)
                 launch_sweep(S->db.p, (const uint32_t*)(S->qs.p + lanes.off[b]), S->acc + lanes.off[b], S->s.num_per, 2 * S->dim0_shard, 0, S->stream);
         }
+        if (!(parts & 4u)) return 0;
         return run_fold_rounds(S, S->s.num_per, 0, S->p.nu2, S->acc, false, true, nullptr, lanes);
     };
     int rc = 0;
@@ -1500,7 +1510,7 @@ int spiral_gpu_server_run_query_batch(spiral_gpu_server* const* servers, uint32_
         rc = body();
     } else {
         bool same = S->graph_batch && S->batch_n == n;
-        for (uint32_t b = 0; same && b < n; b++) same = S->batch_key[b] == servers[b]->arena.p;
+        for (uint32_t b = 0; same && b < n; b++) same = S->batch_key[b] == servers[b]->w_left.p;
         if (!same) {
             if (S->graph_batch) (void)hipGraphExecDestroy(S->graph_batch);
             S->graph_batch = nullptr;
@@ -1516,7 +1526,7 @@ int spiral_gpu_server_run_query_batch(spiral_gpu_server* const* servers, uint32_
             (void)hipGraphDestroy(g);
             if (e2 != hipSuccess) return fail("hipGraphInstantiate failed: %s", hipGetErrorString(e2));
             S->batch_n = n;
-            for (uint32_t b = 0; b < n; b++) S->batch_key[b] = servers[b]->arena.p;
+            for (uint32_t b = 0; b < n; b++) S->batch_key[b] = servers[b]->w_left.p;
         }
         HIP_OK(hipGraphLaunch(S->graph_batch, S->stream));
     }

@@ -125,6 +125,16 @@ template <int MODE, int NB = 1>
 __global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __restrict__ db, SweepBatch bt, uint32_t nic, uint32_t dim0, uint32_t g_log, uint32_t ls_log,
                                                              uint32_t icb0, uint32_t n_icb) {
     static_assert(NB == 1 || MODE == 0, "batched sweeps use the wide geometry");
+    // NB >= 3: the records of all NB queries reach the MACs through LDS instead of SGPRs.  Scalar loads cannot be pipelined deep enough --
+    // 96 SGPRs per query and group, and their L2 round trip behind a saturated HBM stream is long: with every query on the scalar path
+    // sweep_kernel<0, 4> spent 78 % of its wave-cycles waiting (SQ_WAIT_ANY) with the VALU half idle, 614 us against 315 us for NB = 2.  Here a
+    // wave fetches the next group's NB x 384 bytes with one or two coalesced vector loads per lane while it multiplies the current group, parks
+    // them in its own LDS rows and reads them back as same-address (broadcast) ds_read_b128: the multiplicands are VGPRs, nothing waits on the
+    // scalar cache.  Measured per launch at config 2 (tools/sweep_batch_time.py): 297 / 319 / 350 / 437 us for NB = 1 .. 4 (NB = 3, 4 were 413 / 614);
+    // the broadcast reads now share the limit with the VALU (NB = 2 through LDS: 324 us, no better than SGPRs; NB = 4 as two scalar + two LDS queries
+    // 455 us, as LDS-DMA loads (global_load_lds) with a vmcnt(0) per group 483 us: both measured and dropped).
+    constexpr bool LREC = NB >= 3;
+    __shared__ __attribute__((aligned(16))) uint4 qrec[LREC ? kSweepZ * NB * 24 : 1];
     const uint32_t* __restrict__ qs = bt.qs[0];
     uint64_t* __restrict__ acc = bt.acc[0];
     constexpr bool WIDE = MODE == 0;
@@ -152,6 +162,23 @@ __global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __r
     const uint4* q = reinterpret_cast<const uint4*>(qs) + (size_t)z * dim0 * 3u;  // 3 x uint4 per j; wave-uniform when WIDE
     uint64_t a[6] = {0, 0, 0, 0, 0, 0};
     uint64_t ax[NB > 1 ? NB - 1 : 1][6] = {};  // queries 1 .. NB-1 of a batch
+    // LREC: lane t < NB * 24 holds uint4 number t of the group's records [query][j < 8][3]; lanes t - 64 hold the rest
+    uint4 r0 = {}, r1 = {};
+    uint4* const qst = qrec + (LREC ? wv * NB * 24 : 0);
+    const uint4 *rp0 = nullptr, *rp1 = nullptr;
+    if constexpr (LREC) {
+        auto rec_base = [&](uint32_t t) -> const uint4* {
+            const uint32_t b = min(t / 24u, (uint32_t)NB - 1u), off = t - b * 24u;  // (lanes beyond the last record read the last query's: never stored)
+            const uint32_t* p = bt.qs[0];
+#pragma unroll
+            for (int i = 1; i < NB; i++) p = b == (uint32_t)i ? bt.qs[i] : p;
+            return reinterpret_cast<const uint4*>(p) + (size_t)z * dim0 * 3u + off;
+        };
+        rp0 = rec_base(lane);
+        rp1 = rec_base(min(64u + lane, (uint32_t)NB * 24u - 1u));
+        r0 = rp0[(size_t)gfirst * 24u];
+        r1 = rp1[(size_t)gfirst * 24u];
+    }
     for (uint32_t g0 = gfirst; g0 < glast; g0 += 16) {  // 16 groups = 128 j = 256 terms per accumulator between reductions
         const uint32_t gend = min(g0 + 16u, glast);
 #pragma unroll 2
@@ -179,6 +206,18 @@ __global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __r
                 __builtin_amdgcn_wave_barrier();
                 qg = qst + (lane / w) * 24u;
             }
+            if constexpr (LREC) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();  // the previous group's reads of this wave's rows
+                qst[lane] = r0;
+                if (lane < (uint32_t)NB * 24u - 64u) qst[64u + lane] = r1;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t gn = min(g + 1u, glast - 1u);  // the next group's records, in flight under this group's MACs
+                r0 = rp0[(size_t)gn * 24u];
+                r1 = rp1[(size_t)gn * 24u];
+                qg = qst;
+            }
             mac_packed_j<0>(a, qg, d);
             mac_packed_j<1>(a, qg + 3, d);
             mac_packed_j<2>(a, qg + 6, d);
@@ -190,7 +229,7 @@ __global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __r
             if constexpr (NB > 1) {
 #pragma unroll
                 for (int b = 1; b < NB; b++) {
-                    const uint4* qb = reinterpret_cast<const uint4*>(bt.qs[b]) + (size_t)z * dim0 * 3u + (size_t)g * 24u;
+                    const uint4* qb = LREC ? qst + b * 24 : reinterpret_cast<const uint4*>(bt.qs[b]) + (size_t)z * dim0 * 3u + (size_t)g * 24u;
                     mac_packed_j<0>(ax[b - 1], qb, d);
                     mac_packed_j<1>(ax[b - 1], qb + 3, d);
                     mac_packed_j<2>(ax[b - 1], qb + 6, d);
