@@ -171,10 +171,66 @@ __device__ __forceinline__ void signed_residues(int32_t s, uint32_t& rp, uint32_
     rp = min(d, d + kP);
     rb = min(d, d + kB);
 }
+// The DIFFERENCE of two balanced digits needs no carry logic at all.  Within a chain whose digits all may borrow, d_j = u_j - (B/2 - 1) where
+// u_j is the plain base-B digit j of x + bias, x the chain's own bits and bias = sum_j (B/2 - 1) B^j: adding B/2 - 1 to a piece makes it
+// overflow into the next digit exactly when the piece (with its carry-in) exceeds B/2, which is the reference's borrow rule
+// (src/spiral.cpp:283-292, 313-322; the digits of a number in [-B/2 + 1, B/2] are unique), and the constant cancels in G^-1(H)_k - G^-1(L)_k.
+// The first chain's last digit never borrows: it is its plain digit plus the carry out of the biased digits below it.  Per value that is an
+// add and a bit-field extract instead of sdig32's two extracts, compare, add, compare and select.  ok: both chains fit 32 bits
+// (every even gadget dimension up to 12 among others); the other dimensions keep sdig32.
+struct SFast {
+    bool ok, chain1, last0, x_hi;
+    uint32_t x_sh, bias, d_sh, mask, low_mask;
+};
+__device__ __forceinline__ SFast sfast_setup(uint32_t k, uint32_t bits, uint32_t ell) {
+    SFast f;
+    const uint32_t n0 = ell >> 1, n1 = ell - n0, oc = n0 * bits;
+    f.ok = bits <= kSmallDigitBits && n0 >= 1 && n0 * bits <= 32u && n1 * bits <= 32u && ell * bits >= 57u;
+    f.chain1 = k >= n0;
+    const uint32_t j = f.chain1 ? k - n0 : k;
+    f.last0 = !f.chain1 && k + 1 == n0;
+    const uint32_t nb = f.chain1 ? n1 : n0 - 1u;  // the chain's borrowing digits
+    uint32_t b = 0;
+    for (uint32_t i = 0; i < nb; i++) b += ((1u << (bits & 31u)) / 2u - 1u) << ((i * bits) & 31u);
+    f.bias = b;
+    f.x_hi = oc >= 32u;
+    f.x_sh = oc & 31u;
+    f.d_sh = (j * bits) & 31u;
+    f.mask = (1u << (bits & 31u)) - 1u;
+    f.low_mask = (1u << f.d_sh) - 1u;
+    return f;
+}
+// x: the chain's bits (the value's low word for the first chain; the value shifted down to the second chain's start)
+template <bool LAST0>
+__device__ __forceinline__ uint32_t sfast_word(uint32_t x, const SFast& f) {
+    if constexpr (LAST0) return ((x >> f.d_sh) & f.mask) + (((x & f.low_mask) + f.bias) >> f.d_sh);
+    return ((x + f.bias) >> f.d_sh) & f.mask;
+}
+template <bool CHAIN1, bool XHI, bool LAST0>
+__device__ __forceinline__ uint32_t sfast_digit(uint64_t v, const SFast& f) {
+    return sfast_word<LAST0>(CHAIN1 ? (XHI ? hi32(v) >> f.x_sh : __builtin_amdgcn_alignbit(hi32(v), lo32(v), f.x_sh)) : lo32(v), f);
+}
 // digit differences G^-1(h)_k - G^-1(l)_k of a thread's 8 pairs of lifted coefficients as residues (the pair form of a fold
 // round); H(r), L(r) fetch the values (registers or LDS)
 template <class FH, class FL>
 __device__ __forceinline__ void sdigit_diff8(FH H, FL L, uint32_t k, uint32_t bits, uint32_t ell, uint32_t* lo, uint32_t* hi) {
+    const SFast f = sfast_setup(k, bits, ell);
+    if (f.ok) {
+        if (f.last0) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) signed_residues((int32_t)(sfast_digit<false, false, true>(H(r), f) - sfast_digit<false, false, true>(L(r), f)), lo[r], hi[r]);
+        } else if (!f.chain1) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) signed_residues((int32_t)(sfast_digit<false, false, false>(H(r), f) - sfast_digit<false, false, false>(L(r), f)), lo[r], hi[r]);
+        } else if (f.x_hi) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) signed_residues((int32_t)(sfast_digit<true, true, false>(H(r), f) - sfast_digit<true, true, false>(L(r), f)), lo[r], hi[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; r++) signed_residues((int32_t)(sfast_digit<true, false, false>(H(r), f) - sfast_digit<true, false, false>(L(r), f)), lo[r], hi[r]);
+        }
+        return;
+    }
     const SDig32 d = sdig32_setup(k, bits, ell);
     if (d.ok) {
         if (!d.d_hi) {
@@ -349,13 +405,35 @@ __global__ __launch_bounds__(256, 8) void ntt_forward_kernel(Tables t, FwdParams
         const uint32_t i = s / 6u, rc = s - i * 6u;
         const uint64_t* sl = p.src + ((size_t)i * 6u + rc) * kN;
         const uint64_t* sh_ = p.src + ((size_t)(p.fold_np + i) * 6u + rc) * kN;
-        uint64_t rl[8], rh[8];
+        const SFast f = sfast_setup(k, p.bits, p.ell);
+        if (f.ok && (!f.chain1 || f.x_hi)) {
+            // the digit lives in ONE 32-bit word of the value (the first chain in the low word; the second chain, when it starts at or beyond
+            // bit 32, in the high word): half the loads and half the registers of the general form
+            const uint32_t* wl = reinterpret_cast<const uint32_t*>(sl) + (f.chain1 ? 1u : 0u);
+            const uint32_t* wh = reinterpret_cast<const uint32_t*>(sh_) + (f.chain1 ? 1u : 0u);
+            uint32_t xl[8], xh[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            rl[r] = sl[ix_a(tid, r)];
-            rh[r] = sh_[ix_a(tid, r)];
+            for (int r = 0; r < 8; r++) {
+                xl[r] = wl[2u * ix_a(tid, r)];
+                xh[r] = wh[2u * ix_a(tid, r)];
+            }
+            const uint32_t xs = f.chain1 ? f.x_sh : 0u;
+            if (f.last0) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) signed_residues((int32_t)(sfast_word<true>(xh[r], f) - sfast_word<true>(xl[r], f)), lo[r], hi[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; r++) signed_residues((int32_t)(sfast_word<false>(xh[r] >> xs, f) - sfast_word<false>(xl[r] >> xs, f)), lo[r], hi[r]);
+            }
+        } else {
+            uint64_t rl[8], rh[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                rl[r] = sl[ix_a(tid, r)];
+                rh[r] = sh_[ix_a(tid, r)];
+            }
+            sdigit_diff8([&](int r) { return rh[r]; }, [&](int r) { return rl[r]; }, k, p.bits, p.ell, lo, hi);
         }
-        sdigit_diff8([&](int r) { return rh[r]; }, [&](int r) { return rl[r]; }, k, p.bits, p.ell, lo, hi);
     } else if constexpr (LOAD == LD_PDIFF) {
         // SpiralPack fold round in pair form: source s = (trial t, pair i, row) over [nt][np][2]; lifted ciphertexts [t][2 np][2] at p.src;
         // unsigned digits (gadget_invert, src/util.cpp:114), whose base-2^bits expansion always recomposes the value
