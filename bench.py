@@ -391,6 +391,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-config3", action="store_true", help="skip the secondary leg (`also.config3`: BASELINE.json configs[2]'s 2^24 x 256 B geometry, the one whose "
                     "sweep is most of the query, timed after the headline workload in the same invocation so that the N = 1, 2, 4, 8 runs give its curve too)")
     ap.add_argument("--config3-steps", type=int, default=10)
+    ap.add_argument("--no-replicas", action="store_true", help="N > 1: skip the `replicas` block (every rank answering batches of whole queries on its own full copy of the database)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the one-GPU self-test)")
     ap.add_argument("--shared-device", action="store_true", help="self-test: all ranks use device 0")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the reduce even with one rank (self-test)")
@@ -870,6 +871,49 @@ def bench_base(args, ctx, workload, steps, warmup, primary, prog):
     return out, params_kw
 
 
+def bench_replicas(args, ctx, prog, batch=4, n_batches=25):
+    """N > 1, beside the j-shard figure north_star prescribes (never `value`, never the scaling curve): every rank answers on its OWN full copy of the
+    configs[1] database, `batch` whole queries per launch sequence (spiral_gpu_server_run_query_batch) -- what a deployment would do at this database
+    size, where the j-shard is Amdahl-bound.  No collective on the data path: a barrier either side, max over ranks."""
+    import numpy as np
+
+    import spiral_amd as sa
+
+    torch = ctx.torch
+    params_kw = {k: v for k, v in WORKLOADS["config2"].items() if k != "label"}
+    pg = sa.make_params(**params_kw)
+    shp = sa.get_shape(pg)
+    prog.arm("replicas/set-up", 3.0)
+    owner = sa.Server(pg, ctx.local_rank)
+    stream = torch.cuda.Stream(device=ctx.dev)
+    owner.set_stream(stream.cuda_stream)
+    owner.gen_db(DB_SEED)
+    lanes = [owner] + [sa.Server(pg, ctx.local_rank, share_db_of=owner) for _ in range(batch - 1)]
+    pub, query = synth_inputs(np, sa, pg, shp)
+    for ln in lanes:
+        ln.set_pub_params(*pub)
+        ln.set_query(query)
+        ln.use_graphs(True)
+    prog.arm("replicas/timed")
+    for _ in range(5):
+        sa.run_query_batch(lanes)
+    ctx.fence()
+    t0 = time.perf_counter()
+    for _ in range(n_batches):
+        sa.run_query_batch(lanes)
+    ctx.fence()
+    dt = ctx.max_over_ranks(time.perf_counter() - t0)
+    for ln in lanes[1:]:
+        ln.close()
+    owner.close()
+    torch.cuda.empty_cache()
+    total = ctx.world * batch * n_batches
+    return {"n_replicas": ctx.world, "batch": batch, "queries": total, "queries_per_s": round(total / dt, 1), "queries_per_s_per_replica": round(batch * n_batches / dt, 1),
+            "ms_per_batch": round(dt * 1e3 / n_batches, 4),
+            "note": "N independent replicas of the configs[1] database, one per GPU, each answering batches of whole queries; throughput only, NOT the j-shard scaling "
+                    "north_star asks for (that is `value` at each N) and not a latency"}
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
@@ -884,6 +928,9 @@ def main(argv=None):
     prog.arm("process group set-up", 3.0)
     ctx = Ctx(args)
     out, params_kw = bench_base(args, ctx, args.workload, args.steps, args.warmup, True, prog)
+    if ctx.world > 1 and args.workload == "config2" and not args.no_replicas and (args.nu1, args.nu2) == (None, None):
+        out["replicas"] = bench_replicas(args, ctx, prog)  # no collective on its data path: cannot hang where the j-shard schedules did not
+        prog.update(out)
     if args.workload == "config2" and not args.no_config3 and (args.nu1, args.nu2) == (None, None):
         # secondary leg, LAST: configs[2]'s geometry, where the sweep is ~70 % of the query and the j-shard scales; the headline stays configs[1]
         # and is complete (and in the line-so-far) before this leg starts

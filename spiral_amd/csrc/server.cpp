@@ -132,13 +132,9 @@ int srv_alloc(spiral_gpu_server* S, const spiral_gpu_server* db_owner) {
     };
     Arena sizing;
     layout(sizing);
-    // experiment hook: lane k's pieces start skew * k bytes into its allocation, so that the same buffer of different lanes does not sit at the same
-    // offset modulo the memory system's interleaving
-    size_t skew = 0;
-    if (const char* e = getenv("SPIRAL_ARENA_SKEW")) skew = (strtoull(e, nullptr, 10) / 256 * 256 / 8) * (db_owner ? db_owner->n_lanes : 0);
-    if (S->arena.alloc(sizing.used + skew)) return -1;
+    if (S->arena.alloc(sizing.used)) return -1;
     Arena real;
-    real.base = S->arena.p + skew;
+    real.base = S->arena.p;
     layout(real);
     HIP_OK(hipMemset(S->cv.p, 0, S->cv.words * sizeof(uint64_t)));
     S->gs_raw_p = S->cv_raw.p + (size_t)S->dim0_shard * kN;
@@ -1482,15 +1478,10 @@ int spiral_gpu_server_run_query_batch(spiral_gpu_server* const* servers, uint32_
         HIP_OK(hipEventRecord(servers[b]->ev_batch, servers[b]->stream));
         HIP_OK(hipStreamWaitEvent(S->stream, servers[b]->ev_batch, 0));
     }
-    uint32_t parts = 7;  // tuning hook: which parts of the sequence run (1 = expansion + conversion, 2 = sweep, 4 = folding), for timelines of one part
-    if (const char* e = getenv("SPIRAL_BATCH_PARTS")) parts = (uint32_t)atoi(e);
     auto body = [&]() {
-        if (parts & 1u) {
-            if (expand_lanes(S, lanes)) return -1;
-            if (convert_part(S, CONV_BOTH, S->stream, false, lanes)) return -1;
-        }
-        if (!(parts & 2u)) {
-        } else if (sweep_batch_ok(S->s.num_per, 2 * S->dim0_shard)) {
+        if (expand_lanes(S, lanes)) return -1;
+        if (convert_part(S, CONV_BOTH, S->stream, false, lanes)) return -1;
+        if (sweep_batch_ok(S->s.num_per, 2 * S->dim0_shard)) {
             const uint32_t* qs[kMaxLanes];
             uint64_t* acc[kMaxLanes];
             for (uint32_t b = 0; b < n; b++) {
@@ -1502,7 +1493,6 @@ int spiral_gpu_server_run_query_batch(spiral_gpu_server* const* servers, uint32_
             for (uint32_t b = 0; b < n; b++)
                 launch_sweep(S->db.p, (const uint32_t*)(S->qs.p + lanes.off[b]), S->acc + lanes.off[b], S->s.num_per, 2 * S->dim0_shard, 0, S->stream);
         }
-        if (!(parts & 4u)) return 0;
         return run_fold_rounds(S, S->s.num_per, 0, S->p.nu2, S->acc, false, true, nullptr, lanes);
     };
     int rc = 0;

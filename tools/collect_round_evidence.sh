@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the round's evidence on the GPU box into gpurun_out/evidence (copy what is to be judged into profiles/).
-# usage (from the repo root, through gpurun): bash tools/collect_round_evidence.sh r04
+# usage (from the repo root, through gpurun): bash tools/collect_round_evidence.sh r05
 set -u
 R=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp
@@ -10,12 +10,19 @@ F="--no-cpu-baseline --no-config3 --lanes 1"
 python bench.py > $O/${R}_bench.json 2> $O/${R}_bench.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --steps 20 --warmup 3 $F > $O/${R}_bench_under_rocprof.log 2>&1
 cp $O/kt/*/*_kernel_stats.csv $O/${R}_bench_kernel_stats.csv
-# the trace holds, in order: 2 priming queries, --prewarm (40) queries, 3 warm-up steps, 20 timed steps, then the standalone sweep launches.  Query 11 is a
-# pre-warm query = a whole-query graph replay (no gaps); query 50 is timed step 5, a SAMPLED step, whose hipEventRecords between the stages show up as gaps
-python tools/trace_summary.py $O/kt/*/*_kernel_trace.csv --timeline --query 11 > $O/${R}_one_query_timeline.txt
-python tools/trace_summary.py $O/kt/*/*_kernel_trace.csv --timeline --query 50 > $O/${R}_one_query_timeline_sampled_step.txt
+# the trace holds, in order: 2 priming queries, the W + K steps of the no-pre-warm pass (3 + 20), --prewarm (40) queries, 3 warm-up steps, 20 timed steps, then the
+# standalone sweep launches.  Query 40 is a pre-warm query = a whole-query graph replay (no gaps); query 73 is timed step 5, a SAMPLED step, whose hipEventRecords
+# between the stages show up as gaps
+python tools/trace_summary.py $O/kt/*/*_kernel_trace.csv --timeline --query 40 > $O/${R}_one_query_timeline.txt
+python tools/trace_summary.py $O/kt/*/*_kernel_trace.csv --timeline --query 73 > $O/${R}_one_query_timeline_sampled_step.txt
 python tools/kernel_avg.py $O/kt/*/*_kernel_trace.csv "" --by-grid > $O/${R}_kernel_avg_by_grid.txt
 rm -rf $O/kt
+# four whole queries per launch sequence (run_query_batch): times for B = 1 .. 4, and the timeline of one B = 4 batch
+python tools/batch_query.py 1 2 3 4 > $O/${R}_batch_times.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/ktb -- python3 tools/batch_query.py 4 --reps=10 > $O/ktb.log 2>&1
+python tools/trace_summary.py $O/ktb/*/*_kernel_trace.csv --timeline --query 20 > $O/${R}_one_query_timeline_B4.txt
+rm -rf $O/ktb
+python tools/sweep_batch_time.py > $O/${R}_sweep_batch_time.txt 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 4 --warmup 1 $F --no-graphs > $O/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 4 --warmup 1 $F --no-graphs > $O/pmc_write.log 2>&1
 cp $O/pmc_fetch/*/*_counter_collection.csv $O/${R}_pmc_fetch_size_counter_collection.csv
@@ -24,16 +31,21 @@ timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ
 timeout 600 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq2 -- python3 bench.py --steps 2 --warmup 1 $F --no-graphs > $O/pmc_sq2.log 2>&1
 python tools/pmc_summary.py $O/pmc_sq1/*/*_counter_collection.csv $O/pmc_sq2/*/*_counter_collection.csv > $O/${R}_sq_counters_per_kernel.json
 rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq1 $O/pmc_sq2
-# the fold in its forms, alternating on this box (group times of hipGraph replays, tools/stage_ab.py)
-python tools/stage_ab.py "" "SPIRAL_FOLD_PAIR=0" "SPIRAL_FOLD_UNCHAIN_MIN=1" "SPIRAL_FOLD_UNCHAIN_MIN=1000000" "SPIRAL_FOLD_UNCHAIN_MIN=1000000,SPIRAL_FOLD_TEAM=0" "" "SPIRAL_FOLD_PAIR=0" > $O/${R}_fold_forms_ab.txt 2>&1
-# two digits per workgroup on one twiddle fetch
+# the same counters for a B = 4 batch (sweep_kernel<0, 4> and the batched transform launches)
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/pmc_b4 -- python3 tools/batch_query.py 4 --reps=2 > $O/pmc_b4.log 2>&1
+python tools/pmc_summary.py $O/pmc_b4/*/*_counter_collection.csv > $O/${R}_sq_counters_batch4.json
+rm -rf $O/pmc_b4
+# the fold's forms that remain, alternating on this box (group times of hipGraph replays, tools/stage_ab.py)
+python tools/stage_ab.py "" "SPIRAL_FOLD_PAIR=0" "SPIRAL_FOLD_CHAIN=0" "" "SPIRAL_FOLD_PAIR=0" > $O/${R}_fold_forms_ab.txt 2>&1
 ( python tools/digits_time.py; SPIRAL_FWD2=1 python tools/digits_time.py; SPIRAL_FWD2=0 python tools/digits_time.py ) > $O/${R}_digits_time_fwd2.txt 2>&1
-timeout 120 tools/xcd_sync_probe > $O/${R}_xcd_sync_probe_raw.txt 2>&1
+bash tools/run_handoff.sh > $O/${R}_handoff_probe_raw.txt 2>&1
+timeout 120 tools/grid_shape_probe > $O/${R}_grid_shape_probe.txt 2>&1
 python tools/cpu_oracle_scaling.py 1 8 16 32 > $O/${R}_cpu_oracle_scaling.txt 2>&1
 python tools/shard_estimate.py > $O/${R}_shard_estimate.txt 2>&1
 python bench.py --workload config3 --steps 10 --no-cpu-baseline > $O/${R}_bench_config3.json 2>/dev/null
 python bench.py --workload stream --steps 10 --no-cpu-baseline > $O/${R}_bench_stream.json 2>/dev/null
 python bench.py --workload pack --steps 10 --warmup 2 > $O/${R}_bench_pack.json 2>/dev/null
 python bench.py --gpus 2 --backend gloo --shared-device --steps 10 > $O/${R}_bench_selflaunch_2ranks_1gpu.json 2>/dev/null
-python bench.py --gpus 8 --backend gloo --shared-device --steps 5 --no-config3 > $O/${R}_bench_selflaunch_8ranks_1gpu.json 2>/dev/null
-ls -la $O | head -50
+python bench.py --gpus 8 --backend gloo --shared-device --steps 5 --no-config3 --no-replicas > $O/${R}_bench_selflaunch_8ranks_1gpu.json 2>/dev/null
+SPIRAL_BENCH_INJECT_HANG=pipelined SPIRAL_BENCH_WATCHDOG_S=25 SPIRAL_BENCH_PARTIAL=$O/${R}_bench_partial_file.json python bench.py --gpus 2 --backend gloo --shared-device --steps 5 --no-config3 --no-replicas > $O/${R}_bench_injected_hang_2ranks.json 2> $O/${R}_bench_injected_hang_2ranks.err; echo "exit code $?" >> $O/${R}_bench_injected_hang_2ranks.json
+ls -la $O | head -60
