@@ -369,7 +369,7 @@ def parse_args(argv=None):
     ap.add_argument("--nu1", type=int, default=None, help="override the workload's first-dimension size (tuning)")
     ap.add_argument("--nu2", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--watchdog", type=float, default=float(os.environ.get("SPIRAL_BENCH_WATCHDOG_S", "120")), help="seconds a schedule / phase may take before the line-so-far "
+    ap.add_argument("--watchdog", type=float, default=float(os.environ.get("SPIRAL_BENCH_WATCHDOG_S", "180")), help="seconds a schedule / phase may take before the line-so-far "
                     "is printed (partial: true, hung_in) and the process exits 3; 0 = off")
     ap.add_argument("--prewarm", type=int, default=40, help="untimed queries run as part of the set-up before the W warm-up steps, to ramp the GPU's clocks (0 = none)")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
