@@ -180,7 +180,7 @@ __device__ __forceinline__ void signed_residues(int32_t s, uint32_t& rp, uint32_
 // (every even gadget dimension up to 12 among others); the other dimensions keep sdig32.
 struct SFast {
     bool ok, chain1, last0, x_hi;
-    uint32_t x_sh, bias, d_sh, mask, low_mask;
+    uint32_t x_sh, bias, d_sh, bits, low_mask;
 };
 __device__ __forceinline__ SFast sfast_setup(uint32_t k, uint32_t bits, uint32_t ell) {
     SFast f;
@@ -196,15 +196,15 @@ __device__ __forceinline__ SFast sfast_setup(uint32_t k, uint32_t bits, uint32_t
     f.x_hi = oc >= 32u;
     f.x_sh = oc & 31u;
     f.d_sh = (j * bits) & 31u;
-    f.mask = (1u << (bits & 31u)) - 1u;
+    f.bits = bits;
     f.low_mask = (1u << f.d_sh) - 1u;
     return f;
 }
 // x: the chain's bits (the value's low word for the first chain; the value shifted down to the second chain's start)
 template <bool LAST0>
 __device__ __forceinline__ uint32_t sfast_word(uint32_t x, const SFast& f) {
-    if constexpr (LAST0) return ((x >> f.d_sh) & f.mask) + (((x & f.low_mask) + f.bias) >> f.d_sh);
-    return ((x + f.bias) >> f.d_sh) & f.mask;
+    if constexpr (LAST0) return __builtin_amdgcn_ubfe(x, f.d_sh, f.bits) + (((x & f.low_mask) + f.bias) >> f.d_sh);
+    return __builtin_amdgcn_ubfe(x + f.bias, f.d_sh, f.bits);  // v_bfe_u32: d_sh + bits <= 32
 }
 template <bool CHAIN1, bool XHI, bool LAST0>
 __device__ __forceinline__ uint32_t sfast_digit(uint64_t v, const SFast& f) {

@@ -175,6 +175,9 @@ __global__ __launch_bounds__(256, 8) void ntt_forward_kernel(Tables t, FwdParams
             if (f.last0) {
 #pragma unroll
                 for (int r = 0; r < 8; r++) signed_residues((int32_t)(sfast_word<true>(xh[r], f) - sfast_word<true>(xl[r], f)), lo[r], hi[r]);
+            } else if (xs == 0u) {  // (the chain starts at the word's bit 0: the first chain always, the second when it starts at bit 32)
+#pragma unroll
+                for (int r = 0; r < 8; r++) signed_residues((int32_t)(sfast_word<false>(xh[r], f) - sfast_word<false>(xl[r], f)), lo[r], hi[r]);
             } else {
 #pragma unroll
                 for (int r = 0; r < 8; r++) signed_residues((int32_t)(sfast_word<false>(xh[r] >> xs, f) - sfast_word<false>(xl[r] >> xs, f)), lo[r], hi[r]);
