@@ -132,7 +132,8 @@ __global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __r
     // them in its own LDS rows and reads them back as same-address (broadcast) ds_read_b128: the multiplicands are VGPRs, nothing waits on the
     // scalar cache.  Measured per launch at config 2 (tools/sweep_batch_time.py): 297 / 319 / 350 / 437 us for NB = 1 .. 4 (NB = 3, 4 were 413 / 614);
     // the broadcast reads now share the limit with the VALU (NB = 2 through LDS: 324 us, no better than SGPRs; NB = 4 as two scalar + two LDS queries
-    // 455 us, as LDS-DMA loads (global_load_lds) with a vmcnt(0) per group 483 us: both measured and dropped).
+    // 455 us, as LDS-DMA loads (global_load_lds) with a vmcnt(0) per group 483 us, one or two queries' records broadcast with v_readlane out of the
+    // record register instead of LDS 480 / 510 us: all measured and dropped).
     constexpr bool LREC = NB >= 3;
     __shared__ __attribute__((aligned(16))) uint4 qrec[LREC ? kSweepZ * NB * 24 : 1];
     const uint32_t* __restrict__ qs = bt.qs[0];
