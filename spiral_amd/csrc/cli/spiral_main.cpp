@@ -1,7 +1,7 @@
 // ./spiral -- drop-in for the reference executable's command line and text summary (src/spiral.cpp:1228-1346,
 // 209-265), with the server-answer path running on an MI355X through libspiral_gpu.so.
 //
-//   ./spiral <nu1> <nu2> <IDX_TARGET> <dbfile|"a"> [--random-data] [--direct-upload] [--nonoise] [--show-diff] [--seed N]
+//   ./spiral <nu1> <nu2> <IDX_TARGET> <dbfile|"a"> [--random-data] [--direct-upload] [--nonoise] [--show-diff] [--seed N] [--batch B]
 //
 // The reference fixes its scheme parameters at compile time (-DTEXP ... -DOUTN, include/values.h:78-93,
 // select_params.py:337); here the same nine values are read at run time from the environment variables or
@@ -143,6 +143,7 @@ int main(int argc, char** argv) {
     const uint64_t total_n = (1ull << nu1) * (1ull << nu2);
     const uint64_t idx_target = strtoull(argv[3], nullptr, 10);
     bool nonoise = false, random_data = false, show_diff = false, direct_flag = false, high_rate = false;
+    uint32_t batch = 0;
     // as the reference (random_device, src/core.cpp:202; it labels its own generator NOT SECURE): two words of it.
     // This client is a test harness for the server path, not a hardened client.
     std::random_device rd;
@@ -154,6 +155,9 @@ int main(int argc, char** argv) {
         if (!strcmp(argv[i], "--show-diff")) { cout << "Showing diff..." << endl; show_diff = true; }
         if (!strcmp(argv[i], "--direct-upload")) { cout << "Direct uploading of query (no compression)" << endl; direct_flag = true; }
         if (!strcmp(argv[i], "--seed") && i + 1 < argc) seed = strtoull(argv[++i], nullptr, 10);
+        // --batch B (2 .. 4; not a flag of the reference, which answers one query per process): after the reference's own single-query run, B clients --
+        // own keys, own indices -- are answered by ONE call of spiral_gpu_server_run_query_batch and each is decoded and checked
+        if (!strcmp(argv[i], "--batch") && i + 1 < argc) batch = (uint32_t)strtoul(argv[++i], nullptr, 10);
         // --output-err F (src/spiral.cpp:1287-1291) asks the reference to dump its empirical noise statistics (analyze_err.py's
         // input): those are outside this path.  The flag and its file name are consumed so that a driver's
         // command line parses the same way, and the file is not written.
@@ -249,6 +253,56 @@ int main(int argc, char** argv) {
         for (size_t i = 0; i < pt.size(); i++)
             if (pt[i] != corr[i]) cout << i << " " << corr[i] << ", " << pt[i] << endl;
 
+    // ---- --batch B: the same server, B queries of B clients in one launch sequence (include/spiral_gpu.h, spiral_gpu_server_run_query_batch)
+    double batch_us = 0;
+    bool batch_corr = true;
+    if (batch >= 2 && batch <= 4) {
+        std::vector<spiral_gpu_server*> lanes{srv};
+        std::vector<Client> clients;
+        std::vector<uint64_t> idxs;
+        clients.reserve(batch);
+        for (uint32_t b = 0; b < batch; b++) {
+            if (b) {
+                spiral_gpu_server* lane = nullptr;
+                GPU_OK(spiral_gpu_server_create_lane(srv, &lane));
+                lanes.push_back(lane);
+            }
+            clients.emplace_back(p, seed + 1 + b, nonoise);
+            clients[b].keygen();
+            clients[b].gen_pub_params();
+            idxs.push_back((idx_target + 1 + 7919ull * b) % total_n);
+            GPU_OK(spiral_gpu_server_set_pub_params(lanes[b], clients[b].w_left.data(), clients[b].w_right.data(), clients[b].w.data(), clients[b].v.data()));
+            Poly qb = clients[b].query(idxs[b]);
+            GPU_OK(spiral_gpu_server_set_query(lanes[b], qb.data()));
+        }
+        GPU_OK(spiral_gpu_server_use_graphs(srv, 1));
+        const int reps = 10;
+        for (int it = 0; it < 2 + reps; it++) {  // two untimed passes (graph capture, first replay), then `reps` timed ones
+            if (it == 2) {
+                GPU_OK(spiral_gpu_server_sync(srv));
+                t0 = now_us();
+            }
+            GPU_OK(spiral_gpu_server_run_query_batch(lanes.data(), batch));
+        }
+        GPU_OK(spiral_gpu_server_sync(srv));
+        batch_us = (double)(now_us() - t0) / reps;
+        cout << "Batch of " << batch << " queries, Is correct?:";
+        for (uint32_t b = 0; b < batch; b++) {
+            GPU_OK(spiral_gpu_server_sync(lanes[b]));
+            GPU_OK(spiral_gpu_server_read_response_wire(lanes[b], wire.data(), wire.size()));
+            GPU_OK(spiral_gpu_response_from_wire(&p, 2, wire.data(), resp.data()));
+            const bool ok = clients[b].decode(resp.data()) == db_item(db_seed, idxs[b], p.p_db);
+            batch_corr = batch_corr && ok;
+            cout << " " << (ok ? 1 : 0);
+        }
+        cout << endl;
+        GPU_OK(spiral_gpu_server_use_graphs(srv, 0));
+        for (uint32_t b = 1; b < batch; b++) spiral_gpu_server_destroy(lanes[b]);
+    } else if (batch) {
+        fprintf(stderr, "spiral: --batch takes 2, 3 or 4\n");
+        return 1;
+    }
+
     // ---- print_summary (src/spiral.cpp:209-265)
     const double pt_mod = std::log2((double)p.p_db);
     const size_t pt_elem_size = (size_t)((2.0 * 2 * N * pt_mod) / 8.0);
@@ -293,6 +347,7 @@ int main(int argc, char** argv) {
     cout << "        Sweep kernel alone (GPU·us): " << us[5] << endl;
     cout << "      Response switch kernel (GPU·us): " << us[4] << endl;
     cout << "        Whole answer, device (GPU·us): " << us[6] << endl;
+    if (batch_us > 0) cout << "   Batch of " << batch << " queries, wall (GPU·us): " << batch_us << endl;
     spiral_gpu_server_destroy(srv);
-    return is_corr ? 0 : 2;
+    return (is_corr && batch_corr) ? 0 : 2;
 }

@@ -42,6 +42,8 @@ def test_cli_refuses_to_run_without_gpu_or_args():
     (["4", "2", "21", "a", "--output-err", "/tmp/spiral_err_not_written.txt", "--seed", "9"], {"TGSW": "4"}),  # argv of src/spiral.cpp:1287-1291: consumed, ignored
     (["6", "2", "77", "a", "--random-data", "--seed", "4"], {}),
     (["5", "2", "7", "a", "--direct-upload", "--seed", "5"], {"TEXP": "2", "TGSW": "5", "QPBITS": "19"}),  # SURVEY 8c stream probe
+    (["5", "6", "1234", "a", "--seed", "11", "--batch", "4"], {}),  # + four clients answered by one spiral_gpu_server_run_query_batch call (C++ consumer of the batch entry point)
+    (["4", "2", "3", "a", "--direct-upload", "--seed", "12", "--batch", "3"], {"TEXP": "2", "TGSW": "5", "QPBITS": "19"}),
 ])
 def test_cli_end_to_end(args, env):
     e = dict(os.environ)
@@ -52,6 +54,10 @@ def test_cli_end_to_end(args, env):
     missing = [k for k, m in got.items() if m is None]
     assert not missing, (missing, r.stdout)
     assert got["is_corr"].group(1) == "1"
+    if "--batch" in args:
+        n = int(args[args.index("--batch") + 1])
+        assert re.search(r"Batch of %d queries, Is correct\?:( 1){%d}\n" % (n, n), r.stdout), r.stdout[-1500:]
+        assert re.search(r"Batch of %d queries, wall \(GPU·us\): (\d+)" % n, r.stdout)
     if "--output-err" in args:
         assert "noise statistics are not produced" in r.stdout and not os.path.exists(args[args.index("--output-err") + 1])
     assert int(got["resp_sz"].group(1)) == int((2 * 2 * 2048 * (8 + 2) + 2 * 2048 * int(env.get("QPBITS", 20))) / 8)
