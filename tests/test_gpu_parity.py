@@ -456,6 +456,46 @@ def test_random_parameter_sets_bit_exact(sa, oracle, nu1, nu2, kw):
     srv.close()
 
 
+_N_FUZZ_BATCH = max(6, _N_FUZZ // 4)
+
+
+@pytest.mark.parametrize("nu1,nu2,kw", _random_parameter_sets(_N_FUZZ_BATCH, 515), ids=[f"set{i}" for i in range(_N_FUZZ_BATCH)])
+def test_random_parameter_sets_batched(sa, oracle, nu1, nu2, kw):
+    """another seeded draw of parameter sets through run_query_batch with 2-4 lanes (each lane its own client): every lane's folded ciphertext and
+    response == the oracle's for its inputs -- odd gadget dimensions, both query forms, expansions with and without a stop round, tiny geometries
+    whose sweep falls back to one launch per lane"""
+    O = oracle
+    from spiral_amd import server as SV
+
+    po, pg = O.make_params(nu1, nu2, **kw), sa.make_params(nu1, nu2, **kw)
+    n = 2 + (nu1 * 7 + nu2 * 3 + kw["t_gsw"]) % 3
+    seed = 91 + nu2
+    db = O.gen_db(po, seed)
+    owner = sa.Server(pg)
+    owner.gen_db(seed)
+    lanes = [owner] + [sa.Server(pg, share_db_of=owner) for _ in range(n - 1)]
+    clients = [O.Client(po, seed=200 + 13 * b + nu1) for b in range(n)]
+    pps = [cl.pub_params() for cl in clients]
+    for srv, pp in zip(lanes, pps):
+        srv.set_pub_params(*pp)
+        srv.use_graphs(True)
+    total = 1 << (nu1 + nu2)
+    for rnd in range(2):
+        idxs = [(rnd * 5 + 3 * b) % total for b in range(n)]
+        qs = [cl.query(i) for cl, i in zip(clients, idxs)]
+        for srv, q in zip(lanes, qs):
+            srv.set_query(q)
+        sa.run_query_batch(lanes)
+        for b, (srv, pp, q) in enumerate(zip(lanes, pps, qs)):
+            srv.sync()
+            want = O.answer(po, q, pp[0], pp[1], pp[2], pp[3], db)
+            assert_eq(srv.read(SV.BUF_FINAL), want, f"round {rnd} lane {b} of {n}: final ciphertext, params {nu1},{nu2},{kw}")
+            assert_eq(srv.read(SV.BUF_RESPONSE), O.stage_rescale(po, want), f"round {rnd} lane {b} of {n}: response")
+    for srv in lanes[1:]:
+        srv.close()
+    owner.close()
+
+
 def test_two_query_lanes_share_one_database(sa, oracle):
     """share_db: a second server handle sweeps the first one's database image; queries of two clients in flight on two streams,
     interleaved, every answer bit-exact; loading through the lane is refused"""
