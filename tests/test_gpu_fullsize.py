@@ -240,14 +240,17 @@ def sampled_checks(sa, M, po, pg, seed, idx, cl, label, request, n_slots=6, n_it
         import torch
 
         nb = max(batches)
-        lanes, res = [srv], [re]
+        lanes, res, gsws, qbs = [srv], [re], [gsw], [q]
         for b in range(1, nb):
             lane = sa.Server(pg, share_db_of=srv)
             lane.set_pub_params(wl, wr, w, v)
             qb = cl.query((idx * (b + 1) + 12345 * b) % total)
             lane.set_query(qb)
             lanes.append(lane)
-            res.append(M.reorient_ciphertexts(M.stage_convert(po, M.stage_expand(po, qb, wl, wr), w, v)[0]))
+            cts_b, gsw_b = M.stage_convert(po, M.stage_expand(po, qb, wl, wr), w, v)
+            res.append(M.reorient_ciphertexts(cts_b))
+            gsws.append(gsw_b)
+            qbs.append(qb)
         streams = [torch.cuda.Stream() for _ in lanes]
         for ln, st in zip(lanes, streams):
             ln.set_stream(st.cuda_stream)
@@ -266,6 +269,24 @@ def sampled_checks(sa, M, po, pg, seed, idx, cl, label, request, n_slots=6, n_it
                 if b == 0:
                     assert_eq(acc_b, got_acc, f"{label}: batch of {B}, lane 0 == its single sweep")
         record(request, f"{label}: batched sweeps B = {list(batches)}: every lane's accumulators bit-exact on slots {zs} (all ciphertexts) and slot-complete on ciphertexts {cols}")
+        # the whole answer for all lanes in one launch sequence (run_query_batch) at this geometry: the accumulators must be those of the batched sweep
+        # just checked, and each lane's folded ciphertext / response the oracle's fold of ITS accumulators with ITS GSW matrices
+        accs = [ln.read(SV.BUF_ACC).copy() for ln in lanes]
+        srv.keep_cts(False)
+        for ln, qb in zip(lanes, qbs):
+            ln.set_query(qb)
+            ln.use_graphs(True)
+        for rep in range(2):  # capture, then a replay
+            sa.run_query_batch(lanes)
+        for b, ln in enumerate(lanes):
+            ln.sync()
+            assert_eq(ln.read(SV.BUF_ACC), accs[b], f"{label}: whole-query batch of {nb}, lane {b}: accumulators == the batched sweep's")
+            want_b = M.stage_fold(po, M.from_ntt(accs[b]), gsws[b])
+            assert_eq(ln.read(SV.BUF_FINAL), want_b, f"{label}: whole-query batch of {nb}, lane {b}: folded ciphertext")
+            assert_eq(ln.read(SV.BUF_RESPONSE), M.stage_rescale(po, want_b), f"{label}: whole-query batch of {nb}, lane {b}: response")
+            ln.use_graphs(False)
+        record(request, f"{label}: run_query_batch of {nb} lanes: every lane's accumulators, folded ciphertext and response bit-exact")
+        srv.keep_cts(True)
         for ln in lanes[1:]:
             ln.close()
         srv.set_stream(0)
