@@ -152,6 +152,54 @@ def test_two_rank_distributed_fold_equals_single_device(stages):
     assert ok
 
 
+def _worker_bad_tensors(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+
+    from spiral_amd import dist as sdist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    acc = torch.zeros(64, dtype=torch.int64)
+    caught = []
+    for name, fn in (
+        ("dtype", lambda: sdist.reduce_scatter_accumulators(torch.zeros(32, dtype=torch.int64), acc.to(torch.int32))),
+        ("numel", lambda: sdist.reduce_scatter_accumulators(torch.zeros(16, dtype=torch.int64), acc)),
+        ("stride", lambda: sdist.reduce_accumulators(torch.zeros(128, dtype=torch.int64)[::2])),
+        ("gather", lambda: sdist.all_gather_cts(torch.zeros(100, dtype=torch.int64), torch.zeros(64, dtype=torch.int64))),
+        ("stages", lambda: sdist.reduce_scatter_stages(torch.zeros(32, dtype=torch.int64), acc, 3)),
+    ):
+        try:
+            fn()
+        except ValueError:
+            caught.append(name)
+    # and the well-formed call still goes through after the refusals (nothing was half-issued)
+    chunk = torch.zeros(32, dtype=torch.int64)
+    sdist.reduce_scatter_accumulators(chunk, acc + rank + 1)
+    q.put((rank, caught, int(chunk[0])))
+    dist.destroy_process_group()
+
+
+def test_collectives_refuse_malformed_tensors():
+    """spiral_amd/dist.py checks dtype, contiguity and word count of every tensor it hands to a collective BEFORE issuing it (a wrong view would not
+    fail inside RCCL: it would reduce the wrong bytes, or hang every rank on a size mismatch); a refused call leaves the group usable"""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bad_tensors, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    for rank, caught, first in got:
+        assert caught == ["dtype", "numel", "stride", "gather", "stages"], (rank, caught)
+        assert first == 3  # (0 + 1) + (1 + 1)
+
+
 def test_shard_range_partition():
     from spiral_amd import dist as sdist
 
