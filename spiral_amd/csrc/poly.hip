@@ -541,6 +541,40 @@ void launch_expand_mac_round(const ExpandMacParams& p, hipStream_t s) {
 // out = prod + pad(cv row 1) at (1,0) and (2,1)
 __device__ __forceinline__ void scal2mat_slot(const uint64_t* w, const uint64_t* g, uint32_t t_conv, uint64_t cv1, uint32_t z, uint64_t out[3][2]) {
     Acc2 acc[3][2];
+    if (t_conv <= 4) {
+        // few digits (the base path's t_conv = 4): every operand of the product -- the digits and their 6 t_conv W words -- is requested before the first
+        // multiply.  With the W loads inside the per-digit loop a wave made one dependent round trip per digit (a wave of the conversion launch lived 11 us)
+        uint64_t gv[4], wv[4][3][2];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t k = min(u, t_conv - 1);
+            gv[u] = __builtin_nontemporal_load(&g[(size_t)k * kN]);
+#pragma unroll
+            for (uint32_t r = 0; r < 3; r++) {
+                const uint64_t* wr = w + ((size_t)r * 2 * t_conv + 2 * k) * kN + z;
+                wv[u][r][0] = wr[0];
+                wv[u][r][1] = wr[kN];
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++)
+            if (u < t_conv) {
+#pragma unroll
+                for (uint32_t r = 0; r < 3; r++) {
+                    acc[r][0].mac(wv[u][r][0], gv[u]);
+                    acc[r][1].mac(wv[u][r][1], gv[u]);
+                }
+            }
+#pragma unroll
+        for (uint32_t r = 0; r < 3; r++)
+#pragma unroll
+            for (uint32_t c = 0; c < 2; c++) {
+                uint64_t v = acc[r][c].reduced();
+                if ((r == 1 && c == 0) || (r == 2 && c == 1)) v = add_pk(v, cv1);
+                out[r][c] = v;
+            }
+        return;
+    }
     // the digits stream from HBM once (t_conv polynomials per ciphertext, 1.9 GB at the SpiralStream sets' t_conv = 56): eight of them
     // are requested before the first is used -- with one 8-byte load in flight per thread the product ran at 1.8 TB/s
     constexpr uint32_t kAhead = 8;
