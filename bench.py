@@ -762,7 +762,7 @@ def bench_base(args, ctx, workload, steps, warmup, primary, prog):
         # image, one server handle and one stream per lane, each replaying the whole-query graph
         pipelined = None
         if whole and args.lanes > 1:
-            n_lanes = max(args.lanes, 4 if args.batched_sweep else 0)
+            n_lanes = max(args.lanes, 8 if args.batched_sweep else 0)
             lanes = [(srv, stream)]
             for _ in range(n_lanes - 1):
                 lane, lane_stream = sa.Server(pg, local_rank, j0, j1, share_db_of=srv), torch.cuda.Stream(device=dev)
@@ -810,7 +810,7 @@ def bench_base(args, ctx, workload, steps, warmup, primary, prog):
                 # expansion / conversion / lift / fold launches take a query dimension, the sweep is the batched one), one hipGraph replay per batch
                 bq = {}
                 srv.set_acc(0)  # (back to the server's own accumulators: the lanes of a batch address their buffers relative to one another)
-                for name, groups in (("2", [[0, 1]]), ("4", [[0, 1, 2, 3]]), ("2x2", [[0, 1], [2, 3]])):
+                for name, groups in (("2", [[0, 1]]), ("4", [[0, 1, 2, 3]]), ("8", [list(range(8))]), ("2x2", [[0, 1], [2, 3]])):
                     groups = [[lanes[i][0] for i in g] for g in groups]
                     for _ in range(2):  # graph capture, untimed
                         for g in groups: sa.run_query_batch(g)
@@ -825,7 +825,8 @@ def bench_base(args, ctx, workload, steps, warmup, primary, prog):
                     bq[name] = {"queries": n_b * per, "queries_per_s": round(n_b * per / dt_b, 1), "ms_per_query_amortised": round(dt_b * 1e3 / (n_b * per), 4),
                                 "ms_per_batch": round(dt_b * 1e3 / n_b / len(groups), 4)}
                 bq["note"] = ("B whole queries (different lanes: own keys, own query) per launch sequence, every launch carrying all B (gridDim.z = B) and the sweep one pass "
-                              "over the database for all of them; '2x2' = two such batches of 2 in flight on two streams; throughput only -- a query's latency is ms_per_batch")
+                              "over the database for up to four of them (two passes at B = 8); '2x2' = two such batches of 2 in flight on two streams; throughput only -- a "
+                              "query's latency is ms_per_batch")
                 pipelined["batched_query"] = bq
             for lane, _ in lanes[1:]:
                 lane.close()
@@ -871,7 +872,7 @@ def bench_base(args, ctx, workload, steps, warmup, primary, prog):
     return out, params_kw
 
 
-def bench_replicas(args, ctx, prog, batch=4, n_batches=25):
+def bench_replicas(args, ctx, prog, batch=8, n_batches=15):
     """N > 1, beside the j-shard figure north_star prescribes (never `value`, never the scaling curve): every rank answers on its OWN full copy of the
     configs[1] database, `batch` whole queries per launch sequence (spiral_gpu_server_run_query_batch) -- what a deployment would do at this database
     size, where the j-shard is Amdahl-bound.  No collective on the data path: a barrier either side, max over ranks."""

@@ -208,10 +208,11 @@ int spiral_gpu_server_lift(spiral_gpu_server *s, int reduce_first); /* nttInvAnd
  * The lanes are ordered with hipEventRecord / hipStreamWaitEvent on their streams: call it OUTSIDE stream capture (none of the
  * lanes' streams may be capturing a hipGraph; run_pre / run_post capture and replay their own groups either side of it). */
 int spiral_gpu_server_first_dim_batch(spiral_gpu_server *const *servers, uint32_t n);
-/* The same idea for the WHOLE answer: n <= 4 queries -- one per server, an owner and its lanes (create_lane), equal parameters, each with its
+/* The same idea for the WHOLE answer: n <= 8 queries -- one per server, an owner and its lanes (create_lane), equal parameters, each with its
  * own client's public parameters and query -- as one launch sequence in which every launch carries all n queries: the expansion, conversion,
  * lift, folding and switch kernels take a query dimension (the reference runs them once per query, src/spiral.cpp:1664-1743, 1850-2025,
- * 1349-1410, inside process_crtd_query :2337-2406) and the sweep is first_dim_batch's.  A query's ~50 dependent launches outside the sweep are
+ * 1349-1410, inside process_crtd_query :2337-2406) and the sweep is first_dim_batch's (two passes over the database for n = 5 .. 8: a pass carries at most four
+ * queries).  A query's ~50 dependent launches outside the sweep are
  * launch-bound (~5 us each whatever they carry), so n queries cost little more than one there.  Throughput only: each query's latency is the
  * batch's.  Afterwards every server's buffers (accumulators, GSW matrices, final ciphertext, response) hold exactly what its own run_query
  * would have left.  Runs on servers[0]'s stream -- one hipGraph replay per batch when servers[0] has use_graphs on -- with the other lanes'

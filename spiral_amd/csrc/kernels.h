@@ -18,16 +18,19 @@ inline IndexMap identity_map() { return IndexMap{1u, 1u, 0u}; }
 // keys, ciphertexts and scratch.  Every per-query buffer of a server lives in one arena with the same internal layout (srv_alloc), so lane q's
 // buffer is lane 0's pointer + off[q] words: a kernel shifts every non-table pointer of its parameters by off[blockIdx.z] and is otherwise
 // unchanged (n = 1, off = 0: the single-query launch).  The reference answers one query per process_crtd_query (src/spiral.cpp:2337-2406).
-constexpr uint32_t kMaxLanes = 4;
+constexpr uint32_t kMaxLanes = 8;  // (the batched sweep takes at most kSweepMaxBatch = 4 of them per pass over the database: a batch of 5 .. 8 sweeps twice)
 struct Lanes {
     uint32_t n = 1;
-    int64_t off[kMaxLanes] = {0, 0, 0, 0};  // u64 words from lane 0's arena to lane q's
+    int64_t off[kMaxLanes] = {0, 0, 0, 0, 0, 0, 0, 0};  // u64 words from lane 0's arena to lane q's
 #ifdef __HIPCC__
     // (a select chain on constant indices: indexing the by-value kernel argument with blockIdx.z would make the compiler keep the whole
     // parameter struct in scratch memory -- 232 bytes per lane and transforms twice as slow, measured)
     __device__ __forceinline__ int64_t here() const {
         const uint32_t z = blockIdx.z;
-        return z == 0 ? 0 : (z == 1 ? off[1] : (z == 2 ? off[2] : off[3]));
+        int64_t o = 0;
+#pragma unroll
+        for (uint32_t q = 1; q < kMaxLanes; q++) o = z == q ? off[q] : o;
+        return o;
     }
 #endif
 };
@@ -278,7 +281,7 @@ void launch_sweep(const uint64_t* db, const uint32_t* qs, uint64_t* acc, uint32_
 bool sweep_stages_ok(uint32_t num_per, uint32_t jm_total, uint32_t g_log, uint32_t k_log);
 // n = 2 .. kSweepMaxBatch queries against one pass over the database (records qs[b] -> accumulators acc[b]); only where
 // sweep_batch_ok (the packed layout with at least 64 output columns: every published geometry but the smallest streaming ones)
-constexpr uint32_t kSweepMaxBatch = kMaxLanes;
+constexpr uint32_t kSweepMaxBatch = 4;
 bool sweep_batch_ok(uint32_t num_per, uint32_t jm_total);
 void launch_sweep_batch(const uint64_t* db, const uint32_t* const* qs, uint64_t* const* acc, uint32_t n, uint32_t num_per, uint32_t jm_total, uint32_t g_log,
                         hipStream_t s);

@@ -1482,13 +1482,23 @@ int spiral_gpu_server_run_query_batch(spiral_gpu_server* const* servers, uint32_
         if (expand_lanes(S, lanes)) return -1;
         if (convert_part(S, CONV_BOTH, S->stream, false, lanes)) return -1;
         if (sweep_batch_ok(S->s.num_per, 2 * S->dim0_shard)) {
-            const uint32_t* qs[kMaxLanes];
-            uint64_t* acc[kMaxLanes];
-            for (uint32_t b = 0; b < n; b++) {
-                qs[b] = (const uint32_t*)(S->qs.p + lanes.off[b]);
-                acc[b] = S->acc + lanes.off[b];
+            // at most kSweepMaxBatch queries per pass over the database (the sweep's accumulators are registers): a batch of 5 .. 8 sweeps in two
+            // passes of about equal size
+            const uint32_t passes = (n + kSweepMaxBatch - 1) / kSweepMaxBatch;
+            for (uint32_t ps = 0, b0 = 0; ps < passes; ps++) {
+                const uint32_t nb = (n - b0 + (passes - ps) - 1) / (passes - ps);
+                const uint32_t* qs[kSweepMaxBatch];
+                uint64_t* acc[kSweepMaxBatch];
+                for (uint32_t b = 0; b < nb; b++) {
+                    qs[b] = (const uint32_t*)(S->qs.p + lanes.off[b0 + b]);
+                    acc[b] = S->acc + lanes.off[b0 + b];
+                }
+                if (nb == 1)
+                    launch_sweep(S->db.p, qs[0], acc[0], S->s.num_per, 2 * S->dim0_shard, 0, S->stream);
+                else
+                    launch_sweep_batch(S->db.p, qs, acc, nb, S->s.num_per, 2 * S->dim0_shard, 0, S->stream);
+                b0 += nb;
             }
-            launch_sweep_batch(S->db.p, qs, acc, n, S->s.num_per, 2 * S->dim0_shard, 0, S->stream);
         } else {  // geometries the batched kernel does not cover (fewer than 64 output columns, tiny first dimensions): one sweep per lane
             for (uint32_t b = 0; b < n; b++)
                 launch_sweep(S->db.p, (const uint32_t*)(S->qs.p + lanes.off[b]), S->acc + lanes.off[b], S->s.num_per, 2 * S->dim0_shard, 0, S->stream);

@@ -26,7 +26,7 @@ def first_dim_batch(servers):
 
 
 def run_query_batch(servers):
-    """the whole answer for the queries of up to four servers sharing one image, every launch carrying all of them; see include/spiral_gpu.h"""
+    """the whole answer for the queries of up to eight servers sharing one image, every launch carrying all of them; see include/spiral_gpu.h"""
     arr = (C.c_void_p * len(servers))(*[s.h for s in servers])
     check(lib().spiral_gpu_server_run_query_batch(arr, len(servers)))
 

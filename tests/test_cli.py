@@ -44,6 +44,7 @@ def test_cli_refuses_to_run_without_gpu_or_args():
     (["5", "2", "7", "a", "--direct-upload", "--seed", "5"], {"TEXP": "2", "TGSW": "5", "QPBITS": "19"}),  # SURVEY 8c stream probe
     (["5", "6", "1234", "a", "--seed", "11", "--batch", "4"], {}),  # + four clients answered by one spiral_gpu_server_run_query_batch call (C++ consumer of the batch entry point)
     (["4", "2", "3", "a", "--direct-upload", "--seed", "12", "--batch", "3"], {"TEXP": "2", "TGSW": "5", "QPBITS": "19"}),
+    (["5", "6", "99", "a", "--seed", "13", "--batch", "7"], {}),
 ])
 def test_cli_end_to_end(args, env):
     e = dict(os.environ)

@@ -194,7 +194,7 @@ def test_bench_self_launch_without_launcher():
     c3 = out["also"]["config3"]
     assert c3["n_gpus"] == 2 and c3["value"] > 0 and c3["roofline"]["achieved"] > 0 and "2^24" in c3["workload"]
     # the labelled throughput block: every rank batches whole queries on its own full copy of the database (never `value`)
-    assert out["replicas"]["n_replicas"] == 2 and out["replicas"]["batch"] == 4 and out["replicas"]["queries_per_s"] > 0
+    assert out["replicas"]["n_replicas"] == 2 and out["replicas"]["batch"] == 8 and out["replicas"]["queries_per_s"] > 0
     assert len(out["answer_sha256"]) == 64 and "partial" not in out
 
 

@@ -148,18 +148,18 @@ def test_config2_every_stage_bit_exact(sa, oracle_mt, request):
     srv.use_graphs(False)
     srv.set_pub_params(wl, wr, w, v)
 
-    # four whole queries in one launch sequence (run_query_batch, every launch carrying all four; three more clients with their own keys on lanes
+    # eight, four and two whole queries in one launch sequence (run_query_batch, every launch carrying all of them; seven more clients with their own keys on lanes
     # of the same database image): every lane's accumulators, folded ciphertext and response against the oracle's for ITS inputs
-    lanes = [srv] + [sa.Server(pg, share_db_of=srv) for _ in range(3)]
-    clients = [cl] + [M.Client(po, seed=100 + b) for b in range(3)]
+    lanes = [srv] + [sa.Server(pg, share_db_of=srv) for _ in range(7)]
+    clients = [cl] + [M.Client(po, seed=100 + b) for b in range(7)]
     pps = [(wl, wr, w, v)] + [c.pub_params() for c in clients[1:]]
-    idxs = [idx, 0, (1 << 15) - 1, 7777]
+    idxs = [idx, 0, (1 << 15) - 1, 7777, 1, 12345, 31000, 2048]
     qs_b = [c.query(i) for c, i in zip(clients, idxs)]
     for ln, pp, qq in zip(lanes, pps, qs_b):
         ln.set_pub_params(*pp)
         ln.set_query(qq)
         ln.use_graphs(True)
-    for n_b in (4, 2):
+    for n_b in (8, 4, 2):  # (eight lanes: two passes over the database, four queries each)
         for rep in range(2):  # capture, then a replay
             sa.run_query_batch(lanes[:n_b])
         for b, (ln, c, pp, qq, i2) in enumerate(zip(lanes[:n_b], clients, pps, qs_b, idxs)):
@@ -173,7 +173,7 @@ def test_config2_every_stage_bit_exact(sa, oracle_mt, request):
             got_r = ln.read(SV.BUF_RESPONSE)
             assert_eq(got_r, M.stage_rescale(po, fin_l), f"batch of {n_b}, lane {b}: response")
             assert_eq(c.decode(got_r), M.db_item(po, 1234, i2), f"batch of {n_b}, lane {b}: decoded plaintext")
-    record(request, "config 2 run_query_batch: 4 and 2 queries per launch sequence (own keys per lane), every lane's accumulators / folded ciphertext / response bit-exact")
+    record(request, "config 2 run_query_batch: 8, 4 and 2 queries per launch sequence (own keys per lane), every lane's accumulators / folded ciphertext / response bit-exact")
     for ln in lanes[1:]:
         ln.close()
     srv.use_graphs(False)

@@ -461,14 +461,14 @@ _N_FUZZ_BATCH = max(6, _N_FUZZ // 4)
 
 @pytest.mark.parametrize("nu1,nu2,kw", _random_parameter_sets(_N_FUZZ_BATCH, 515), ids=[f"set{i}" for i in range(_N_FUZZ_BATCH)])
 def test_random_parameter_sets_batched(sa, oracle, nu1, nu2, kw):
-    """another seeded draw of parameter sets through run_query_batch with 2-4 lanes (each lane its own client): every lane's folded ciphertext and
+    """another seeded draw of parameter sets through run_query_batch with 2-8 lanes (each lane its own client): every lane's folded ciphertext and
     response == the oracle's for its inputs -- odd gadget dimensions, both query forms, expansions with and without a stop round, tiny geometries
     whose sweep falls back to one launch per lane"""
     O = oracle
     from spiral_amd import server as SV
 
     po, pg = O.make_params(nu1, nu2, **kw), sa.make_params(nu1, nu2, **kw)
-    n = 2 + (nu1 * 7 + nu2 * 3 + kw["t_gsw"]) % 3
+    n = 2 + (nu1 * 7 + nu2 * 3 + kw["t_gsw"]) % 7
     seed = 91 + nu2
     db = O.gen_db(po, seed)
     owner = sa.Server(pg)
@@ -666,6 +666,8 @@ def test_batched_sweep_equals_single_sweeps(sa, oracle, nu1, nu2, n):
     (2, 2, 4, dict(t_gsw=5, t_exp=2, qprime_bits=19, direct_upload=1), True),             # no expansion (SpiralStream form), plain database layout
     (4, 5, 3, dict(t_gsw=14), True),                                                      # a gadget whose digits do not recompose: the two-product fold (fold_chain_kernel) with lanes
     (2, 1, 2, {}, False),                                                                  # stopround == 0
+    (3, 6, 8, dict(t_gsw=8), True), (5, 6, 5, dict(t_gsw=8), True), (4, 5, 7, dict(t_gsw=8), False),  # more than four lanes: the sweep in two passes (4 + 4, 3 + 2, 4 + 3)
+    (5, 3, 6, dict(t_gsw=4), True),                                                       # six lanes on the per-lane sweep fallback
 ])
 def test_run_query_batch_equals_single_queries(sa, oracle, nu1, nu2, n, kw, graphs):
     """run_query_batch: n whole queries (different clients: own keys, own query) in one launch sequence whose every launch carries all of them

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import spiral_amd as sa
 
-Bs = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [1, 2, 4]
+Bs = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [1, 2, 4, 8]
 opts = dict(a[2:].split("=") for a in sys.argv[1:] if a.startswith("--"))
 nu1, nu2, reps = int(opts.get("nu1", 8)), int(opts.get("nu2", 7)), int(opts.get("reps", 40))
 kw = {k: int(opts[k]) for k in ("t_gsw", "t_conv", "t_exp", "t_exp_right") if k in opts}
