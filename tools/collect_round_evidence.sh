@@ -18,7 +18,7 @@ python tools/trace_summary.py $O/kt/*/*_kernel_trace.csv --timeline --query 73 >
 python tools/kernel_avg.py $O/kt/*/*_kernel_trace.csv "" --by-grid > $O/${R}_kernel_avg_by_grid.txt
 rm -rf $O/kt
 # four whole queries per launch sequence (run_query_batch): times for B = 1 .. 4, and the timeline of one B = 4 batch
-python tools/batch_query.py 1 2 3 4 > $O/${R}_batch_times.txt 2>&1
+python tools/batch_query.py 1 2 3 4 6 8 > $O/${R}_batch_times.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/ktb -- python3 tools/batch_query.py 4 --reps=10 > $O/ktb.log 2>&1
 python tools/trace_summary.py $O/ktb/*/*_kernel_trace.csv --timeline --query 20 > $O/${R}_one_query_timeline_B4.txt
 rm -rf $O/ktb
