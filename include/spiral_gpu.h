@@ -115,6 +115,12 @@ int spiral_gpu_response_from_wire(const spiral_gpu_params *p, uint32_t out_n, co
  * [num_per][n1][n2][2][N]. */
 int spiral_gpu_multiply_query_by_database(uint64_t *output, const uint64_t *reorientedCiphertexts,
                                           const uint64_t *database, size_t dim0, size_t num_per);
+/* The same for n <= 8 queries against ONE pass over the database (no reference counterpart: the reference answers one query per
+ * call): reorientedCts = the n queries' buffers one after the other, outputs = [n][num_per][n1][n2][2][N].  Where the geometry allows
+ * (num_per >= 64, dim0 a multiple of 64, <= 2048) the pass runs on the matrix cores (csrc/sweep_mfma.hip), else as passes of two /
+ * one on the vector ALU; every output equals multiply_query_by_database's for that query. */
+int spiral_gpu_multiply_queries_by_database(uint64_t *outputs, const uint64_t *reorientedCiphertexts, size_t n,
+                                            const uint64_t *database, size_t dim0, size_t num_per);
 /* split_and_crt, src/spiral.cpp:270 : raw [num_per][n1][n2][N] -> NTT [num_per][m2][n2][2][N] */
 int spiral_gpu_split_and_crt(uint64_t *out, const uint64_t *in, size_t num_per, uint32_t t_gsw);
 /* foldOneFurtherDimension, src/spiral.cpp:1349.  cts: raw [2*num_per][n1][n2][N], the first num_per

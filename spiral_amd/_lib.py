@@ -77,6 +77,7 @@ PROTOTYPES = {
     "spiral_gpu_gadget_invert": (C.c_int, [U64P, U64P, C.c_size_t, C.c_size_t, C.c_size_t]),
     "spiral_gpu_get_rescaled": (C.c_int, [U64P, U64P, C.c_size_t, C.c_uint64, C.c_uint64]),
     "spiral_gpu_multiply_query_by_database": (C.c_int, [U64P, U64P, U64P, C.c_size_t, C.c_size_t]),
+    "spiral_gpu_multiply_queries_by_database": (C.c_int, [U64P, U64P, C.c_size_t, U64P, C.c_size_t, C.c_size_t]),
     "spiral_gpu_split_and_crt": (C.c_int, [U64P, U64P, C.c_size_t, C.c_uint32]),
     "spiral_gpu_fold_one_further_dimension": (C.c_int, [U64P, C.c_size_t, U64P, U64P, C.c_uint32]),
     "spiral_gpu_expand_improved": (C.c_int, [U64P, C.c_uint32, C.c_uint32, U64P, C.c_uint32, U64P, C.c_uint32, C.c_uint32, C.c_uint32]),

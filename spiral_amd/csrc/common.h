@@ -147,6 +147,12 @@ __device__ __forceinline__ uint64_t rescale_dev(uint64_t a, uint64_t inp_mod, ui
     return (neg && res != 0) ? out_mod - res : res;
 }
 
+// position of ciphertext i0 in the sweep's accumulator buffer (sweep.hip: [stage][rank][ct])
+__device__ __forceinline__ uint32_t acc_pos(uint32_t i0, uint32_t g_log, uint32_t ls_log) {
+    const uint32_t g = i0 & ((1u << g_log) - 1u), k = i0 >> g_log;
+    return ((((k >> ls_log) << g_log) | g) << ls_log) | (k & ((1u << ls_log) - 1u));
+}
+
 // include/util.h:34-38
 __host__ __device__ constexpr uint32_t get_bits_per(uint32_t dim) { return dim == 56 ? 1u : 56u / dim + 1u; }
 

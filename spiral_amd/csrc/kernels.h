@@ -18,7 +18,7 @@ inline IndexMap identity_map() { return IndexMap{1u, 1u, 0u}; }
 // keys, ciphertexts and scratch.  Every per-query buffer of a server lives in one arena with the same internal layout (srv_alloc), so lane q's
 // buffer is lane 0's pointer + off[q] words: a kernel shifts every non-table pointer of its parameters by off[blockIdx.z] and is otherwise
 // unchanged (n = 1, off = 0: the single-query launch).  The reference answers one query per process_crtd_query (src/spiral.cpp:2337-2406).
-constexpr uint32_t kMaxLanes = 8;  // (the batched sweep takes at most kSweepMaxBatch = 4 of them per pass over the database: a batch of 5 .. 8 sweeps twice)
+constexpr uint32_t kMaxLanes = 8;  // (= the queries one pass of the matrix-core sweep takes, sweep_mfma.hip)
 struct Lanes {
     uint32_t n = 1;
     int64_t off[kMaxLanes] = {0, 0, 0, 0, 0, 0, 0, 0};  // u64 words from lane 0's arena to lane q's
@@ -281,10 +281,16 @@ void launch_sweep(const uint64_t* db, const uint32_t* qs, uint64_t* acc, uint32_
 bool sweep_stages_ok(uint32_t num_per, uint32_t jm_total, uint32_t g_log, uint32_t k_log);
 // n = 2 .. kSweepMaxBatch queries against one pass over the database (records qs[b] -> accumulators acc[b]); only where
 // sweep_batch_ok (the packed layout with at least 64 output columns: every published geometry but the smallest streaming ones)
-constexpr uint32_t kSweepMaxBatch = 4;
+constexpr uint32_t kSweepMaxBatch = 2;
 bool sweep_batch_ok(uint32_t num_per, uint32_t jm_total);
 void launch_sweep_batch(const uint64_t* db, const uint32_t* const* qs, uint64_t* const* acc, uint32_t n, uint32_t num_per, uint32_t jm_total, uint32_t g_log,
                         hipStream_t s);
+// the same on the matrix cores for n = 1 .. kMaxLanes queries per pass (sweep_mfma.hip): needs the "limb plane" image of the database, built
+// from the packed one by launch_db_limb_planes (as many words); where sweep_mfma_ok (>= 64 columns, first dimension a multiple of 64)
+bool sweep_mfma_ok(uint32_t num_per, uint32_t jm_total);
+void launch_db_limb_planes(const uint64_t* db_packed_img, uint64_t* db_limbs, uint32_t num_per, uint32_t jm_total, hipStream_t s);
+void launch_sweep_mfma(const uint64_t* db_limbs, const uint32_t* const* qs, uint64_t* const* acc, uint32_t n, uint32_t num_per, uint32_t jm_total, uint32_t g_log,
+                       hipStream_t s);
 // reference DB layout (src/spiral.cpp:1139-1153) -> device layout, for the j-range [j0, j0 + dim0_shard): db_ref holds the nz
 // consecutive z slabs z0 .. z0+nz-1, db_dev is the base of the shard's device database
 void launch_db_relayout(const uint64_t* db_ref, uint64_t* db_dev, uint32_t num_per, uint32_t dim0, uint32_t j0, uint32_t dim0_shard, uint32_t z0,

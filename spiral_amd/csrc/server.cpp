@@ -74,6 +74,12 @@ struct spiral_gpu_server {
     hipGraphExec_t graph_batch = nullptr;
     const uint64_t* batch_key[kMaxLanes] = {};  // the lanes' arenas: every pointer the capture holds is one of them plus a fixed offset
     uint32_t batch_n = 0;
+    // batched sweeps of sweep_mfma_min or more queries run on the matrix cores (sweep_mfma.hip) from a second image of the database, the "limb
+    // planes": built from db on first use by the image's holder (the owner of a shared image), as large as db, dropped when db is reloaded.
+    // SPIRAL_SWEEP_MFMA=n sets the threshold (0 = never: at most kSweepMaxBatch queries per pass, on the vector ALU)
+    DevBuf db_limbs;
+    bool limbs_valid = false;
+    uint32_t sweep_mfma_min = 2;
 };
 
 namespace {
@@ -156,14 +162,15 @@ void srv_drop_graphs(spiral_gpu_server* S) {
 
 void srv_free(spiral_gpu_server* S, bool keep_db = false) {
     srv_drop_graphs(S);
-    DevBuf keep;
+    DevBuf keep, keep_limbs;
     if (keep_db) {
         keep = S->db;
-        S->db.p = nullptr;
+        keep_limbs = S->db_limbs;
+        S->db.p = S->db_limbs.p = nullptr;
     }
     DevBuf* all[] = {&S->db, &S->w_left, &S->w_right, &S->w, &S->v, &S->query, &S->cv, &S->ex_raw, &S->ex_g, &S->ex_raw2, &S->ex_g2, &S->cv_raw,
                      &S->cv_g, &S->gsw, &S->key, &S->cts_keep, &S->qs, &S->acc_own, &S->raw, &S->fold_d, &S->fold_c, &S->fold_c2,
-                     &S->resp, &S->stage, &S->wire, &S->arena};  // (the arena after its pieces)
+                     &S->resp, &S->stage, &S->wire, &S->db_limbs, &S->arena};  // (the arena after its pieces)
     if (S->db_shared) S->db.p = nullptr;
     for (DevBuf* b : all) b->release();
     for (auto& e : S->ev)
@@ -176,7 +183,7 @@ void srv_free(spiral_gpu_server* S, bool keep_db = false) {
     S->side_stream = S->own_stream = nullptr;
     S->ev_fork = S->ev_join = S->ev_batch = nullptr;
     for (auto& e : S->ev) e = nullptr;
-    if (keep_db) S->db = keep;
+    if (keep_db) S->db = keep, S->db_limbs = keep_limbs;
 }
 
 // lane <-> owner bookkeeping of a shared database image
@@ -190,8 +197,48 @@ void lane_detach(spiral_gpu_server* lane) {
     lane->db_owner = nullptr;
     if (--owner->n_lanes == 0 && owner->zombie) {  // the owner was destroyed first: its image goes with its last lane
         owner->db.release();
+        owner->db_limbs.release();
         delete owner;
     }
+}
+
+// the first-dimension sweep of n queries against one database image: one pass on the matrix cores when the limb-plane image is given, else passes of
+// up to kSweepMaxBatch queries on the vector ALU (wide packed geometries), else one sweep per query
+void sweep_queries(const spiral_gpu_server* S, const uint64_t* limbs, const uint32_t* const* qs, uint64_t* const* acc, uint32_t n, uint32_t g_log, hipStream_t st) {
+    const uint32_t np = S->s.num_per, jm = 2 * S->dim0_shard;
+    if (limbs) return launch_sweep_mfma(limbs, qs, acc, n, np, jm, g_log, st);
+    const uint32_t step = sweep_batch_ok(np, jm) ? kSweepMaxBatch : 1;
+    for (uint32_t b0 = 0; b0 < n; b0 += step) {
+        const uint32_t nb = n - b0 < step ? n - b0 : step;
+        if (nb == 1)
+            launch_sweep(S->db.p, qs[b0], acc[b0], np, jm, g_log, st);
+        else
+            launch_sweep_batch(S->db.p, qs + b0, acc + b0, nb, np, jm, g_log, st);
+    }
+}
+
+// The limb-plane image for a batched sweep of n queries on the matrix cores, or nullptr when that sweep does not apply (threshold, geometry) --
+// then *rc stays 0 -- or could not be built (*rc = -1).  Built once per database load by the image's holder; never call this inside a capture.
+const uint64_t* limb_image(spiral_gpu_server* S, uint32_t n, int* rc) {
+    *rc = 0;
+    if (S->sweep_mfma_min == 0 || n < S->sweep_mfma_min || S->fold_g_log || !sweep_mfma_ok(S->s.num_per, 2 * S->dim0_shard)) return nullptr;
+    spiral_gpu_server* H = S->db_owner ? S->db_owner : S;
+    if (H->limbs_valid) return H->db_limbs.p;
+    if (!H->db_limbs.p && H->db_limbs.alloc(H->db.words)) {
+        *rc = fail("no memory for the limb-plane image of the database (%zu MiB)", H->db.words * 8 >> 20);
+        return nullptr;
+    }
+    if (hipDeviceSynchronize() != hipSuccess) {  // whatever wrote the packed image, on whichever stream
+        *rc = fail("hipDeviceSynchronize failed");
+        return nullptr;
+    }
+    launch_db_limb_planes(H->db.p, H->db_limbs.p, H->s.num_per, 2 * H->dim0_shard, S->stream);
+    if (hipStreamSynchronize(S->stream) != hipSuccess) {
+        *rc = fail("building the limb-plane image failed");
+        return nullptr;
+    }
+    H->limbs_valid = true;
+    return H->db_limbs.p;
 }
 
 // the fold needs the keys the forked conversion produces
@@ -495,6 +542,41 @@ int spiral_gpu_multiply_query_by_database(uint64_t* output, const uint64_t* reor
     return download_pk(sc, d_acc, identity_map(), output, num_per * 6);
 }
 
+int spiral_gpu_multiply_queries_by_database(uint64_t* outputs, const uint64_t* reorientedCiphertexts, size_t n, const uint64_t* database, size_t dim0,
+                                            size_t num_per) {
+    if (dim0 == 0 || num_per == 0 || n == 0) return fail("empty geometry");
+    if (n > kMaxLanes) return fail("at most %u queries per pass", kMaxLanes);
+    Scratch sc;
+    const size_t db_words = (size_t)kN * dim0 * num_per * 4, dev_words = db_device_words((uint32_t)(2 * num_per), (uint32_t)dim0);
+    const bool mfma = sweep_mfma_ok((uint32_t)num_per, (uint32_t)(2 * dim0));
+    uint64_t* d_ref = sc.upload(database, db_words);
+    uint64_t* d_db = sc.get(dev_words);
+    uint64_t* d_limbs = mfma ? sc.get(dev_words) : nullptr;
+    uint64_t* d_re = sc.upload(reorientedCiphertexts, n * (size_t)kN * dim0 * 8);
+    uint64_t* d_qs = sc.get(n * (size_t)kN * dim0 * 6);
+    uint64_t* d_acc = sc.get(n * num_per * 6 * kN);
+    if (!d_ref || !d_db || (mfma && !d_limbs) || !d_re || !d_qs || !d_acc) return fail("device allocation/upload failed");
+    launch_db_relayout(d_ref, d_db, (uint32_t)num_per, (uint32_t)dim0, 0, (uint32_t)dim0, 0, kN, 0);
+    if (mfma) launch_db_limb_planes(d_db, d_limbs, (uint32_t)num_per, (uint32_t)(2 * dim0), 0);
+    const uint32_t* qs[kMaxLanes];
+    uint64_t* acc[kMaxLanes];
+    for (size_t b = 0; b < n; b++) {
+        qs[b] = (const uint32_t*)(d_qs + b * (size_t)kN * dim0 * 6);
+        acc[b] = d_acc + b * num_per * 6 * kN;
+        launch_qs_from_reoriented(d_re + b * (size_t)kN * dim0 * 8, (uint32_t*)qs[b], (uint32_t)(2 * dim0), 0);
+    }
+    if (mfma)
+        launch_sweep_mfma(d_limbs, qs, acc, (uint32_t)n, (uint32_t)num_per, (uint32_t)(2 * dim0), 0, 0);
+    else
+        for (size_t b0 = 0; b0 < n; b0 += 2) {
+            if (n - b0 >= 2 && sweep_batch_ok((uint32_t)num_per, (uint32_t)(2 * dim0)))
+                launch_sweep_batch(d_db, qs + b0, acc + b0, 2, (uint32_t)num_per, (uint32_t)(2 * dim0), 0, 0);
+            else
+                for (size_t b = b0; b < n && b < b0 + 2; b++) launch_sweep(d_db, qs[b], acc[b], (uint32_t)num_per, (uint32_t)(2 * dim0), 0, 0);
+        }
+    return download_pk(sc, d_acc, identity_map(), outputs, n * num_per * 6);
+}
+
 int spiral_gpu_split_and_crt(uint64_t* out, const uint64_t* in, size_t num_per, uint32_t t_gsw) {
     DeviceTables tb;
     if (current_tables(&tb)) return -1;
@@ -658,6 +740,7 @@ static int srv_create(const spiral_gpu_params* p, int device, uint32_t j_begin, 
     if (const char* e = getenv("SPIRAL_FOLD_CHAIN")) S->fold_chain = atoi(e) != 0;
     if (const char* e = getenv("SPIRAL_FOLD_PAIR")) S->fold_pair = atoi(e) != 0;
     if (const char* e = getenv("SPIRAL_FOLD_BLOCKS")) S->fold_blocks = (uint32_t)strtoul(e, nullptr, 10);
+    if (const char* e = getenv("SPIRAL_SWEEP_MFMA")) S->sweep_mfma_min = (uint32_t)strtoul(e, nullptr, 10);
     if (p->direct_upload || s.stopround == 0) {
         S->pos_stride = 1;
         S->pos_first = 0;
@@ -765,6 +848,7 @@ int spiral_gpu_server_load_db(spiral_gpu_server* S, const uint64_t* database) {
     }
     st.release();
     S->have_db = true;
+    S->limbs_valid = false;
     return 0;
 }
 
@@ -789,6 +873,7 @@ int spiral_gpu_server_gen_db(spiral_gpu_server* S, uint64_t seed) {
     }
     HIP_OK(hipStreamSynchronize(S->stream));
     S->have_db = true;
+    S->limbs_valid = false;
     return 0;
 }
 
@@ -818,6 +903,7 @@ int spiral_gpu_server_load_db_items(spiral_gpu_server* S, const void* items, uin
         }))
         return -1;
     S->have_db = true;
+    S->limbs_valid = false;
     return 0;
 }
 
@@ -871,6 +957,7 @@ int spiral_gpu_server_fill_db_random(spiral_gpu_server* S, uint64_t seed) {
     launch_fill_db_random(S->db.p, S->s.num_per, S->dim0_shard, seed, S->stream);
     HIP_OK(hipStreamSynchronize(S->stream));
     S->have_db = true;
+    S->limbs_valid = false;
     return 0;
 }
 
@@ -1122,11 +1209,11 @@ int spiral_gpu_server_first_dim_batch(spiral_gpu_server* const* servers, uint32_
         if (!servers[b]) return fail("null server");
     spiral_gpu_server* S0 = servers[0];
     if (n == 1) return spiral_gpu_server_first_dim(S0);
-    if (n > kSweepMaxBatch) return fail("at most %u queries per batched sweep", kSweepMaxBatch);
+    if (n > kMaxLanes) return fail("at most %u queries per batched sweep", kMaxLanes);
     HIP_OK(hipSetDevice(S0->device));
     if (!S0->have_db) return fail("no database loaded");
-    const uint32_t* qs[kSweepMaxBatch];
-    uint64_t* acc[kSweepMaxBatch];
+    const uint32_t* qs[kMaxLanes];
+    uint64_t* acc[kMaxLanes];
     for (uint32_t b = 0; b < n; b++) {  // every lane is validated before anything is launched: a failure leaves no lane swept
         spiral_gpu_server* S = servers[b];
         if (!S->have_db) return fail("first_dim_batch: server %u has no database", b);
@@ -1138,7 +1225,10 @@ int spiral_gpu_server_first_dim_batch(spiral_gpu_server* const* servers, uint32_
         qs[b] = (const uint32_t*)S->qs.p;
         acc[b] = S->acc;
     }
-    if (!sweep_batch_ok(S0->s.num_per, 2 * S0->dim0_shard)) {
+    int rc = 0;
+    const uint64_t* limbs = limb_image(S0, n, &rc);
+    if (rc) return rc;
+    if (!limbs && !sweep_batch_ok(S0->s.num_per, 2 * S0->dim0_shard)) {
         for (uint32_t b = 0; b < n; b++)
             if (spiral_gpu_server_first_dim(servers[b])) return -1;
         return 0;
@@ -1147,7 +1237,7 @@ int spiral_gpu_server_first_dim_batch(spiral_gpu_server* const* servers, uint32_
         HIP_OK(hipEventRecord(servers[b]->ev_batch, servers[b]->stream));
         HIP_OK(hipStreamWaitEvent(S0->stream, servers[b]->ev_batch, 0));
     }
-    launch_sweep_batch(S0->db.p, qs, acc, n, S0->s.num_per, 2 * S0->dim0_shard, S0->fold_g_log, S0->stream);
+    sweep_queries(S0, limbs, qs, acc, n, S0->fold_g_log, S0->stream);
     for (uint32_t b = 0; b < n; b++) servers[b]->raw_from_acc = false;
     HIP_OK(hipEventRecord(S0->ev_batch, S0->stream));
     for (uint32_t b = 1; b < n; b++) HIP_OK(hipStreamWaitEvent(servers[b]->stream, S0->ev_batch, 0));
@@ -1478,31 +1568,19 @@ int spiral_gpu_server_run_query_batch(spiral_gpu_server* const* servers, uint32_
         HIP_OK(hipEventRecord(servers[b]->ev_batch, servers[b]->stream));
         HIP_OK(hipStreamWaitEvent(S->stream, servers[b]->ev_batch, 0));
     }
+    int rc_l = 0;
+    const uint64_t* limbs = limb_image(S, n, &rc_l);  // (not inside the capture below: it may build the image)
+    if (rc_l) return rc_l;
     auto body = [&]() {
         if (expand_lanes(S, lanes)) return -1;
         if (convert_part(S, CONV_BOTH, S->stream, false, lanes)) return -1;
-        if (sweep_batch_ok(S->s.num_per, 2 * S->dim0_shard)) {
-            // at most kSweepMaxBatch queries per pass over the database (the sweep's accumulators are registers): a batch of 5 .. 8 sweeps in two
-            // passes of about equal size
-            const uint32_t passes = (n + kSweepMaxBatch - 1) / kSweepMaxBatch;
-            for (uint32_t ps = 0, b0 = 0; ps < passes; ps++) {
-                const uint32_t nb = (n - b0 + (passes - ps) - 1) / (passes - ps);
-                const uint32_t* qs[kSweepMaxBatch];
-                uint64_t* acc[kSweepMaxBatch];
-                for (uint32_t b = 0; b < nb; b++) {
-                    qs[b] = (const uint32_t*)(S->qs.p + lanes.off[b0 + b]);
-                    acc[b] = S->acc + lanes.off[b0 + b];
-                }
-                if (nb == 1)
-                    launch_sweep(S->db.p, qs[0], acc[0], S->s.num_per, 2 * S->dim0_shard, 0, S->stream);
-                else
-                    launch_sweep_batch(S->db.p, qs, acc, nb, S->s.num_per, 2 * S->dim0_shard, 0, S->stream);
-                b0 += nb;
-            }
-        } else {  // geometries the batched kernel does not cover (fewer than 64 output columns, tiny first dimensions): one sweep per lane
-            for (uint32_t b = 0; b < n; b++)
-                launch_sweep(S->db.p, (const uint32_t*)(S->qs.p + lanes.off[b]), S->acc + lanes.off[b], S->s.num_per, 2 * S->dim0_shard, 0, S->stream);
+        const uint32_t* qs[kMaxLanes];
+        uint64_t* acc[kMaxLanes];
+        for (uint32_t b = 0; b < n; b++) {
+            qs[b] = (const uint32_t*)(S->qs.p + lanes.off[b]);
+            acc[b] = S->acc + lanes.off[b];
         }
+        sweep_queries(S, limbs, qs, acc, n, 0, S->stream);  // one pass on the matrix cores where the limb-plane image exists
         return run_fold_rounds(S, S->s.num_per, 0, S->p.nu2, S->acc, false, true, nullptr, lanes);
     };
     int rc = 0;

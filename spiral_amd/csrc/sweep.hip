@@ -5,7 +5,8 @@
 //
 // Per NTT slot z this is a (nic x JM) by (JM x 3) product per limb with nic = 2*num_per output columns
 // (ii, c) and JM = 2*dim0 terms (j, m): 6 integer MADs per 8-byte database word, so the kernel is bound
-// by streaming the database once from HBM.  MFMA does not apply (32x32->64-bit modular integer MACs).
+// by streaming the database once from HBM and the vector ALU keeps up (6 x 32x32->64-bit MADs per 7 bytes).  Batches of queries against one pass
+// over the database run on the matrix cores instead: sweep_mfma.hip.
 //
 // Device database layout (built at load time, any re-layout is internal; common.h): 64-lane tiles -- (z, block of 64
 // columns), or 64/nic slots z x nic columns when there are fewer than 64 columns -- each one sequential stream; a word is
@@ -53,10 +54,6 @@ __device__ __forceinline__ void reduce6(uint64_t (&a)[6]) {
 // One stage (ls_log = log2(num_per / G)) is the plain grouping by rank; with K = 2^k_log stages (ls_log smaller by k_log) the
 // ciphertexts of stage s -- the contiguous columns [s num_per/K, (s+1) num_per/K) -- form one contiguous [G][Ls] block, which one
 // reduce-scatter per stage turns into rank g's rows k of that stage (the sweep of stage s + 1 runs under it, server.cpp).
-__device__ __forceinline__ uint32_t acc_pos(uint32_t i0, uint32_t g_log, uint32_t ls_log) {
-    const uint32_t g = i0 & ((1u << g_log) - 1u), k = i0 >> g_log;
-    return ((((k >> ls_log) << g_log) | g) << ls_log) | (k & ((1u << ls_log) - 1u));
-}
 __device__ __forceinline__ void store_acc(uint64_t* acc, const uint64_t (&a)[6], uint32_t ic, uint32_t z, uint32_t g_log, uint32_t ls_log) {
     const uint32_t i0 = ic >> 1, c = ic & 1u;
     const uint32_t ii = acc_pos(i0, g_log, ls_log);
@@ -117,6 +114,8 @@ constexpr uint32_t kQStage = 8 * 24;  // uint4 per wave: up to 8 slots x (8 j x 
 // multiplied into NB accumulator sets, each against its own query's records (all wave-uniform, scalar loads).  The sweep has the
 // VALU headroom (6 MADs per 7 bytes at 6.4 TB/s = 5.5 T MAD/s of ~31): for throughput at the database sizes where the sweep is
 // most of a query, the stream is paid once per NB queries (spiral_gpu_server_first_dim_batch).  Single-query latency is NB = 1.
+// NB = 2 is the fallback where the matrix-core sweep (sweep_mfma.hip: up to eight queries per pass at the cost of the stream) does not apply; with
+// three and four queries per pass this kernel became VALU / LDS bound (350 / 440 us at config 2: round 5's LDS-record variant, removed).
 struct SweepBatch {
     const uint32_t* qs[kSweepMaxBatch];
     uint64_t* acc[kSweepMaxBatch];
@@ -125,17 +124,6 @@ template <int MODE, int NB = 1>
 __global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __restrict__ db, SweepBatch bt, uint32_t nic, uint32_t dim0, uint32_t g_log, uint32_t ls_log,
                                                              uint32_t icb0, uint32_t n_icb) {
     static_assert(NB == 1 || MODE == 0, "batched sweeps use the wide geometry");
-    // NB >= 3: the records of all NB queries reach the MACs through LDS instead of SGPRs.  Scalar loads cannot be pipelined deep enough --
-    // 96 SGPRs per query and group, and their L2 round trip behind a saturated HBM stream is long: with every query on the scalar path
-    // sweep_kernel<0, 4> spent 78 % of its wave-cycles waiting (SQ_WAIT_ANY) with the VALU half idle, 614 us against 315 us for NB = 2.  Here a
-    // wave fetches the next group's NB x 384 bytes with one or two coalesced vector loads per lane while it multiplies the current group, parks
-    // them in its own LDS rows and reads them back as same-address (broadcast) ds_read_b128: the multiplicands are VGPRs, nothing waits on the
-    // scalar cache.  Measured per launch at config 2 (tools/sweep_batch_time.py): 297 / 319 / 350 / 437 us for NB = 1 .. 4 (NB = 3, 4 were 413 / 614);
-    // the broadcast reads now share the limit with the VALU (NB = 2 through LDS: 324 us, no better than SGPRs; NB = 4 as two scalar + two LDS queries
-    // 455 us, as LDS-DMA loads (global_load_lds) with a vmcnt(0) per group 483 us, one or two queries' records broadcast with v_readlane out of the
-    // record register instead of LDS 480 / 510 us: all measured and dropped).
-    constexpr bool LREC = NB >= 3;
-    __shared__ __attribute__((aligned(16))) uint4 qrec[LREC ? kSweepZ * NB * 24 : 1];
     const uint32_t* __restrict__ qs = bt.qs[0];
     uint64_t* __restrict__ acc = bt.acc[0];
     constexpr bool WIDE = MODE == 0;
@@ -163,23 +151,6 @@ __global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __r
     const uint4* q = reinterpret_cast<const uint4*>(qs) + (size_t)z * dim0 * 3u;  // 3 x uint4 per j; wave-uniform when WIDE
     uint64_t a[6] = {0, 0, 0, 0, 0, 0};
     uint64_t ax[NB > 1 ? NB - 1 : 1][6] = {};  // queries 1 .. NB-1 of a batch
-    // LREC: lane t < NB * 24 holds uint4 number t of the group's records [query][j < 8][3]; lanes t - 64 hold the rest
-    uint4 r0 = {}, r1 = {};
-    uint4* const qst = qrec + (LREC ? wv * NB * 24 : 0);
-    const uint4 *rp0 = nullptr, *rp1 = nullptr;
-    if constexpr (LREC) {
-        auto rec_base = [&](uint32_t t) -> const uint4* {
-            const uint32_t b = min(t / 24u, (uint32_t)NB - 1u), off = t - b * 24u;  // (lanes beyond the last record read the last query's: never stored)
-            const uint32_t* p = bt.qs[0];
-#pragma unroll
-            for (int i = 1; i < NB; i++) p = b == (uint32_t)i ? bt.qs[i] : p;
-            return reinterpret_cast<const uint4*>(p) + (size_t)z * dim0 * 3u + off;
-        };
-        rp0 = rec_base(lane);
-        rp1 = rec_base(min(64u + lane, (uint32_t)NB * 24u - 1u));
-        r0 = rp0[(size_t)gfirst * 24u];
-        r1 = rp1[(size_t)gfirst * 24u];
-    }
     for (uint32_t g0 = gfirst; g0 < glast; g0 += 16) {  // 16 groups = 128 j = 256 terms per accumulator between reductions
         const uint32_t gend = min(g0 + 16u, glast);
 #pragma unroll 2
@@ -207,18 +178,6 @@ __global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __r
                 __builtin_amdgcn_wave_barrier();
                 qg = qst + (lane / w) * 24u;
             }
-            if constexpr (LREC) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();  // the previous group's reads of this wave's rows
-                qst[lane] = r0;
-                if (lane < (uint32_t)NB * 24u - 64u) qst[64u + lane] = r1;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const uint32_t gn = min(g + 1u, glast - 1u);  // the next group's records, in flight under this group's MACs
-                r0 = rp0[(size_t)gn * 24u];
-                r1 = rp1[(size_t)gn * 24u];
-                qg = qst;
-            }
             mac_packed_j<0>(a, qg, d);
             mac_packed_j<1>(a, qg + 3, d);
             mac_packed_j<2>(a, qg + 6, d);
@@ -230,7 +189,7 @@ __global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __r
             if constexpr (NB > 1) {
 #pragma unroll
                 for (int b = 1; b < NB; b++) {
-                    const uint4* qb = LREC ? qst + b * 24 : reinterpret_cast<const uint4*>(bt.qs[b]) + (size_t)z * dim0 * 3u + (size_t)g * 24u;
+                    const uint4* qb = reinterpret_cast<const uint4*>(bt.qs[b]) + (size_t)z * dim0 * 3u + (size_t)g * 24u;
                     mac_packed_j<0>(ax[b - 1], qb, d);
                     mac_packed_j<1>(ax[b - 1], qb + 3, d);
                     mac_packed_j<2>(ax[b - 1], qb + 6, d);
@@ -323,8 +282,6 @@ void launch_sweep_batch(const uint64_t* db, const uint32_t* const* qs, uint64_t*
     const dim3 grid((kN / kSweepZ) * (nic >> 6)), block(kSweepZ * 64);
     switch (n) {
         case 2: hipLaunchKernelGGL((sweep_kernel<0, 2>), grid, block, 0, s, db, bt, nic, dim0, g_log, ls_log, 0u, nic >> 6); break;
-        case 3: hipLaunchKernelGGL((sweep_kernel<0, 3>), grid, block, 0, s, db, bt, nic, dim0, g_log, ls_log, 0u, nic >> 6); break;
-        case 4: hipLaunchKernelGGL((sweep_kernel<0, 4>), grid, block, 0, s, db, bt, nic, dim0, g_log, ls_log, 0u, nic >> 6); break;
         default: abort();
     }
 }

@@ -15,7 +15,7 @@ Q = P * B
 
 __all__ = [
     "N", "P", "B", "Q", "make_params", "get_shape", "get_tables", "ntt_forward", "ntt_inverse", "to_ntt", "to_ntt_no_reduce", "from_ntt",
-    "multiply", "add", "mul_by_const", "automorph", "invert", "gadget_invert", "getRescaled", "multiplyQueryByDatabase", "split_and_crt",
+    "multiply", "add", "mul_by_const", "automorph", "invert", "gadget_invert", "getRescaled", "multiplyQueryByDatabase", "multiplyQueriesByDatabase", "split_and_crt",
     "foldOneFurtherDimension", "expandImproved", "scalToMat", "regevToGSW", "time_ntt", "time_ntt_digits", "response_wire_bytes", "response_from_wire",
 ]
 
@@ -148,6 +148,15 @@ def response_from_wire(params, wire, out_n: int = 2) -> np.ndarray:
 def multiplyQueryByDatabase(reoriented_cts, database, dim0, num_per) -> np.ndarray:
     out = np.zeros((num_per, 3, 2, 2, N), dtype=np.uint64)
     check(lib().spiral_gpu_multiply_query_by_database(_p(out), _p(_c(reoriented_cts)), _p(_c(database)), dim0, num_per))
+    return out
+
+
+def multiplyQueriesByDatabase(reoriented_cts_list, database, dim0, num_per) -> np.ndarray:
+    """n <= 8 queries against one pass over the database (the matrix-core sweep where the geometry allows): [n][num_per][3][2][2][N]"""
+    n = len(reoriented_cts_list)
+    re = np.ascontiguousarray(np.stack([_c(r).reshape(-1) for r in reoriented_cts_list]))
+    out = np.zeros((n, num_per, 3, 2, 2, N), dtype=np.uint64)
+    check(lib().spiral_gpu_multiply_queries_by_database(_p(out), _p(re), n, _p(_c(database)), dim0, num_per))
     return out
 
 

@@ -131,6 +131,43 @@ def test_multiply_query_by_database(sa, oracle, nu1, nu2):
     assert_eq(sa.multiplyQueryByDatabase(re, db, dim0, num_per), O.multiply_query_by_database(re, db, dim0, num_per), "sweep")
 
 
+# the batched sweep on the matrix cores (csrc/sweep_mfma.hip): num_per >= 64, dim0 a multiple of 64.  (6,6): one 128-term piece per prime and
+# one workgroup column group; (7,6): two pieces; (6,7): two column groups per z; n = 1 .. 8 queries = 1 .. 6 column tiles, the last one part
+# empty for n = 3, 5, 6, 7.  (5,6) and (6,5) fall back to the vector ALU (first dimension / columns too small) through the same entry point.
+@pytest.mark.parametrize("nu1,nu2,n", [(6, 6, 1), (6, 6, 2), (6, 6, 3), (6, 6, 4), (6, 6, 5), (6, 6, 6), (6, 6, 7), (6, 6, 8), (7, 6, 4), (6, 7, 8), (8, 6, 5),
+                                       (5, 6, 3), (6, 5, 4)])
+def test_multiply_queries_by_database(sa, oracle, nu1, nu2, n):
+    """n queries against one pass over the database == the oracle's multiplyQueryByDatabase (src/spiral.cpp:628-999) of every query"""
+    O = oracle
+    dim0, num_per = 1 << nu1, 1 << nu2
+    rng = np.random.default_rng(900 + nu1 * 64 + nu2 * 8 + n)
+    res = [O.reorient_ciphertexts(rand_ntt(rng, O, (dim0, 3, 2))) for _ in range(n)]
+    db = O.fill_db_random(nu1 * 100 + nu2 + 7, dim0 * num_per * 4 * N)
+    got = sa.multiplyQueriesByDatabase(res, db, dim0, num_per)
+    for b, re in enumerate(res):
+        assert_eq(got[b], O.multiply_query_by_database(re, db, dim0, num_per), f"query {b} of {n}")
+
+
+@pytest.mark.parametrize("vq,vd", [("max", "max"), ("limb-", "limb-"), ("limb-", "limb+"), ("wrap", "max"), ("zero", "max")])
+def test_matrix_core_sweep_extremes(sa, oracle, vq, vd):
+    """constant operands at the edges of the limb decomposition, dim0 = 256 (K = 512 terms per sum): m - 1; the values whose three signed limb
+    bytes are all -128 (top nibble 15) / all +127 (top nibble 14): the largest limb products of either sign; the first residue mod p stored as
+    a - p (2^28 - 0x808080; as a query value its top limb is 16); zero.  Every output is 2 dim0 vq vd mod m."""
+    O = oracle
+    dim0, num_per, n = 256, 64, 3
+    val = {"max": (O.P - 1, O.B - 1), "limb-": ((15 << 24) - 0x808080,) * 2, "limb+": ((14 << 24) - 0x808080 + 0xFFFFFF,) * 2,
+           "wrap": ((1 << 28) - 0x808080, O.B - 1), "zero": (0, 0)}
+    (qp, qb), (dp, db_) = val[vq], val[vd]
+    assert max(qp, dp) < O.P and max(qb, db_) < O.B
+    cts = np.zeros((dim0, 3, 2, 2, N), dtype=np.uint64)
+    cts[..., 0, :] = qp
+    cts[..., 1, :] = qb
+    re = O.reorient_ciphertexts(cts)
+    db = np.full(dim0 * num_per * 4 * N, dp | (db_ << 32), dtype=np.uint64)
+    got = sa.multiplyQueriesByDatabase([re] * n, db, dim0, num_per)
+    assert (got[..., 0, :] == (2 * dim0 * qp * dp) % O.P).all() and (got[..., 1, :] == (2 * dim0 * qb * db_) % O.B).all()
+
+
 def test_sweep_accumulator_extremes(sa, oracle):
     """all operands m-1: the largest partial sums, exercises the 256-term reduction rule with dim0 = 256"""
     O = oracle
@@ -586,11 +623,12 @@ def test_lane_created_on_the_owners_image(sa, oracle):
     owner.close()
 
 
-@pytest.mark.parametrize("nu1,nu2,n", [(4, 5, 2), (3, 6, 3), (3, 5, 4), (5, 3, 3)])
+@pytest.mark.parametrize("nu1,nu2,n", [(4, 5, 2), (3, 6, 3), (3, 5, 4), (5, 3, 3), (6, 6, 4), (6, 6, 7)])
 def test_batched_sweep_equals_single_sweeps(sa, oracle, nu1, nu2, n):
     """first_dim_batch: the queries of n lanes against one pass over the shared database image; every lane's accumulators and
     final answer equal its own first_dim() and the oracle.  (5, 3): fewer than 64 output columns, where the call falls back to
-    one sweep per lane.  Lanes run on their own streams with the whole-group graphs either side of the shared sweep."""
+    one sweep per lane; (6, 6): one pass on the matrix cores (sweep_mfma.hip), the others passes of two on the vector ALU.
+    Lanes run on their own streams with the whole-group graphs either side of the shared sweep."""
     import torch
 
     O = oracle
@@ -666,7 +704,8 @@ def test_batched_sweep_equals_single_sweeps(sa, oracle, nu1, nu2, n):
     (2, 2, 4, dict(t_gsw=5, t_exp=2, qprime_bits=19, direct_upload=1), True),             # no expansion (SpiralStream form), plain database layout
     (4, 5, 3, dict(t_gsw=14), True),                                                      # a gadget whose digits do not recompose: the two-product fold (fold_chain_kernel) with lanes
     (2, 1, 2, {}, False),                                                                  # stopround == 0
-    (3, 6, 8, dict(t_gsw=8), True), (5, 6, 5, dict(t_gsw=8), True), (4, 5, 7, dict(t_gsw=8), False),  # more than four lanes: the sweep in two passes (4 + 4, 3 + 2, 4 + 3)
+    (3, 6, 8, dict(t_gsw=8), True), (5, 6, 5, dict(t_gsw=8), True), (4, 5, 7, dict(t_gsw=8), False),  # more than two lanes: the vector-ALU sweep in passes of two
+    (6, 6, 3, dict(t_gsw=8), True), (6, 6, 8, dict(t_gsw=8), True), (7, 6, 5, dict(t_gsw=8), False),  # the sweep on the matrix cores, one pass for all lanes
     (5, 3, 6, dict(t_gsw=4), True),                                                       # six lanes on the per-lane sweep fallback
 ])
 def test_run_query_batch_equals_single_queries(sa, oracle, nu1, nu2, n, kw, graphs):
