@@ -803,14 +803,16 @@ def bench_base(args, ctx, workload, steps, warmup, primary, prog):
                     torch.cuda.synchronize()
                     dt_b = time.perf_counter() - t1
                     pipelined["batched_sweep"][str(B)] = {"queries": n_b * B, "queries_per_s": round(n_b * B / dt_b, 1), "ms_per_query_amortised": round(dt_b * 1e3 / (n_b * B), 4)}
-                pipelined["batched_sweep"]["note"] = ("B queries per pass over the database (sweep_kernel<0, B>: the 112-byte groups a lane fetches are multiplied into B "
-                                                      "accumulator sets); throughput only, every answer bit-identical to the single-query path")
+                pipelined["batched_sweep"]["note"] = ("B queries per pass over the database (sweep_mfma_kernel), each lane's expansion / conversion / fold still its own launches "
+                                                      "on its own stream; throughput only, every answer bit-identical to the single-query path")
             if args.batched_sweep:
                 # whole queries batched: every launch of the answer carries the B queries of a batch (spiral_gpu_server_run_query_batch: the
                 # expansion / conversion / lift / fold launches take a query dimension, the sweep is the batched one), one hipGraph replay per batch
                 bq = {}
                 srv.set_acc(0)  # (back to the server's own accumulators: the lanes of a batch address their buffers relative to one another)
                 for name, groups in (("2", [[0, 1]]), ("4", [[0, 1, 2, 3]]), ("8", [list(range(8))]), ("2x2", [[0, 1], [2, 3]])):
+                    for g in groups:  # the lanes of a batch on the batch's own stream (lane 0's): no cross-stream ordering around the launch sequence
+                        for i in g: lanes[i][0].set_stream(lanes[g[0]][1].cuda_stream)
                     groups = [[lanes[i][0] for i in g] for g in groups]
                     for _ in range(2):  # graph capture, untimed
                         for g in groups: sa.run_query_batch(g)
@@ -824,9 +826,9 @@ def bench_base(args, ctx, workload, steps, warmup, primary, prog):
                     dt_b = time.perf_counter() - t1
                     bq[name] = {"queries": n_b * per, "queries_per_s": round(n_b * per / dt_b, 1), "ms_per_query_amortised": round(dt_b * 1e3 / (n_b * per), 4),
                                 "ms_per_batch": round(dt_b * 1e3 / n_b / len(groups), 4)}
-                bq["note"] = ("B whole queries (different lanes: own keys, own query) per launch sequence, every launch carrying all B (gridDim.z = B) and the sweep one pass "
-                              "over the database for up to four of them (two passes at B = 8); '2x2' = two such batches of 2 in flight on two streams; throughput only -- a "
-                              "query's latency is ms_per_batch")
+                bq["note"] = ("B whole queries (different lanes: own keys, own query) per launch sequence, every launch carrying all B (gridDim.z = B) and the sweep ONE pass "
+                              "over the database for all of them on the matrix cores (sweep_mfma_kernel: i8 limb products, bit-identical accumulators); '2x2' = two such "
+                              "batches of 2 in flight on two streams; throughput only -- a query's latency is ms_per_batch")
                 pipelined["batched_query"] = bq
             for lane, _ in lanes[1:]:
                 lane.close()

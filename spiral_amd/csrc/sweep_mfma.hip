@@ -226,6 +226,7 @@ __global__ __launch_bounds__(512, 2) void sweep_mfma_kernel(const uint4* __restr
     extern __shared__ __attribute__((aligned(16))) uint4 bq[];
     constexpr int R = NT >= 5 ? 2 : 1;  // 96 items per query and piece over 512 threads: one each up to five queries
     constexpr uint32_t buf_sz = 2u * NT * 64u, W = 8;
+    constexpr bool kZeroC = NT >= 6;
     const uint32_t lane = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nk2 = dim0 >> 6, ppi = 2u * nk2, ppi_log = 31u - (uint32_t)__builtin_clz(ppi);  // ppi: pieces per item (both primes), a power of two
     const uint32_t per = (n_work + gridDim.x - 1u) / gridDim.x, w0 = min(blockIdx.x * per, n_work), w1 = min(w0 + per, n_work);
@@ -272,15 +273,32 @@ __global__ __launch_bounds__(512, 2) void sweep_mfma_kernel(const uint4* __restr
         const u32x4 nib = d[6];
         a[3][0] = v4i{(int)(nib.x & 0x0F0F0F0Fu), (int)(nib.y & 0x0F0F0F0Fu), (int)(nib.z & 0x0F0F0F0Fu), (int)(nib.w & 0x0F0F0F0Fu)};
         a[3][1] = v4i{(int)((nib.x >> 4) & 0x0F0F0F0Fu), (int)((nib.y >> 4) & 0x0F0F0F0Fu), (int)((nib.z >> 4) & 0x0F0F0F0Fu), (int)((nib.w >> 4) & 0x0F0F0F0Fu)};
-#pragma unroll
-        for (int c = 0; c < 2; c++)
+        // the first piece of a prime starts the sums.  NT = 6: its chunk-0 products take the constant 0 as C (the second copy of the loop costs the
+        // narrower kernels 3 %, the 96 v_movs it saves cost this one 6 %); NT < 6: the registers are zeroed after the prime's last piece
+        if (kZeroC && (g & (nk2 - 1u)) == 0) {
 #pragma unroll
             for (int t = 0; t < NT; t++) {
-                const uint4 bv = bbuf[(c * NT + t) * 64];
+                const uint4 bv = bbuf[t * 64];
                 const v4i b = v4i{(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w};
 #pragma unroll
-                for (int i = 0; i < 4; i++) acc[i][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i][c], b, acc[i][t], 0, 0, 0);
+                for (int i = 0; i < 4; i++) acc[i][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i][0], b, v4i{0, 0, 0, 0}, 0, 0, 0);
             }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const uint4 bv = bbuf[t * 64];
+                const v4i b = v4i{(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[i][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i][0], b, acc[i][t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const uint4 bv = bbuf[(NT + t) * 64];
+            const v4i b = v4i{(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[i][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i][1], b, acc[i][t], 0, 0, 0);
+        }
         {
             const u32x4* src = piece_ptr(g + 1u);  // the next piece, in flight under this one's products
 #pragma unroll
@@ -314,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void sweep_mfma_kernel(const uint4* __restr
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        if (p_end == nk2 || p_end == 0) {
+        if (!kZeroC && (p_end == nk2 || p_end == 0)) {
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
