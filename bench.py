@@ -830,6 +830,23 @@ def bench_base(args, ctx, workload, steps, warmup, primary, prog):
                               "over the database for all of them on the matrix cores (sweep_mfma_kernel: i8 limb products, bit-identical accumulators); '2x2' = two such "
                               "batches of 2 in flight on two streams; throughput only -- a query's latency is ms_per_batch")
                 pipelined["batched_query"] = bq
+                # the batched sweep's own roofline: one launch of sweep_mfma_kernel for B queries (HIP events on the launch stream, 12 launches), against
+                # the bytes ONE pass has to move: the database once (SURVEY 8d's 8 bytes per word), B queries' records and accumulators
+                sk = {}
+                for ln, _ in lanes: ln.run_pre()
+                torch.cuda.synchronize()
+                for B in (2, 4, 5, 8):
+                    group = [ln for ln, _ in lanes[:B]]
+                    sa.time_sweep_batch(group, 2)
+                    ms_b = sa.time_sweep_batch(group, 12)
+                    one = srv.sweep_bytes()
+                    db_b = shp.dim0 // world * shp.num_per * 4 * 2048 * 8
+                    alg = db_b + B * (one - db_b)
+                    sk[str(B)] = {"avg_launch_ms": round(ms_b, 4), "algorithmic_bytes_per_launch": alg, "achieved": round(alg / (ms_b * 1e-3) / 1e9, 1),
+                                  "frac": round(alg / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "queries_x_database_bytes_per_s": round(B * db_b / (ms_b * 1e-3) / 1e9, 1)}
+                sk["note"] = ("bound: hbm, peak %d GB/s; `achieved` counts the database once per launch -- per query the pass streams "
+                              "`queries_x_database_bytes_per_s` GB/s of database" % HBM_PEAK_GBPS)
+                pipelined["batched_sweep_kernel"] = sk
             for lane, _ in lanes[1:]:
                 lane.close()
         # untimed: the reference's stage buckets (src/spiral.cpp:246-257) from one eager pass with HIP events

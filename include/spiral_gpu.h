@@ -202,27 +202,34 @@ int spiral_gpu_server_expand(spiral_gpu_server *s);    /* expandImproved + reord
 int spiral_gpu_server_convert(spiral_gpu_server *s);   /* scalToMat x dim0, regevToGSW x nu2, Q_neg   */
 int spiral_gpu_server_first_dim(spiral_gpu_server *s); /* multiplyQueryByDatabase on this shard       */
 int spiral_gpu_server_lift(spiral_gpu_server *s, int reduce_first); /* nttInvAndCrtLiftCiphertexts     */
-/* Throughput, beyond the reference (which answers one query at a time): multiplyQueryByDatabase for the queries of n <= 4
+/* Throughput, beyond the reference (which answers one query at a time): multiplyQueryByDatabase for the queries of n <= 8
  * servers that share one database image (an owner and its lanes, create_lane) in ONE pass over the database -- server b's
- * converted query against the image into server b's accumulators, each bit-identical to its own first_dim().  Asynchronous:
+ * converted query against the image into server b's accumulators, each bit-identical to its own first_dim().  The pass runs on
+ * the matrix cores (csrc/sweep_mfma.hip: both operands as signed 8-bit limbs, v_mfma_i32_16x16x64_i8, exact recombination mod
+ * the primes): at config 2 two to five queries take the time of one (0.30 ms), eight take 0.39 ms.  It reads a second image of the
+ * database, the "limb planes" -- as large as the first, built on the device by the image's owner the first time a batch needs it
+ * and again after the database is reloaded; SPIRAL_SWEEP_MFMA=0 (read at create) turns it off.  Without it (that switch, fewer
+ * than 128 output columns, a first dimension that is not a multiple of 64 or above 2048) the call makes passes of two queries
+ * on the vector ALU.  Asynchronous:
  * the launch runs on servers[0]'s stream and the other lanes' streams are ordered around it with events, so per lane the
  * sequence run_pre(lane) ... first_dim_batch(all) ... run_post(lane, 0) needs no host synchronisation.  Pays where the sweep is
  * most of a query (large databases); a single query's latency is first_dim().
  * Every server is checked (same image and layout, database present, query converted since its last set_query) before anything is
  * launched: a failing call leaves no lane swept.  Geometries with fewer than 64 output columns (nu2 <= 4: 2 num_per < 64) or without the
  * packed database layout have no batched kernel: the call then runs one first_dim() per server, in order -- same results, no shared pass.
- * The lanes are ordered with hipEventRecord / hipStreamWaitEvent on their streams: call it OUTSIDE stream capture (none of the
- * lanes' streams may be capturing a hipGraph; run_pre / run_post capture and replay their own groups either side of it). */
+ * The lanes are ordered with hipEventRecord / hipStreamWaitEvent on their streams (a lane on servers[0]'s own stream needs none and
+ * costs none): call it OUTSIDE stream capture (none of the lanes' streams may be capturing a hipGraph; run_pre / run_post capture
+ * and replay their own groups either side of it). */
 int spiral_gpu_server_first_dim_batch(spiral_gpu_server *const *servers, uint32_t n);
 /* The same idea for the WHOLE answer: n <= 8 queries -- one per server, an owner and its lanes (create_lane), equal parameters, each with its
  * own client's public parameters and query -- as one launch sequence in which every launch carries all n queries: the expansion, conversion,
  * lift, folding and switch kernels take a query dimension (the reference runs them once per query, src/spiral.cpp:1664-1743, 1850-2025,
- * 1349-1410, inside process_crtd_query :2337-2406) and the sweep is first_dim_batch's (two passes over the database for n = 5 .. 8: a pass carries at most four
- * queries).  A query's ~50 dependent launches outside the sweep are
+ * 1349-1410, inside process_crtd_query :2337-2406) and the sweep is first_dim_batch's: one pass over the database for all n on the matrix
+ * cores.  A query's ~50 dependent launches outside the sweep are
  * launch-bound (~5 us each whatever they carry), so n queries cost little more than one there.  Throughput only: each query's latency is the
  * batch's.  Afterwards every server's buffers (accumulators, GSW matrices, final ciphertext, response) hold exactly what its own run_query
  * would have left.  Runs on servers[0]'s stream -- one hipGraph replay per batch when servers[0] has use_graphs on -- with the other lanes'
- * streams ordered around it by events (call it outside stream capture).  Needs the default schedule on every server: own accumulators, no
+ * streams ordered around it by events (call it outside stream capture; ~20 us per batch and other stream: put the lanes of a batch on one stream).  Needs the default schedule on every server: own accumulators, no
  * keep_cts, no split / sharded / staged options; every server is checked before anything is launched.  n = 1 is run_query. */
 int spiral_gpu_server_run_query_batch(spiral_gpu_server *const *servers, uint32_t n);
 int spiral_gpu_server_fold(spiral_gpu_server *s);      /* foldOneFurtherDimension x nu2               */
@@ -326,6 +333,8 @@ int spiral_gpu_server_write_raw(spiral_gpu_server *s, const uint64_t *raw_cts);
 /* measurement helper: average duration (ms) of the sweep kernel alone over `iters` launches, timed
  * with HIP events on the server stream */
 int spiral_gpu_server_time_sweep(spiral_gpu_server *s, int iters, float *avg_ms);
+/* the same for first_dim_batch's kernel launch alone: the (already converted) queries of the n servers, `iters` launches */
+int spiral_gpu_server_time_sweep_batch(spiral_gpu_server *const *servers, uint32_t n, int iters, float *avg_ms);
 /* algorithmic bytes of one sweep on this shard: DB + query records + accumulators */
 uint64_t spiral_gpu_server_sweep_bytes(spiral_gpu_server *s);
 /* bytes one launch actually has to move on this device: the database in its device layout (two 28-bit residues

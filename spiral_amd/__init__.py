@@ -8,4 +8,4 @@ used by the parity tests and the benchmark.  numpy uint64 arrays carry the refer
 from ._lib import PackShape, Params, Shape, SpiralGpuError, build, lib  # noqa: F401
 from .ops import *  # noqa: F401,F403
 from .pack import PackServer, fastMultiplyQueryByDatabaseDim1, get_pack_shape, pack  # noqa: F401
-from .server import Server, first_dim_batch, run_query_batch  # noqa: F401
+from .server import Server, first_dim_batch, run_query_batch, time_sweep_batch  # noqa: F401

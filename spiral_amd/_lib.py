@@ -140,6 +140,7 @@ PROTOTYPES = {
     "spiral_gpu_server_read": (C.c_int, [C.c_void_p, C.c_int, U64P]),
     "spiral_gpu_server_write_raw": (C.c_int, [C.c_void_p, U64P]),
     "spiral_gpu_server_time_sweep": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
+    "spiral_gpu_server_time_sweep_batch": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.c_int, C.POINTER(C.c_float)]),
     "spiral_gpu_server_sweep_bytes": (C.c_uint64, [C.c_void_p]),
     "spiral_gpu_server_sweep_device_bytes": (C.c_uint64, [C.c_void_p]),
     "spiral_gpu_pack_get_shape": (C.c_int, [C.POINTER(Params), C.c_uint32, C.POINTER(PackShape)]),

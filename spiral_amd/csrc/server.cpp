@@ -1933,6 +1933,35 @@ int spiral_gpu_server_time_sweep(spiral_gpu_server* S, int iters, float* avg_ms)
     return 0;
 }
 
+int spiral_gpu_server_time_sweep_batch(spiral_gpu_server* const* servers, uint32_t n, int iters, float* avg_ms) {
+    if (!servers || !avg_ms || iters <= 0 || n == 0 || n > kMaxLanes) return fail("bad argument");
+    spiral_gpu_server* S = servers[0];
+    if (!S) return fail("null server");
+    HIP_OK(hipSetDevice(S->device));
+    const uint32_t* qs[kMaxLanes];
+    uint64_t* acc[kMaxLanes];
+    for (uint32_t b = 0; b < n; b++) {
+        spiral_gpu_server* L = servers[b];
+        if (!L || !L->have_db || !L->have_records || L->db.p != S->db.p || L->device != S->device || L->dim0_shard != S->dim0_shard || L->fold_g_log != S->fold_g_log || L->sweep_k_log)
+            return fail("time_sweep_batch: server %u is not a converted lane of server 0's database image", b);
+        qs[b] = (const uint32_t*)L->qs.p;
+        acc[b] = L->acc;
+        L->raw_from_acc = false;
+    }
+    int rc = 0;
+    const uint64_t* limbs = limb_image(S, n, &rc);
+    if (rc) return rc;
+    HIP_OK(hipDeviceSynchronize());  // (the lanes' streams: their records are complete)
+    HIP_OK(hipEventRecord(S->ev[0], S->stream));
+    for (int i = 0; i < iters; i++) sweep_queries(S, limbs, qs, acc, n, S->fold_g_log, S->stream);
+    HIP_OK(hipEventRecord(S->ev[1], S->stream));
+    HIP_OK(hipStreamSynchronize(S->stream));
+    float ms = 0;
+    HIP_OK(hipEventElapsedTime(&ms, S->ev[0], S->ev[1]));
+    *avg_ms = ms / iters;
+    return 0;
+}
+
 uint64_t spiral_gpu_server_sweep_device_bytes(spiral_gpu_server* S) {
     if (!S) return 0;
     // what one launch has to move on this device: the database in its device layout (7 bytes per word when packed),

@@ -20,9 +20,17 @@ def _p(a: np.ndarray):
 
 
 def first_dim_batch(servers):
-    """one pass over the database for the (converted) queries of up to four servers sharing one image; see include/spiral_gpu.h"""
+    """one pass over the database for the (converted) queries of up to eight servers sharing one image; see include/spiral_gpu.h"""
     arr = (C.c_void_p * len(servers))(*[s.h for s in servers])
     check(lib().spiral_gpu_server_first_dim_batch(arr, len(servers)))
+
+
+def time_sweep_batch(servers, iters: int = 20) -> float:
+    """average ms of first_dim_batch's sweep launch alone (HIP events on servers[0]'s stream)"""
+    arr = (C.c_void_p * len(servers))(*[s.h for s in servers])
+    ms = C.c_float()
+    check(lib().spiral_gpu_server_time_sweep_batch(arr, len(servers), iters, C.byref(ms)))
+    return ms.value
 
 
 def run_query_batch(servers):

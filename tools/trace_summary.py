@@ -9,7 +9,7 @@ from collections import defaultdict
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-sweeps = [i for i, r in enumerate(rows) if "sweep_kernel" in r["Kernel_Name"]]
+sweeps = [i for i, r in enumerate(rows) if "sweep_kernel" in r["Kernel_Name"] or "sweep_mfma_kernel" in r["Kernel_Name"]]
 nq = len(sweeps)
 which = int(sys.argv[sys.argv.index("--query") + 1]) if "--query" in sys.argv else nq // 2
 last = sweeps[which]
