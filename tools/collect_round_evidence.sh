@@ -17,12 +17,29 @@ python tools/trace_summary.py $O/kt/*/*_kernel_trace.csv --timeline --query 40 >
 python tools/trace_summary.py $O/kt/*/*_kernel_trace.csv --timeline --query 73 > $O/${R}_one_query_timeline_sampled_step.txt
 python tools/kernel_avg.py $O/kt/*/*_kernel_trace.csv "" --by-grid > $O/${R}_kernel_avg_by_grid.txt
 rm -rf $O/kt
-# four whole queries per launch sequence (run_query_batch): times for B = 1 .. 4, and the timeline of one B = 4 batch
-python tools/batch_query.py 1 2 3 4 6 8 > $O/${R}_batch_times.txt 2>&1
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/ktb -- python3 tools/batch_query.py 4 --reps=10 > $O/ktb.log 2>&1
-python tools/trace_summary.py $O/ktb/*/*_kernel_trace.csv --timeline --query 20 > $O/${R}_one_query_timeline_B4.txt
+# B whole queries per launch sequence (run_query_batch): times for B = 1 .. 8, the same with every lane on its own stream, and the timelines of one B = 4 and one B = 8 batch
+python tools/batch_query.py 1 2 3 4 5 6 7 8 > $O/${R}_batch_times.txt 2>&1
+python tools/batch_query.py 2 4 8 --streams=1 > $O/${R}_batch_times_own_streams.txt 2>&1
+for B in 4 8; do
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/ktb -- python3 tools/batch_query.py $B --reps=10 > $O/ktb.log 2>&1
+python tools/trace_summary.py $O/ktb/*/*_kernel_trace.csv --timeline --query 20 > $O/${R}_one_query_timeline_B$B.txt
 rm -rf $O/ktb
-python tools/sweep_batch_time.py > $O/${R}_sweep_batch_time.txt 2>&1
+done
+# the batched sweep on the matrix cores: bit-identity against the single-query sweep on random inputs + kernel durations for 1 .. 8 queries per pass
+# (rocprofv3 kernel trace: the tool's own wall figures include the host's event ordering of eight streams), then its counters
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktm -- python3 tools/sweep_mfma_check.py --reps=4 > $O/${R}_sweep_mfma_check.txt 2>&1
+python3 - >> $O/${R}_sweep_mfma_check.txt <<PY
+import csv, glob
+for r in csv.DictReader(open(glob.glob("$O/ktm/*/*_kernel_stats.csv")[0])):
+    if "sweep" in r["Name"]: print("%-50s calls %4s avg %8.1f us  min %8.1f us" % (r["Name"].split("(")[0][-50:], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3))
+PY
+rm -rf $O/ktm
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pm1 -- python3 tools/sweep_mfma_check.py --reps=2 > $O/pm1.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pm2 -- python3 tools/sweep_mfma_check.py --reps=2 > $O/pm2.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pm3 -- python3 tools/sweep_mfma_check.py --reps=2 > $O/pm3.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pm4 -- python3 tools/sweep_mfma_check.py --reps=2 > $O/pm4.log 2>&1
+python tools/pmc_summary.py $O/pm1/*/*_counter_collection.csv $O/pm2/*/*_counter_collection.csv $O/pm3/*/*_counter_collection.csv $O/pm4/*/*_counter_collection.csv > $O/${R}_sweep_mfma_counters.json
+rm -rf $O/pm1 $O/pm2 $O/pm3 $O/pm4
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 4 --warmup 1 $F --no-graphs > $O/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 4 --warmup 1 $F --no-graphs > $O/pmc_write.log 2>&1
 cp $O/pmc_fetch/*/*_counter_collection.csv $O/${R}_pmc_fetch_size_counter_collection.csv
@@ -31,7 +48,7 @@ timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ
 timeout 600 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq2 -- python3 bench.py --steps 2 --warmup 1 $F --no-graphs > $O/pmc_sq2.log 2>&1
 python tools/pmc_summary.py $O/pmc_sq1/*/*_counter_collection.csv $O/pmc_sq2/*/*_counter_collection.csv > $O/${R}_sq_counters_per_kernel.json
 rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq1 $O/pmc_sq2
-# the same counters for a B = 4 batch (sweep_kernel<0, 4> and the batched transform launches)
+# the same counters for a B = 4 batch (the batched transform and product launches)
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/pmc_b4 -- python3 tools/batch_query.py 4 --reps=2 > $O/pmc_b4.log 2>&1
 python tools/pmc_summary.py $O/pmc_b4/*/*_counter_collection.csv > $O/${R}_sq_counters_batch4.json
 rm -rf $O/pmc_b4
