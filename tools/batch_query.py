@@ -4,7 +4,7 @@ usage: tools/batch_query.py [B ...] [--reps=40] [--nu1=8 --nu2=7] [--streams=1] 
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-if any(a.startswith('--streams') for a in sys.argv): import torch  # (before the library initialises the device)
+import torch  # (before the library initialises the device)
 import spiral_amd as sa
 
 Bs = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [1, 2, 4, 8]
@@ -22,10 +22,10 @@ for ln in lanes:  # every lane its own keys and query
     ln.set_pub_params(mk((s.n_left, 2, pg.t_exp)), mk((s.n_right, 2, pg.t_exp_right)), mk((3, 2 * pg.t_conv)), mk((3, 2 * pg.t_conv)))
     ln.set_query(mk((s.n_query_cts, 2)))
     ln.use_graphs(True)
-if int(opts.get("streams", 0)):
-    streams = [torch.cuda.Stream() for _ in lanes]
-    for ln, st in zip(lanes, streams):
-        ln.set_stream(st.cuda_stream)
+# one stream for all lanes (not the legacy default stream, whose implicit synchronisation costs a batch 5-10 %), or one per lane
+streams = [torch.cuda.Stream() for _ in lanes] if int(opts.get("streams", 0)) else [torch.cuda.Stream()] * len(lanes)
+for ln, st in zip(lanes, streams):
+    ln.set_stream(st.cuda_stream)
 for B in Bs:
     group = lanes[:B]
     for _ in range(5):
