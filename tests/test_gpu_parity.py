@@ -698,6 +698,56 @@ def test_batched_sweep_equals_single_sweeps(sa, oracle, nu1, nu2, n):
         srv.close()
 
 
+def test_batch_without_the_matrix_core_image_and_after_a_reload(sa, oracle, monkeypatch):
+    """(6, 6) is a geometry the matrix-core sweep covers.  SPIRAL_SWEEP_MFMA=0 (read when a handle is created): the same batch sweeps in passes of two on
+    the vector ALU (2 + 2 + 1 for five lanes).  With the image: reloading the database drops it -- the next batch rebuilds it from the new contents."""
+    O = oracle
+    from spiral_amd import server as SV
+
+    kw = dict(t_gsw=8)
+    po, pg = O.make_params(6, 6, **kw), sa.make_params(6, 6, **kw)
+    s = O.shape_of(po)
+    n = 5
+    clients = [O.Client(po, seed=300 + b) for b in range(n)]
+    pps = [cl.pub_params() for cl in clients]
+    qs = [cl.query((97 * b + 5) % (s.dim0 * s.num_per)) for b, cl in enumerate(clients)]
+
+    def answers(seed):
+        db = O.gen_db(po, seed)
+        return [O.answer(po, q, *pp, db) for q, pp in zip(qs, pps)]
+
+    def lanes_on(seed):
+        owner = sa.Server(pg)
+        owner.gen_db(seed)
+        lanes = [owner] + [sa.Server(pg, share_db_of=owner) for _ in range(n - 1)]
+        for srv, pp, q in zip(lanes, pps, qs):
+            srv.set_pub_params(*pp)
+            srv.set_query(q)
+            srv.use_graphs(True)
+        return lanes
+
+    want = {seed: answers(seed) for seed in (11, 12)}
+    monkeypatch.setenv("SPIRAL_SWEEP_MFMA", "0")
+    lanes = lanes_on(11)
+    sa.run_query_batch(lanes)
+    for b, srv in enumerate(lanes):
+        srv.sync()
+        assert_eq(srv.read(SV.BUF_FINAL), want[11][b], f"vector-ALU passes, lane {b}")
+    for srv in reversed(lanes):
+        srv.close()
+    monkeypatch.delenv("SPIRAL_SWEEP_MFMA")
+    lanes = lanes_on(11)
+    for seed in (11, 12, 11):  # the image follows the database: built, rebuilt after each reload
+        lanes[0].gen_db(seed)
+        for rnd in range(2):  # capture, replay
+            sa.run_query_batch(lanes)
+            for b, srv in enumerate(lanes):
+                srv.sync()
+                assert_eq(srv.read(SV.BUF_FINAL), want[seed][b], f"database {seed}, run {rnd}, lane {b}")
+    for srv in reversed(lanes):
+        srv.close()
+
+
 @pytest.mark.parametrize("nu1,nu2,n,kw,graphs", [
     (3, 6, 2, dict(t_gsw=8), True), (3, 6, 4, dict(t_gsw=8), True), (5, 6, 2, dict(t_gsw=8), False), (5, 6, 4, dict(t_gsw=8), True),
     (5, 3, 3, dict(t_gsw=4), True),                                                       # fewer than 64 output columns: one sweep per lane inside the sequence
