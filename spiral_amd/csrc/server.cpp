@@ -78,7 +78,7 @@ struct spiral_gpu_server {
     // planes": built from db on first use by the image's holder (the owner of a shared image), as large as db, dropped when db is reloaded.
     // SPIRAL_SWEEP_MFMA=n sets the threshold (0 = never: at most kSweepMaxBatch queries per pass, on the vector ALU)
     DevBuf db_limbs;
-    bool limbs_valid = false;
+    bool limbs_valid = false, limbs_refused = false;  // refused: the allocation failed once, do not try again
     uint32_t sweep_mfma_min = 2;
 };
 
@@ -221,11 +221,15 @@ void sweep_queries(const spiral_gpu_server* S, const uint64_t* limbs, const uint
 // then *rc stays 0 -- or could not be built (*rc = -1).  Built once per database load by the image's holder; never call this inside a capture.
 const uint64_t* limb_image(spiral_gpu_server* S, uint32_t n, int* rc) {
     *rc = 0;
-    if (S->sweep_mfma_min == 0 || n < S->sweep_mfma_min || S->fold_g_log || !sweep_mfma_ok(S->s.num_per, 2 * S->dim0_shard)) return nullptr;
+    if (S->sweep_mfma_min == 0 || n < S->sweep_mfma_min || !sweep_mfma_ok(S->s.num_per, 2 * S->dim0_shard)) return nullptr;
     spiral_gpu_server* H = S->db_owner ? S->db_owner : S;
     if (H->limbs_valid) return H->db_limbs.p;
+    if (H->limbs_refused) return nullptr;
     if (!H->db_limbs.p && H->db_limbs.alloc(H->db.words)) {
-        *rc = fail("no memory for the limb-plane image of the database (%zu MiB)", H->db.words * 8 >> 20);
+        // the second image does not fit beside the first (databases beyond ~120 GiB on one device): the batch sweeps in passes of two on the vector ALU
+        fprintf(stderr, "spiral_gpu: no memory for the limb-plane image of the database (%zu MiB): batched sweeps stay on the vector ALU\n", (size_t)(H->db.words * 8 >> 20));
+        (void)hipGetLastError();
+        H->limbs_refused = true;
         return nullptr;
     }
     if (hipDeviceSynchronize() != hipSuccess) {  // whatever wrote the packed image, on whichever stream
