@@ -911,6 +911,7 @@ def bench_replicas(args, ctx, prog, batch=8, n_batches=15):
     lanes = [owner] + [sa.Server(pg, ctx.local_rank, share_db_of=owner) for _ in range(batch - 1)]
     pub, query = synth_inputs(np, sa, pg, shp)
     for ln in lanes:
+        ln.set_stream(stream.cuda_stream)  # the lanes of a batch on the batch's stream: no cross-stream ordering around the launch sequence
         ln.set_pub_params(*pub)
         ln.set_query(query)
         ln.use_graphs(True)

@@ -1,5 +1,5 @@
 """the batched sweep on the matrix cores (sweep_mfma.hip) against the single-query sweep on the same random database and random query
-records: accumulators of every lane must be bit-identical; then wall us per launch for B = 1 .. 8 queries per pass.
+records: accumulators of every lane must be bit-identical; then wall us per launch for B = 1 .. 8 queries per pass (back-to-back launches on one stream).
   python tools/sweep_mfma_check.py [--nu1=8 --nu2=7 --reps=30 --min=1]      (--min: SPIRAL_SWEEP_MFMA threshold, 1 = every batch size)"""
 import os, sys, time
 opts = dict(a[2:].split("=") for a in sys.argv[1:] if a.startswith("--"))
@@ -20,7 +20,9 @@ owner.fill_db_random(3)
 lanes = [owner] + [sa.Server(pg, share_db_of=owner) for _ in range(nl - 1)]
 want, accs = [], []
 acc_words = s.num_per * 6 * sa.N  # PK words: [num_per][3][2][N]
+stream = torch.cuda.Stream()  # one stream for all lanes: first_dim_batch then needs no event ordering between them
 for ln in lanes:
+    ln.set_stream(stream.cuda_stream)
     accs.append(torch.zeros(acc_words, dtype=torch.int64, device="cuda"))
     ln.set_acc(accs[-1].data_ptr())
     ln.set_pub_params(mk((s.n_left, 2, pg.t_exp)), mk((s.n_right, 2, pg.t_exp_right)), mk((3, 2 * pg.t_conv)), mk((3, 2 * pg.t_conv)))
