@@ -147,6 +147,16 @@ __device__ __forceinline__ uint64_t rescale_dev(uint64_t a, uint64_t inp_mod, ui
     return (neg && res != 0) ? out_mod - res : res;
 }
 
+// 28-bit field T of a 112-byte group of the packed database (sweep.hip, sweep_mfma.hip, pack.hip)
+template <int T>
+__device__ __forceinline__ uint32_t field28(const uint32_t (&d)[28]) {
+    constexpr uint32_t bit = 28u * T, w = bit >> 5, sh = bit & 31u;
+    if constexpr (sh <= 4)
+        return (d[w] >> sh) & 0xFFFFFFFu;
+    else
+        return __builtin_amdgcn_alignbit(d[w + 1], d[w], sh) & 0xFFFFFFFu;
+}
+
 // position of ciphertext i0 in the sweep's accumulator buffer (sweep.hip: [stage][rank][ct])
 __device__ __forceinline__ uint32_t acc_pos(uint32_t i0, uint32_t g_log, uint32_t ls_log) {
     const uint32_t g = i0 & ((1u << g_log) - 1u), k = i0 >> g_log;

@@ -33,14 +33,6 @@ __device__ __forceinline__ void store_acc1(uint64_t* acc, const uint64_t (&a)[4]
 // block -> tile mapping keeps the workgroups that share a z-group's query records on one XCD.
 constexpr uint32_t kSweep1Z = 16, kSweep1Row = 64 * 2 + 1;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-template <int T>
-__device__ __forceinline__ uint32_t field28(const uint32_t (&d)[28]) {  // 28-bit field T of a 112-byte group
-    constexpr uint32_t bit = 28u * T, w = bit >> 5, sh = bit & 31u;
-    if constexpr (sh <= 4)
-        return (d[w] >> sh) & 0xFFFFFFFu;
-    else
-        return __builtin_amdgcn_alignbit(d[w + 1], d[w], sh) & 0xFFFFFFFu;
-}
 template <int W>
 __device__ __forceinline__ void mac4_packed(uint64_t (&a)[4], uint4 q, const uint32_t (&d)[28]) {
     const uint32_t bl = field28<2 * W>(d), bh = field28<2 * W + 1>(d);

@@ -78,14 +78,6 @@ constexpr uint32_t kSweepZ = SPIRAL_SWEEP_Z;  // tools/build_variants.sh can ove
 constexpr uint32_t kSweepRow = 64 * 3 + 1;    // packed results per z in LDS, +1 word of padding against bank conflicts
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <int T>
-__device__ __forceinline__ uint32_t field28(const uint32_t (&d)[28]) {  // 28-bit field T of a 112-byte group
-    constexpr uint32_t bit = 28u * T, w = bit >> 5, sh = bit & 31u;
-    if constexpr (sh <= 4)
-        return (d[w] >> sh) & 0xFFFFFFFu;
-    else
-        return __builtin_amdgcn_alignbit(d[w + 1], d[w], sh) & 0xFFFFFFFu;
-}
 // j = JJ of the group: fields 4JJ .. 4JJ+3 = (p, b) of m = 0, (p, b) of m = 1, against the 12-dword query record of that j
 template <int JJ>
 __device__ __forceinline__ void mac_packed_j(uint64_t (&a)[6], const uint4* q, const uint32_t (&d)[28]) {

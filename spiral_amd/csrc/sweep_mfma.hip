@@ -34,14 +34,6 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr uint32_t kLimbBias = 0x808080u;
 
-template <int T>
-__device__ __forceinline__ uint32_t field28_of(const uint32_t (&d)[28]) {
-    constexpr uint32_t bit = 28u * T, w = bit >> 5, sh = bit & 31u;
-    if constexpr (sh <= 4)
-        return (d[w] >> sh) & 0xFFFFFFFu;
-    else
-        return __builtin_amdgcn_alignbit(d[w + 1], d[w], sh) & 0xFFFFFFFu;
-}
 __device__ __forceinline__ uint32_t limb_word(uint32_t a, uint32_t m) {  // w = a'' + bias of residue a mod m
     return (a >= (1u << 28) - kLimbBias ? a - m : a) + kLimbBias;
 }
@@ -49,8 +41,8 @@ template <int E>
 __device__ __forceinline__ void limbs_of_group(const uint32_t (&d)[28], uint32_t (&wp)[16], uint32_t (&wb)[16]) {
     if constexpr (E < 16) {
         constexpr int JJ = E >> 1, M = E & 1;
-        wp[E] = limb_word(field28_of<4 * JJ + 2 * M>(d), kP);
-        wb[E] = limb_word(field28_of<4 * JJ + 2 * M + 1>(d), kB);
+        wp[E] = limb_word(field28<4 * JJ + 2 * M>(d), kP);
+        wb[E] = limb_word(field28<4 * JJ + 2 * M + 1>(d), kB);
         limbs_of_group<E + 1>(d, wp, wb);
     }
 }
