@@ -698,6 +698,44 @@ def test_batched_sweep_equals_single_sweeps(sa, oracle, nu1, nu2, n):
         srv.close()
 
 
+@pytest.mark.parametrize("G", [2, 8])
+def test_matrix_core_sweep_groups_accumulators_by_fold_rank(sa, oracle, G):
+    """first_dim_batch on lanes prepared for a distributed fold over G ranks (set_fold_ranks: the sweep writes ciphertext ii = g + G k at [g][k], sweep.hip
+    acc_pos): the matrix-core sweep honours the same layout -- every lane's accumulator words equal what its own first_dim() writes."""
+    import torch
+
+    pg = sa.make_params(6, 6, t_gsw=8)
+    s = sa.get_shape(pg)
+    rng = np.random.default_rng(77)
+    mk = lambda shape: np.stack([rng.integers(0, m, size=shape + (N,), dtype=np.uint64) for m in (sa.P, sa.B)], axis=-2)
+    owner = sa.Server(pg)
+    owner.fill_db_random(5)
+    lanes = [owner] + [sa.Server(pg, share_db_of=owner) for _ in range(2)]
+    accs, want = [], []
+    for ln in lanes:
+        ln.set_fold_ranks(G)
+        accs.append(torch.zeros(s.num_per * 6 * N, dtype=torch.int64, device="cuda"))
+        ln.set_acc(accs[-1].data_ptr())
+        ln.set_pub_params(mk((s.n_left, 2, pg.t_exp)), mk((s.n_right, 2, pg.t_exp_right)), mk((3, 2 * pg.t_conv)), mk((3, 2 * pg.t_conv)))
+        ln.set_query(mk((s.n_query_cts, 2)))
+        ln.run_pre()
+        ln.first_dim()
+        ln.sync()
+        torch.cuda.synchronize()
+        want.append(accs[-1].clone())
+        accs[-1].fill_(-1)
+    torch.cuda.synchronize()
+    sa.first_dim_batch(lanes)
+    for ln in lanes:
+        ln.sync()
+    torch.cuda.synchronize()
+    for b, (got, w) in enumerate(zip(accs, want)):
+        assert torch.equal(got, w), f"lane {b}: accumulators of the batched sweep differ from first_dim() with {G} fold ranks"
+    assert not torch.equal(want[0], want[1])
+    for ln in reversed(lanes):
+        ln.close()
+
+
 def test_batch_without_the_matrix_core_image_and_after_a_reload(sa, oracle, monkeypatch):
     """(6, 6) is a geometry the matrix-core sweep covers.  SPIRAL_SWEEP_MFMA=0 (read when a handle is created): the same batch sweeps in passes of two on
     the vector ALU (2 + 2 + 1 for five lanes).  With the image: reloading the database drops it -- the next batch rebuilds it from the new contents."""
