@@ -698,6 +698,44 @@ def test_batched_sweep_equals_single_sweeps(sa, oracle, nu1, nu2, n):
         srv.close()
 
 
+_N_FUZZ_SWEEP = max(6, _N_FUZZ // 3)
+
+
+@pytest.mark.parametrize("seed", range(_N_FUZZ_SWEEP))
+def test_matrix_core_sweep_random_geometries_and_edge_values(sa, oracle, seed):
+    """seeded random (geometry, queries per pass) for the matrix-core sweep with the limb decomposition's edge residues sprinkled over uniform ones in
+    both operands: 0, 1, m - 1, the residues either side of the wrap point 2^28 - 0x808080, all-(-128) / all-(+127) limb bytes.  Against the oracle."""
+    O = oracle
+    rng = np.random.default_rng(7000 + seed)
+    nu1, nu2 = int(rng.integers(6, 8)), int(rng.integers(6, 8))
+    n = int(rng.integers(1, 9))
+    dim0, num_per = 1 << nu1, 1 << nu2
+    wrap = (1 << 28) - 0x808080
+    edges = {0: [0, 1, O.P - 1, O.P - 2, wrap - 1, wrap, wrap + 1, (15 << 24) - 0x808080, (14 << 24) - 0x808080 + 0xFFFFFF, 0x808080, 0x7F7F7F],
+             1: [0, 1, O.B - 1, O.B - 2, (14 << 24) - 0x808080, (13 << 24) - 0x808080 + 0xFFFFFF, 0x808080, 0x7F7F7F, 0x800000, 0x7FFFFF, 1 << 27]}
+
+    def sprinkle(a, limb_axis):  # a[..., limb, z]: replace ~3 % of the residues by edge values of their prime
+        for limb, mod in ((0, O.P), (1, O.B)):
+            view = np.moveaxis(a, limb_axis, 0)[limb]
+            mask = rng.random(view.shape) < 0.03
+            vals = np.array([v for v in edges[limb] if v < mod], dtype=np.uint64)
+            view[mask] = vals[rng.integers(0, len(vals), size=int(mask.sum()))]
+
+    res = []
+    for _ in range(n):
+        cts = rand_ntt(rng, O, (dim0, 3, 2))
+        sprinkle(cts, -2)
+        res.append(O.reorient_ciphertexts(cts))
+    lo = rng.integers(0, O.P, size=dim0 * num_per * 4 * N, dtype=np.uint64)
+    hi = rng.integers(0, O.B, size=dim0 * num_per * 4 * N, dtype=np.uint64)
+    both = np.stack([lo, hi])
+    sprinkle(both[:, None, :], 0)
+    db = both[0] | (both[1] << np.uint64(32))
+    got = sa.multiplyQueriesByDatabase(res, db, dim0, num_per)
+    for b, re in enumerate(res):
+        assert_eq(got[b], O.multiply_query_by_database(re, db, dim0, num_per), f"seed {seed}: ({nu1},{nu2}), query {b} of {n}")
+
+
 @pytest.mark.parametrize("G", [2, 8])
 def test_matrix_core_sweep_groups_accumulators_by_fold_rank(sa, oracle, G):
     """first_dim_batch on lanes prepared for a distributed fold over G ranks (set_fold_ranks: the sweep writes ciphertext ii = g + G k at [g][k], sweep.hip
