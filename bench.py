@@ -762,7 +762,7 @@ def bench_base(args, ctx, workload, steps, warmup, primary, prog):
         # image, one server handle and one stream per lane, each replaying the whole-query graph
         pipelined = None
         if whole and args.lanes > 1:
-            n_lanes = max(args.lanes, 8 if args.batched_sweep else 0)
+            n_lanes = max(args.lanes, 16 if args.batched_sweep else 0)
             lanes = [(srv, stream)]
             for _ in range(n_lanes - 1):
                 lane, lane_stream = sa.Server(pg, local_rank, j0, j1, share_db_of=srv), torch.cuda.Stream(device=dev)
@@ -810,7 +810,7 @@ def bench_base(args, ctx, workload, steps, warmup, primary, prog):
                 # expansion / conversion / lift / fold launches take a query dimension, the sweep is the batched one), one hipGraph replay per batch
                 bq = {}
                 srv.set_acc(0)  # (back to the server's own accumulators: the lanes of a batch address their buffers relative to one another)
-                for name, groups in (("2", [[0, 1]]), ("4", [[0, 1, 2, 3]]), ("8", [list(range(8))]), ("2x2", [[0, 1], [2, 3]])):
+                for name, groups in (("2", [[0, 1]]), ("4", [[0, 1, 2, 3]]), ("8", [list(range(8))]), ("2x2", [[0, 1], [2, 3]]), ("2x8", [list(range(8)), list(range(8, 16))])):
                     for g in groups:  # the lanes of a batch on the batch's own stream (lane 0's): no cross-stream ordering around the launch sequence
                         for i in g: lanes[i][0].set_stream(lanes[g[0]][1].cuda_stream)
                     groups = [[lanes[i][0] for i in g] for g in groups]
@@ -827,8 +827,9 @@ def bench_base(args, ctx, workload, steps, warmup, primary, prog):
                     bq[name] = {"queries": n_b * per, "queries_per_s": round(n_b * per / dt_b, 1), "ms_per_query_amortised": round(dt_b * 1e3 / (n_b * per), 4),
                                 "ms_per_batch": round(dt_b * 1e3 / n_b / len(groups), 4)}
                 bq["note"] = ("B whole queries (different lanes: own keys, own query) per launch sequence, every launch carrying all B (gridDim.z = B) and the sweep ONE pass "
-                              "over the database for all of them on the matrix cores (sweep_mfma_kernel: i8 limb products, bit-identical accumulators); '2x2' = two such "
-                              "batches of 2 in flight on two streams; throughput only -- a query's latency is ms_per_batch")
+                              "over the database for all of them on the matrix cores (sweep_mfma_kernel: i8 limb products, bit-identical accumulators); '2x2' / '2x8' = two such "
+                              "batches of 2 / 8 in flight on two streams (one batch's HBM-bound sweep under the other's VALU-bound stages); throughput only -- a query's latency "
+                              "is ms_per_batch (twice that with two batches in flight)")
                 pipelined["batched_query"] = bq
                 # the batched sweep's own roofline: one launch of sweep_mfma_kernel for B queries (HIP events on the launch stream, 12 launches), against
                 # the bytes ONE pass has to move: the database once (SURVEY 8d's 8 bytes per word), B queries' records and accumulators
