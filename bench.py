@@ -840,12 +840,15 @@ def bench_base(args, ctx, workload, steps, warmup, primary, prog):
                     group = [ln for ln, _ in lanes[:B]]
                     sa.time_sweep_batch(group, 2)
                     ms_b = sa.time_sweep_batch(group, 12)
-                    one = srv.sweep_bytes()
+                    one, one_dev = srv.sweep_bytes(), srv.sweep_device_bytes()
                     db_b = shp.dim0 // world * shp.num_per * 4 * 2048 * 8
-                    alg = db_b + B * (one - db_b)
+                    alg, dev_b = db_b + B * (one - db_b), db_b // 8 * 7 + B * (one_dev - db_b // 8 * 7)
                     sk[str(B)] = {"avg_launch_ms": round(ms_b, 4), "algorithmic_bytes_per_launch": alg, "achieved": round(alg / (ms_b * 1e-3) / 1e9, 1),
-                                  "frac": round(alg / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "queries_x_database_bytes_per_s": round(B * db_b / (ms_b * 1e-3) / 1e9, 1)}
-                sk["note"] = ("bound: hbm, peak %d GB/s; `achieved` counts the database once per launch -- per query the pass streams "
+                                  "frac": round(alg / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "device_bytes_per_launch": dev_b,
+                                  "frac_device_bytes": round(dev_b / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                  "queries_x_database_bytes_per_s": round(B * db_b / (ms_b * 1e-3) / 1e9, 1)}
+                sk["note"] = ("bound: hbm, peak %d GB/s; `achieved` / `frac` in algorithmic bytes (SURVEY 8d's 8 bytes per database word, the database counted ONCE per launch: the "
+                              "image holds a word in 7 bytes, so `frac` can pass 1 where `frac_device_bytes` -- bytes physically moved -- is 0.88); per query the pass streams "
                               "`queries_x_database_bytes_per_s` GB/s of database" % HBM_PEAK_GBPS)
                 pipelined["batched_sweep_kernel"] = sk
             for lane, _ in lanes[1:]:
