@@ -895,10 +895,11 @@ def bench_base(args, ctx, workload, steps, warmup, primary, prog):
     return out, params_kw
 
 
-def bench_replicas(args, ctx, prog, batch=8, n_batches=15):
+def bench_replicas(args, ctx, prog, batch=8, n_rounds=10, in_flight=2):
     """N > 1, beside the j-shard figure north_star prescribes (never `value`, never the scaling curve): every rank answers on its OWN full copy of the
-    configs[1] database, `batch` whole queries per launch sequence (spiral_gpu_server_run_query_batch) -- what a deployment would do at this database
-    size, where the j-shard is Amdahl-bound.  No collective on the data path: a barrier either side, max over ranks."""
+    configs[1] database, `batch` whole queries per launch sequence (spiral_gpu_server_run_query_batch), `in_flight` such batches on their own streams (one
+    batch's HBM-bound sweep runs under the other's VALU-bound stages) -- what a deployment would do at this database size, where the j-shard is Amdahl-bound
+    (DESIGN.md section 6).  No collective on the data path: a barrier either side, max over ranks."""
     import numpy as np
 
     import spiral_amd as sa
@@ -909,34 +910,36 @@ def bench_replicas(args, ctx, prog, batch=8, n_batches=15):
     shp = sa.get_shape(pg)
     prog.arm("replicas/set-up", 3.0)
     owner = sa.Server(pg, ctx.local_rank)
-    stream = torch.cuda.Stream(device=ctx.dev)
-    owner.set_stream(stream.cuda_stream)
+    streams = [torch.cuda.Stream(device=ctx.dev) for _ in range(in_flight)]
+    owner.set_stream(streams[0].cuda_stream)
     owner.gen_db(DB_SEED)
-    lanes = [owner] + [sa.Server(pg, ctx.local_rank, share_db_of=owner) for _ in range(batch - 1)]
+    lanes = [owner] + [sa.Server(pg, ctx.local_rank, share_db_of=owner) for _ in range(in_flight * batch - 1)]
+    groups = [lanes[g * batch:(g + 1) * batch] for g in range(in_flight)]
     pub, query = synth_inputs(np, sa, pg, shp)
-    for ln in lanes:
-        ln.set_stream(stream.cuda_stream)  # the lanes of a batch on the batch's stream: no cross-stream ordering around the launch sequence
-        ln.set_pub_params(*pub)
-        ln.set_query(query)
-        ln.use_graphs(True)
+    for g, grp in enumerate(groups):
+        for ln in grp:
+            ln.set_stream(streams[g].cuda_stream)  # the lanes of a batch on the batch's stream: no cross-stream ordering around the launch sequence
+            ln.set_pub_params(*pub)
+            ln.set_query(query)
+            ln.use_graphs(True)
     prog.arm("replicas/timed")
-    for _ in range(5):
-        sa.run_query_batch(lanes)
+    for _ in range(4):
+        for grp in groups: sa.run_query_batch(grp)
     ctx.fence()
     t0 = time.perf_counter()
-    for _ in range(n_batches):
-        sa.run_query_batch(lanes)
+    for _ in range(n_rounds):
+        for grp in groups: sa.run_query_batch(grp)
     ctx.fence()
     dt = ctx.max_over_ranks(time.perf_counter() - t0)
     for ln in lanes[1:]:
         ln.close()
     owner.close()
     torch.cuda.empty_cache()
-    total = ctx.world * batch * n_batches
-    return {"n_replicas": ctx.world, "batch": batch, "queries": total, "queries_per_s": round(total / dt, 1), "queries_per_s_per_replica": round(batch * n_batches / dt, 1),
-            "ms_per_batch": round(dt * 1e3 / n_batches, 4),
-            "note": "N independent replicas of the configs[1] database, one per GPU, each answering batches of whole queries; throughput only, NOT the j-shard scaling "
-                    "north_star asks for (that is `value` at each N) and not a latency"}
+    per_rank = in_flight * batch * n_rounds
+    return {"n_replicas": ctx.world, "batch": batch, "batches_in_flight": in_flight, "queries": ctx.world * per_rank, "queries_per_s": round(ctx.world * per_rank / dt, 1),
+            "queries_per_s_per_replica": round(per_rank / dt, 1), "ms_per_batch": round(dt * 1e3 / n_rounds, 4),
+            "note": "N independent replicas of the configs[1] database, one per GPU, each answering batches of whole queries (two batches in flight on two streams; "
+                    "ms_per_batch = one round of both); throughput only, NOT the j-shard scaling north_star asks for (that is `value` at each N) and not a latency"}
 
 
 def main(argv=None):
