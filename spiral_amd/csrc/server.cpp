@@ -1541,7 +1541,7 @@ int spiral_gpu_server_run_query(spiral_gpu_server* S) {
 
 // B <= kMaxLanes whole queries -- one per server: an owner and its lanes (create_lane), all with the same parameters, each with its own
 // client's keys and query -- as ONE launch sequence: every launch of expansion, conversion, lift, folding and the switch carries all B queries
-// (gridDim.z = B, kernels.h Lanes), and the sweep makes one pass over the database for all of them (sweep_kernel<0, B>).  The reference
+// (gridDim.z = B, kernels.h Lanes), and the sweep makes one pass over the database for all of them (sweep_mfma_kernel; sweep_queries).  The reference
 // answers one query per process_crtd_query (src/spiral.cpp:2337-2406); this is throughput, not latency: a query's ~50 launch-bound launches
 // cost the same ~5 us whether they carry one query or four.  Every lane's buffers end up exactly as after its own run_query.
 // The sequence runs on servers[0]'s stream (captured once per lane set into a hipGraph when servers[0] has use_graphs on); the other

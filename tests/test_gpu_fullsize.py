@@ -159,7 +159,7 @@ def test_config2_every_stage_bit_exact(sa, oracle_mt, request):
         ln.set_pub_params(*pp)
         ln.set_query(qq)
         ln.use_graphs(True)
-    for n_b in (8, 4, 2):  # (eight lanes: two passes over the database, four queries each)
+    for n_b in (8, 4, 2):  # (every batch one pass over the database on the matrix cores: 6, 3 and 2 column tiles)
         for rep in range(2):  # capture, then a replay
             sa.run_query_batch(lanes[:n_b])
         for b, (ln, c, pp, qq, i2) in enumerate(zip(lanes[:n_b], clients, pps, qs_b, idxs)):
