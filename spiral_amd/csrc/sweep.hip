@@ -112,14 +112,14 @@ struct SweepBatch {
     const uint32_t* qs[kSweepMaxBatch];
     uint64_t* acc[kSweepMaxBatch];
 };
-template <int MODE, int NB = 1>
-__global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __restrict__ db, SweepBatch bt, uint32_t nic, uint32_t dim0, uint32_t g_log, uint32_t ls_log,
+template <int MODE, int NB = 1, uint32_t Z = kSweepZ>
+__global__ __launch_bounds__(Z * 64) void sweep_kernel(const uint64_t* __restrict__ db, SweepBatch bt, uint32_t nic, uint32_t dim0, uint32_t g_log, uint32_t ls_log,
                                                              uint32_t icb0, uint32_t n_icb) {
     static_assert(NB == 1 || MODE == 0, "batched sweeps use the wide geometry");
     const uint32_t* __restrict__ qs = bt.qs[0];
     uint64_t* __restrict__ acc = bt.acc[0];
     constexpr bool WIDE = MODE == 0;
-    constexpr uint32_t kShWords = MODE == 2 ? (kSweepZ * kQStage * 2 > kSweepZ * kSweepRow ? kSweepZ * kQStage * 2 : kSweepZ * kSweepRow) : kSweepZ * kSweepRow;
+    constexpr uint32_t kShWords = MODE == 2 ? (Z * kQStage * 2 > Z * kSweepRow ? Z * kQStage * 2 : Z * kSweepRow) : Z * kSweepRow;
     __shared__ __attribute__((aligned(16))) uint64_t sh[kShWords];  // results; MODE 2: first the record staging (aliased)
     const uint32_t lane = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t w = WIDE ? 64u : nic, pz = 64u / w, nblk = nic / w;  // columns and slots per tile, column blocks per slot group
@@ -130,13 +130,13 @@ __global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __r
     uint32_t work = blockIdx.x;
     if ((gridDim.x & 7u) == 0) work = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     // (a launch may cover only the column blocks [icb0, icb0 + n_icb) of the wide geometry: one stage of a pipelined sweep)
-    const uint32_t zg = work / n_icb, icb = icb0 + (work - zg * n_icb);  // WIDE: zg = group of kSweepZ slots; else one tile of pz slots
+    const uint32_t zg = work / n_icb, icb = icb0 + (work - zg * n_icb);  // WIDE: zg = group of Z slots; else one tile of pz slots
     const uint32_t groups = dim0 >> 3;
-    // WIDE: the workgroup's waves take kSweepZ consecutive tiles whole.  !WIDE: there are only N/pz tiles, each a long
+    // WIDE: the workgroup's waves take Z consecutive tiles whole.  !WIDE: there are only N/pz tiles, each a long
     // stream, so the waves of a workgroup split ONE tile's j range between them (load concurrency is what buys bandwidth)
     // and their partial sums are added through LDS.
-    const uint32_t ztile = WIDE ? zg * kSweepZ + wv : zg, tile = ztile * nblk + icb;
-    const uint32_t gper = WIDE ? groups : (groups + kSweepZ - 1u) / kSweepZ;
+    const uint32_t ztile = WIDE ? zg * Z + wv : zg, tile = ztile * nblk + icb;
+    const uint32_t gper = WIDE ? groups : (groups + Z - 1u) / Z;
     const uint32_t gfirst = WIDE ? 0u : min(wv * gper, groups), glast = WIDE ? groups : min(gfirst + gper, groups);
     const uint32_t z = WIDE ? ztile : ztile * pz + lane / w;  // this lane's slot
     const u32x4* dbp = reinterpret_cast<const u32x4*>(db) + (size_t)tile * groups * 7u * 64u + lane;
@@ -213,23 +213,23 @@ __global__ __launch_bounds__(kSweepZ * 64) void sweep_kernel(const uint64_t* __r
 #pragma unroll
     for (uint32_t r = 0; r < 3; r++) sh[wv * kSweepRow + lane * 3u + r] = pack((uint32_t)a[r], (uint32_t)a[3 + r]);
     __syncthreads();
-    // w*3 (column, row) results x kSweepZ*pz consecutive z: thread -> (result, z) with z fastest.
+    // w*3 (column, row) results x Z*pz consecutive z: thread -> (result, z) with z fastest.
     // acc[perm(ii)][r][c][z], ic = ii*2 + c -> polynomial 6*perm(ii) + 2*r + c; perm groups the ciphertexts by ii mod G
     // (G = 2^g_log ranks of a distributed fold: rank g then owns the contiguous chunk ii = g + G*k, which is what one
     // reduce-scatter hands it); G = 1 is the identity.
     if constexpr (WIDE) {
 #pragma unroll
         for (uint32_t m = 0; m < 3; m++) {
-            const uint32_t idx = threadIdx.x + kSweepZ * 64u * m, res = idx / kSweepZ, zz = idx - res * kSweepZ;
+            const uint32_t idx = threadIdx.x + Z * 64u * m, res = idx / Z, zz = idx - res * Z;
             const uint32_t col = res / 3u, r = res - col * 3u, ic = icb * 64u + col, i0 = ic >> 1, c = ic & 1u;
             const uint32_t ii = acc_pos(i0, g_log, ls_log);
-            acc[((size_t)(6u * ii + 2u * r + c)) * kN + zg * kSweepZ + zz] = sh[zz * kSweepRow + res];
+            acc[((size_t)(6u * ii + 2u * r + c)) * kN + zg * Z + zz] = sh[zz * kSweepRow + res];
         }
-    } else if (threadIdx.x < 192u) {  // 64 lanes x 3 results of this tile, each the sum of the kSweepZ waves' partials (< 16 * 2^28)
+    } else if (threadIdx.x < 192u) {  // 64 lanes x 3 results of this tile, each the sum of the Z waves' partials (< 16 * 2^28)
         const uint32_t sl = threadIdx.x / 3u, r = threadIdx.x - sl * 3u, zz = sl / w, col = sl - zz * w, i0 = col >> 1, c = col & 1u;
         uint64_t sp = 0, sb = 0;
 #pragma unroll
-        for (uint32_t v = 0; v < kSweepZ; v++) {
+        for (uint32_t v = 0; v < Z; v++) {
             const uint64_t x = sh[v * kSweepRow + threadIdx.x];
             sp += lo32(x);
             sb += hi32(x);
@@ -298,7 +298,12 @@ void launch_sweep(const uint64_t* db, const uint32_t* qs, uint64_t* acc, uint32_
         if (nic >= 64) {
             const uint32_t nblk = nic >> 6, per = nblk >> k_log;  // column blocks per stage
             const uint32_t icb0 = stage < 0 ? 0u : (uint32_t)stage * per, n_icb = stage < 0 ? nblk : per;
-            hipLaunchKernelGGL(sweep_kernel<0>, dim3((kN / kSweepZ) * n_icb), dim3(kSweepZ * 64), 0, s, db, bt, nic, dim0, g_log, ls_log, icb0, n_icb);
+            // 64 columns (nu2 = 5; one stage of a pipelined sweep) are only 128 workgroups of 16 slots, half the chip: 8 slots per workgroup there
+            // (177 -> 146 us = 6.4 -> 7.8 TB/s at nu1 = 9, nu2 = 5; no difference from 128 columns up)
+            if ((kN / kSweepZ) * n_icb < 256u)
+                hipLaunchKernelGGL((sweep_kernel<0, 1, 8>), dim3((kN / 8) * n_icb), dim3(8 * 64), 0, s, db, bt, nic, dim0, g_log, ls_log, icb0, n_icb);
+            else
+                hipLaunchKernelGGL(sweep_kernel<0>, dim3((kN / kSweepZ) * n_icb), dim3(kSweepZ * 64), 0, s, db, bt, nic, dim0, g_log, ls_log, icb0, n_icb);
         } else if (nic >= 8 && stage_recs)  // one workgroup per tile of 64/nic <= 8 slots, its waves split the j range; records staged in LDS
             hipLaunchKernelGGL(sweep_kernel<2>, dim3(kN / (64 / nic)), dim3(kSweepZ * 64), 0, s, db, bt, nic, dim0, g_log, ls_log, 0u, 1u);
         else
