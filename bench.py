@@ -35,6 +35,21 @@ def pmc_traffic(n_gpus, nu1, nu2):
     return None, None
 
 
+def batch_roofline_from_profile(nu1, nu2):
+    """per-kernel-class roofline of one eight-query batch (run_query_batch) from the committed rocprofv3 passes -- kernel-trace durations, FETCH_SIZE and
+    WRITE_SIZE each in its own pass, corrected as MI355X_MICROARCH.md prescribes (tools/batch_roofline.sh, tools/batch_bytes.py).  Like roofline.traffic it
+    is read from the file named in `source`, NOT measured by the run that prints it; valid for configs[1] on one GPU only."""
+    try:
+        files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("batch_kernel_bytes_B8.json") and f.startswith("r"))
+        if not files or (nu1, nu2) != (8, 7):
+            return None
+        d = json.load(open(os.path.join(ROOT, "profiles", files[-1])))
+        return {"source": "profiles/" + files[-1], "lanes": d["lanes"], "batch_us": d["batch_us"], "peak_GBps": d["peak_GBps"], "per_kernel_class": d["per_kernel_class"],
+                "note": "us from a rocprofv3 kernel trace of one batch; bytes = FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 from separate counter passes; not measured by this run"}
+    except Exception:
+        return None
+
+
 def synth_residues(rng, np, shape):
     """uniform canonical NTT-form polynomials [..., 2, N] (synthetic query / public parameters)"""
     import spiral_amd as sa
@@ -75,15 +90,18 @@ class Progress:
         import threading
 
         self.rank, self.seconds = rank, seconds
-        self.line, self.where, self.deadline = None, "set-up", None
+        self.line, self.where, self.deadline, self.limit = None, "set-up", None, seconds
         self.lock = threading.Lock()
         self.wrap = lambda line: line  # the secondary leg nests its line under the primary's `also`
+        self.on_hang = None  # optional: () -> dict merged into the hung line (the process-group set-up says which ranks never joined)
         t = threading.Thread(target=self._watch, daemon=True)
         t.start()
 
-    def arm(self, where, factor=1.0):
+    def arm(self, where, factor=1.0, seconds=None):
+        """seconds: this phase's own limit (the process-group set-up's is short); otherwise `factor` x the --watchdog seconds"""
+        limit = seconds if seconds is not None else self.seconds * factor
         with self.lock:
-            self.where, self.deadline = where, (time.monotonic() + self.seconds * factor) if self.seconds > 0 else None
+            self.where, self.limit, self.deadline = where, limit, (time.monotonic() + limit) if (self.seconds > 0 and limit > 0) else None
 
     def disarm(self):
         with self.lock:
@@ -108,16 +126,21 @@ class Progress:
             time.sleep(0.25)
             with self.lock:
                 late = self.deadline is not None and time.monotonic() > self.deadline
-                line, where = self.line, self.where
+                line, where, limit, hook = self.line, self.where, self.limit, self.on_hang
             if late:
+                more = {}
+                try:
+                    more = hook() if hook else {}
+                except Exception as e:  # the hook is diagnostics only
+                    more = {"hang_diagnostics_failed": repr(e)}
                 if self.rank == 0:
                     out = dict(line or {"metric": "server ms/query + DB GB/s vs HBM roofline", "value": None}, partial=True, hung_in=where,
-                               watchdog_s=self.seconds)
+                               watchdog_s=limit, **more)
                     sys.stdout.write(json.dumps(out) + "\n")
                     sys.stdout.flush()
                 else:
                     time.sleep(10)  # rank 0 goes first: the launcher tears every rank down as soon as one exits
-                print(f"bench.py: rank {self.rank} made no progress in '{where}' for {self.seconds} s; giving up (exit 3)", file=sys.stderr, flush=True)
+                print(f"bench.py: rank {self.rank} made no progress in '{where}' for {limit} s; giving up (exit 3, a fresh exit: nothing is re-exec'd) {more or ''}", file=sys.stderr, flush=True)
                 os._exit(3)  # the main thread is stuck in a collective or a synchronize: no clean way out
 
 
@@ -366,6 +389,11 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS) + ["pack"], help="config2 = BASELINE.json configs[1], the one the metric is quoted on; "
                     "config3 / stream / pack = configs[2] / [3] / [4]")
+    ap.add_argument("--headline", default=None, choices=["config2", "config3"], help="which of the two base geometries is `value` when both are timed (default config2 = configs[1], "
+                    "the one the metric is quoted on, with configs[2]'s geometry under `also.config3`); --headline config3 swaps them: `value` is then the 2^24 x 256 B geometry, "
+                    "whose sweep is 75 %% of the query -- the one a j-shard over N GPUs CAN scale -- and configs[1] goes under `also.config2`")
+    ap.add_argument("--pg-watchdog", type=float, default=float(os.environ.get("SPIRAL_BENCH_PG_WATCHDOG_S", "90")), help="seconds the process-group set-up and its collective smoke "
+                    "test may take (N > 1) before the run exits 3 with a line that says which ranks never joined")
     ap.add_argument("--nu1", type=int, default=None, help="override the workload's first-dimension size (tuning)")
     ap.add_argument("--nu2", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -398,6 +426,10 @@ def parse_args(argv=None):
     args = ap.parse_args(argv)
     if args.comm_overlap:
         args.schedule = "comm-overlap"
+    if args.headline == "config3" and args.workload == "config2":
+        args.workload, args.secondary = "config3", "config2"
+    else:
+        args.secondary = "config3" if args.workload == "config2" else None
     return args
 
 
@@ -417,10 +449,36 @@ def self_launch(args, argv):
     return subprocess.call(cmd, env=env, cwd=ROOT)
 
 
+def _pg_checkin(rank):
+    """a file per rank in a directory named after the rendezvous: who has reached the process-group set-up (one node, so /tmp is shared)"""
+    import atexit
+    import tempfile
+
+    d = os.path.join(tempfile.gettempdir(), "spiral_bench_pg_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none")))
+    os.makedirs(d, exist_ok=True)
+    f = os.path.join(d, f"rank{rank}")
+    with open(f, "w") as fh:
+        fh.write(str(time.time()))
+    atexit.register(lambda: os.path.exists(f) and os.remove(f))
+    return d
+
+
+def _pg_absent(d, world):
+    """for the watchdog's line: the ranks whose check-in file is missing (or older than ten minutes: a previous run's)"""
+    now, present = time.time(), []
+    for r in range(world):
+        try:
+            if now - os.path.getmtime(os.path.join(d, f"rank{r}")) < 600:
+                present.append(r)
+        except OSError:
+            pass
+    return {"ranks_checked_in": present, "ranks_never_joined": [r for r in range(world) if r not in present]}
+
+
 class Ctx:
     """what every leg of one invocation shares: the rank layout and the (once-initialised) process group"""
 
-    def __init__(self, args):
+    def __init__(self, args, prog=None):
         import torch
 
         self.torch = torch
@@ -445,6 +503,16 @@ class Ctx:
             os.environ.setdefault("MASTER_PORT", "29517")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
+            # The first real multi-rank run must say in seconds, not minutes, what went wrong: every rank checks in with a file before the (blocking)
+            # set-up, and the set-up + a collective smoke test run under their own short watchdog whose line names the ranks that never arrived.
+            here = _pg_checkin(self.rank)
+            if prog is not None:
+                prog.on_hang = lambda: _pg_absent(here, self.world)
+                prog.arm("process group set-up", seconds=args.pg_watchdog)
+            if os.environ.get("SPIRAL_BENCH_INJECT_HANG", "") == f"pg-setup:{self.rank}":  # test hook: this rank never joins
+                print(f"bench.py: SPIRAL_BENCH_INJECT_HANG: rank {self.rank} never joins the process group", file=sys.stderr, flush=True)
+                os.remove(os.path.join(here, f"rank{self.rank}"))
+                time.sleep(10 ** 6)
             if args.backend == "nccl":
                 dist.init_process_group(backend="nccl", device_id=self.dev)
             else:
@@ -457,6 +525,33 @@ class Ctx:
             dist.all_gather_object(seen, mine)
             self.rccl = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_seen": seen,
                          "distinct_devices": len({(r["device"]) for r in seen}), "nccl_version": list(torch.cuda.nccl.version()) if args.backend == "nccl" else None}
+            # collective smoke test, still under the short watchdog: the three collectives of the data path on 4-byte-per-rank tensors, checked.  An
+            # xGMI / IPC fault shows up here, with ranks_seen already in the line, not minutes later inside a timed schedule.
+            if prog is not None:
+                prog.line = {"metric": "server ms/query + DB GB/s vs HBM roofline", "value": None, "rccl": self.rccl}
+                prog.arm("collective smoke test (all_reduce, reduce_scatter_tensor, all_gather_into_tensor)", seconds=args.pg_watchdog)
+            w, r = dist.get_world_size(), dist.get_rank()
+            t0 = time.perf_counter()
+            a = torch.full((1,), r + 1, dtype=torch.int32, device=self.dev)
+            dist.all_reduce(a)
+            src = torch.arange(w, dtype=torch.int32, device=self.dev) + r
+            part = torch.zeros(1, dtype=torch.int32, device=self.dev)
+            if args.backend == "gloo":  # (the one-GPU self-test: gloo has no reduce-scatter, spiral_amd/dist.py emulates it the same way)
+                tmp = src.clone()
+                dist.all_reduce(tmp)
+                part.copy_(tmp[r:r + 1])
+            else:
+                dist.reduce_scatter_tensor(part, src)
+            allg = torch.zeros(w, dtype=torch.int32, device=self.dev)
+            dist.all_gather_into_tensor(allg, part)
+            torch.cuda.synchronize()
+            want = [k * w + w * (w - 1) // 2 for k in range(w)]  # rank k's reduce-scattered word: sum over ranks r of (k + r)
+            ok = int(a.item()) == w * (w + 1) // 2 and allg.tolist() == want
+            self.rccl["collective_smoke"] = {"ok": bool(ok), "ms": round((time.perf_counter() - t0) * 1e3, 1)}
+            if not ok:
+                raise SystemExit(f"bench.py: rank {r}: the collective smoke test gave wrong sums (all_reduce {int(a.item())}, all_gather {allg.tolist()}, expected {want})")
+            if prog is not None:
+                prog.on_hang = None
 
     def fence(self):
         if self.use_dist:
@@ -682,6 +777,10 @@ def bench_base(args, ctx, workload, steps, warmup, primary, prog):
             "dtype": "u32 residues, 32x32->64-bit integer MAC (two 28-bit CRT primes)",
             "data": "synthetic",
             "config": {"workload": label + ", explicit DB generated on device, sharded by first-dimension index",
+                       # (inside `config` because the driver's record keeps this dict whole: the hash of what the timed graph computed -- the full-size GPU
+                       # test prints the oracle's hash for the same inputs -- and the no-pre-warm protocol's value)
+                       "answer_sha256": hashes.get(best) or (next(iter(hashes.values())) if hashes else None),
+                       "value_no_prewarm": no_prewarm["value"] if no_prewarm else None,
                        "db_bytes_ntt_form": int(shp.dim0) * int(shp.num_per) * 4 * sa.N * 8, "schedule": "split: the GSW side of the query on a side stream" if args.overlap else "in order, one stream",
                        "parallelism": (f"j-shard x{world}, reduce-scatter + distributed fold + all-gather" if sharded_fold else f"j-shard x{world} + 1 reduce")
                                       + (", sharded expansion + all-gather of the GSW bits" if shard_expand else "")
@@ -831,6 +930,8 @@ def bench_base(args, ctx, workload, steps, warmup, primary, prog):
                               "batches of 2 / 8 in flight on two streams (one batch's HBM-bound sweep under the other's VALU-bound stages); throughput only -- a query's latency "
                               "is ms_per_batch (twice that with two batches in flight)")
                 pipelined["batched_query"] = bq
+                bqr = batch_roofline_from_profile(nu1, nu2)
+                if bqr: pipelined["batched_query_roofline"] = bqr
                 # the batched sweep's own roofline: one launch of sweep_mfma_kernel for B queries (HIP events on the launch stream, 12 launches), against
                 # the bytes ONE pass has to move: the database once (SURVEY 8d's 8 bytes per word), B queries' records and accumulators
                 sk = {}
@@ -851,8 +952,28 @@ def bench_base(args, ctx, workload, steps, warmup, primary, prog):
                               "image holds a word in 7 bytes, so `frac` can pass 1 where `frac_device_bytes` -- bytes physically moved -- is 0.88); per query the pass streams "
                               "`queries_x_database_bytes_per_s` GB/s of database" % HBM_PEAK_GBPS)
                 pipelined["batched_sweep_kernel"] = sk
+                # ONE database image: the batches above made the holder convert its image to limb planes IN PLACE (include/spiral_gpu.h,
+                # spiral_gpu_server_set_db_format); single queries on such a server sweep it with the one-query instance of the matrix-core kernel
+                image = {"format_after_batches": "limb planes" if srv.db_format() == SV.DB_LIMBS else "packed", "db_device_bytes": int(srv.db_device_bytes()),
+                         "one_image_bytes": int(srv.sweep_device_bytes() - shp.dim0 // world * 48 * 2048 - shp.num_per * 6 * 2048 * 8)}
+                if srv.db_format() == SV.DB_LIMBS:
+                    srv.time_sweep(2)
+                    ms_l = srv.time_sweep(12)
+                    image["one_query_sweep_on_limb_planes"] = {"kernel": "sweep_mfma_kernel<1>", "avg_launch_ms": round(ms_l, 4), "frac": round(srv.sweep_bytes() / (ms_l * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+                    for _ in range(3): srv.run_query()  # (re-captured for the new form)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(20): srv.run_query()
+                    torch.cuda.synchronize()
+                    image["one_query_sweep_on_limb_planes"]["ms_per_query"] = round((time.perf_counter() - t1) * 1e3 / 20, 4)
+                    image["one_query_sweep_on_limb_planes"]["answer_sha256"] = read_answer()
+                image["note"] = ("db_device_bytes = device memory held for database images after the batched legs: one image (3.5 bytes per residue), not two; the image goes back to the "
+                                 "packed form (in place) before the standalone kernel timings below")
+                pipelined["database_image"] = image
             for lane, _ in lanes[1:]:
                 lane.close()
+            if srv.db_format() != SV.DB_PACKED:
+                srv.set_db_format(SV.DB_PACKED)
         # untimed: the reference's stage buckets (src/spiral.cpp:246-257) from one eager pass with HIP events
         detail = None
         if primary and world == 1:
@@ -879,12 +1000,18 @@ def bench_base(args, ctx, workload, steps, warmup, primary, prog):
         fwd_ms, inv_ms = sa.time_ntt(16384, 10)
         ns_f, ns_i = fwd_ms * 1e6 / 16384, inv_ms * 1e6 / 16384
         ns_d = sa.time_ntt_digits(2048, 8, 10) * 1e6 / 16384
-        extra["roofline_ntt"] = {"bound": "valu", "unit": "ns per limb-pair transform (2048 points x 2 primes)", "peak": 3.6,
+        # Two bounds per launch, the larger one applies: VALU issue (3.6 ns, above) and HBM -- to_ntt / from_ntt read AND write 16 KiB per transform
+        # (32 KiB / 8 TB/s = 4.1 ns), the digit launch writes 16 KiB and reads its source once per 8 digits (18 KiB / 8 TB/s = 2.3 ns: VALU-bound)
+        hbm_rw, hbm_dig = 32768 / HBM_PEAK_GBPS, (16384 + 16384 / 8) / HBM_PEAK_GBPS  # ns per transform
+        extra["roofline_ntt"] = {"bound": "max(valu, hbm) per launch", "unit": "ns per limb-pair transform (2048 points x 2 primes)", "peak": 3.6, "peak_valu": 3.6,
+                                 "peak_hbm": {"forward_to_ntt": round(hbm_rw, 2), "inverse_from_ntt": round(hbm_rw, 2), "forward_digits": round(hbm_dig, 2)},
                                  "forward_to_ntt": round(ns_f, 2), "inverse_from_ntt": round(ns_i, 2), "forward_digits": round(ns_d, 2),
-                                 "frac_forward": round(3.6 / ns_f, 3), "frac_inverse": round(3.6 / ns_i, 3), "frac_forward_digits": round(3.6 / ns_d, 3),
-                                 "batch": 16384, "note": "standalone launches of 16384 transforms, HIP events: to_ntt (reduce mod p, b + forward) and from_ntt (inverse + CRT lift) "
-                                                         "each read and write 16 KiB of HBM per transform; forward_digits is the launch the stages are built from (8 gadget digits "
-                                                         "of each of 2048 polynomials: the source is re-read from cache, every transform writes its 16 KiB)"}
+                                 "frac_forward": round(max(3.6, hbm_rw) / ns_f, 3), "frac_inverse": round(max(3.6, hbm_rw) / ns_i, 3), "frac_forward_digits": round(max(3.6, hbm_dig) / ns_d, 3),
+                                 "frac_vs_valu_only": {"forward_to_ntt": round(3.6 / ns_f, 3), "inverse_from_ntt": round(3.6 / ns_i, 3), "forward_digits": round(3.6 / ns_d, 3)},
+                                 "batch": 16384, "note": "standalone launches of 16384 transforms, HIP events.  frac_* = the LARGER of the two bounds / measured: to_ntt (reduce mod p, b + forward) "
+                                                         "and from_ntt (inverse + CRT lift) each read and write 16 KiB of HBM per transform, so their bound is the memory one (4.1 ns at the "
+                                                         "8 TB/s peak); forward_digits is the launch the stages are built from (8 gadget digits of each of 2048 polynomials: the source is "
+                                                         "re-read from cache, every transform writes its 16 KiB) and is bound by VALU issue (3.6 ns)"}
     if pipelined: extra["pipelined"] = pipelined
     out = make_out(extra)
     prog.update(out)
@@ -944,6 +1071,7 @@ def bench_replicas(args, ctx, prog, batch=8, n_rounds=10, in_flight=2):
 
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC, which RCCL needs on this driver: set before torch is imported, also under an external launcher
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args, argv))
@@ -954,24 +1082,30 @@ def main(argv=None):
 
     prog = Progress(int(os.environ.get("RANK", "0")), args.watchdog)
     prog.arm("process group set-up", 3.0)
-    ctx = Ctx(args)
+    ctx = Ctx(args, prog)
+    prog.arm("set-up", 3.0)
     out, params_kw = bench_base(args, ctx, args.workload, args.steps, args.warmup, True, prog)
-    if ctx.world > 1 and args.workload == "config2" and not args.no_replicas and (args.nu1, args.nu2) == (None, None):
+    if ctx.world > 1 and "config2" in (args.workload, args.secondary) and not args.no_replicas and (args.nu1, args.nu2) == (None, None):
         out["replicas"] = bench_replicas(args, ctx, prog)  # no collective on its data path: cannot hang where the j-shard schedules did not
         prog.update(out)
-    if args.workload == "config2" and not args.no_config3 and (args.nu1, args.nu2) == (None, None):
-        # secondary leg, LAST: configs[2]'s geometry, where the sweep is ~70 % of the query and the j-shard scales; the headline stays configs[1]
-        # and is complete (and in the line-so-far) before this leg starts
+    if args.secondary and not args.no_config3 and (args.nu1, args.nu2) == (None, None):
+        # secondary leg, LAST.  Default: configs[2]'s geometry (where the sweep is ~75 % of the query and the j-shard scales) under `also.config3`, the
+        # headline configs[1] complete and in the line-so-far before it starts; --headline config3 swaps the two
+        sec = args.secondary
+
         def nest(o3):
             c3 = {k: o3[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "stages_us", "queries_per_s", "schedules", "collectives_us", "pipelined", "answer_sha256", "value_no_prewarm") if k in o3}
             c3["workload"] = o3["config"]["workload"]
             c3["parallelism"] = o3["config"]["parallelism"]
             if "roofline" in o3:
                 c3["roofline"] = {k: o3["roofline"][k] for k in ("achieved", "frac", "frac_device_bytes", "avg_launch_ms", "algorithmic_bytes_per_launch", "shard")}
-            return dict(out, also={"config3": c3})
+            line = dict(out, also={sec: c3})
+            # (the driver keeps `config` whole: the secondary leg's value and answer hash are readable from its record too)
+            line["config"] = dict(out["config"], **{f"also_{sec}_value": c3.get("value"), f"also_{sec}_answer_sha256": c3.get("answer_sha256")})
+            return line
 
         prog.wrap = nest
-        o3, _ = bench_base(args, ctx, "config3", args.config3_steps, min(args.warmup, 2), False, prog)
+        o3, _ = bench_base(args, ctx, sec, args.config3_steps if sec == "config3" else args.steps, min(args.warmup, 2) if sec == "config3" else args.warmup, False, prog)
         prog.wrap = lambda line: line
         out = nest(o3)
     prog.update(out)
@@ -979,7 +1113,7 @@ def main(argv=None):
     ctx.close()
     prog.disarm()
     if ctx.rank == 0:
-        if ctx.world == 1 and not args.no_cpu_baseline and args.workload == "config2":  # (the larger workloads' 32 / 64 GiB host databases are not built for a baseline)
+        if ctx.world == 1 and not args.no_cpu_baseline and args.workload == "config2" and args.headline != "config3":  # (the larger workloads' 32 / 64 GiB host databases are not built for a baseline)
             out["cpu_baseline"] = cpu_baseline(params_kw, np, args.workload)
         import ctypes
 

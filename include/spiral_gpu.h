@@ -63,6 +63,21 @@ const char *spiral_gpu_last_error(void);
 int spiral_gpu_device_count(void);
 int spiral_gpu_get_shape(const spiral_gpu_params *p, spiral_gpu_shape *out);
 
+/* Process-wide options: schedule forms that compute the same function (the reference has one form of each: its own loops).  A server takes
+ * the values in force when it is created; "fwd2" and "db_stage_bytes" apply to every later call.  Unknown names fail.
+ *   "fold_pair"       1 (default) foldOneFurtherDimension as C[i] + Q * NTT(G^-1(C[np+i]) - G^-1(C[i])); 0 the reference's two products
+ *                     (src/spiral.cpp:1349-1410).  Initial value: environment variable SPIRAL_FOLD_PAIR.
+ *   "fold_chain"      1 (default) the two-product form lifts inside its digit transforms; 0 separate lift and digit launches
+ *   "fold_blocks"     workgroups a two-product round aims for when it splits a polynomial's digits over workgroups (default 768)
+ *   "sweep_mfma_min"  batches of at least this many queries sweep on the matrix cores (default 2; 0 = never).  Initial value: SPIRAL_SWEEP_MFMA.
+ *   "one_image"       1 (default) a server that batches on the matrix cores keeps ONE image of its database and converts it in place between the
+ *                     packed and the limb-plane form (spiral_gpu_server_set_db_format); 0 = a second image beside the first
+ *   "fwd2"            -1 (default) the two-digits-per-workgroup transform kernel from 8192 transforms per launch; 0 never; 1 always
+ *   "db_stage_bytes"  bytes of the staging buffer of load_db / load_db_items (default 64 MiB).  Initial value: SPIRAL_DB_STAGE_BYTES.
+ * These three environment variables are the only ones the library reads. */
+int spiral_gpu_set_option(const char *name, int64_t value);
+int spiral_gpu_get_option(const char *name, int64_t *value);
+
 /* ------------------------------------------------------------------------------------------------
  * L1/L2 seams: NTT core and polynomial algebra (host buffers)
  * ------------------------------------------------------------------------------------------------ */
@@ -178,6 +193,19 @@ int spiral_gpu_server_read_db_slots(spiral_gpu_server *s, uint32_t z_begin, uint
  * polynomials of those ciphertexts (2048 * n_ii * n2 * (j_end - j_begin) * n0 words; tests at sizes whose whole image
  * does not fit a host-side reference) */
 int spiral_gpu_server_read_db_columns(spiral_gpu_server *s, uint32_t ii_begin, uint32_t n_ii, uint64_t *out);
+/* The two forms of the device image.  PACKED (every loader writes it): a word = two 28-bit residues in 7 bytes, streamed by the vector-ALU
+ * sweep (the single-query path).  LIMBS: every residue as three signed bytes and a 4-bit top limb, still 3.5 bytes, laid out as MFMA operands
+ * for the batched sweep on the matrix cores (csrc/sweep_mfma.hip); single queries then sweep it with the one-query instance of the same kernel.
+ * set_db_format converts the holder's image in place through a bounded staging buffer (the maps are bijective: packed -> limbs -> packed
+ * reproduces every byte), so one image serves both kernels whatever the database's size; a batch converts to LIMBS by itself (option
+ * "one_image"), a partial load_db_items and set_sweep_stages(K > 1) convert back.  LIMBS exists where the matrix-core sweep does (>= 64
+ * ciphertexts per slot, the shard's first dimension a power of two in [64, 2048]); elsewhere set_db_format(LIMBS) fails.  Call it on the
+ * image's owner (not on a lane), outside stream capture; the lanes' captured graphs are re-captured by themselves.
+ * db_device_bytes: device memory the holder of this server's image keeps for database images (one image, unless "one_image" is 0). */
+enum spiral_gpu_db_format { SPIRAL_GPU_DB_PACKED = 0, SPIRAL_GPU_DB_LIMBS = 1 };
+int spiral_gpu_server_set_db_format(spiral_gpu_server *s, int format);
+int spiral_gpu_server_db_format(spiral_gpu_server *s);
+uint64_t spiral_gpu_server_db_device_bytes(spiral_gpu_server *s);
 /* --random-data analogue: arbitrary valid NTT-form words, timing only */
 int spiral_gpu_server_fill_db_random(spiral_gpu_server *s, uint64_t seed);
 /* a second in-flight query on one database: `s` releases its own image and sweeps `owner`'s (same parameters, shard and device;
@@ -206,11 +234,11 @@ int spiral_gpu_server_lift(spiral_gpu_server *s, int reduce_first); /* nttInvAnd
  * servers that share one database image (an owner and its lanes, create_lane) in ONE pass over the database -- server b's
  * converted query against the image into server b's accumulators, each bit-identical to its own first_dim().  The pass runs on
  * the matrix cores (csrc/sweep_mfma.hip: both operands as signed 8-bit limbs, v_mfma_i32_16x16x64_i8, exact recombination mod
- * the primes): at config 2 two to five queries take the time of one (0.30 ms), eight take 0.39 ms.  It reads a second image of the
- * database, the "limb planes" -- as large as the first, built on the device by the image's owner the first time a batch needs it
- * and again after the database is reloaded; SPIRAL_SWEEP_MFMA=0 (read at create) turns it off.  Without it (that switch, fewer
- * than 128 output columns, a first dimension that is not a multiple of 64 or above 2048) the call makes passes of two queries
- * on the vector ALU.  Asynchronous:
+ * the primes): at config 2 two to five queries take the time of one (0.30 ms), eight take 0.39 ms.  It reads the database as "limb
+ * planes": the image's holder converts its image to that form IN PLACE the first time a batch needs it (option "one_image"; no second
+ * image -- see spiral_gpu_server_set_db_format) and again after the database is reloaded; option "sweep_mfma_min" = 0 turns it off.
+ * Without it (that option, fewer than 128 output columns, a first dimension -- of this shard -- that is not a power of two in [64, 2048])
+ * the call makes passes of two queries on the vector ALU.  Asynchronous:
  * the launch runs on servers[0]'s stream and the other lanes' streams are ordered around it with events, so per lane the
  * sequence run_pre(lane) ... first_dim_batch(all) ... run_post(lane, 0) needs no host synchronisation.  Pays where the sweep is
  * most of a query (large databases); a single query's latency is first_dim().
@@ -232,6 +260,17 @@ int spiral_gpu_server_first_dim_batch(spiral_gpu_server *const *servers, uint32_
  * streams ordered around it by events (call it outside stream capture; ~20 us per batch and other stream: put the lanes of a batch on one stream).  Needs the default schedule on every server: own accumulators, no
  * keep_cts, no split / sharded / staged options; every server is checked before anything is launched.  n = 1 is run_query. */
 int spiral_gpu_server_run_query_batch(spiral_gpu_server *const *servers, uint32_t n);
+/* One query against n INSTANCES of the database.  An item larger than one plaintext -- configs[3]: 100 KB items of 15 360-byte plaintexts -- is
+ * factor = ceil(item size / plaintext size) database instances (select_params.py:297-298): the client sends ONE query, the server expands and converts it
+ * once and answers it against every instance -- first dimension, folding and response switch per instance, `factor` responses.  (The reference runs a
+ * single instance and multiplies its first-dimension time, folding time and response size by the factor, select_params.py:409-418.)  `s` holds the query;
+ * instances[k] hold the images: servers of the same geometry on the same device, each with its own database (s may be one of them; lanes are fine).
+ * pre != 0 runs expansion + conversion first, else s must have converted its query (run_pre).  responses (device pointer): n x 6 x 2048 words, instance k's
+ * switched response n1 x n2 at k * 6 * 2048; finals (device pointer or NULL): the folded ciphertexts likewise.  One launch sequence on s's stream, a
+ * hipGraph per instance set when s has use_graphs on.  Across GPUs the instances are independent: rank r holds instances r, r + N, ... and the responses are
+ * gathered -- no reduce (spiral_amd/dist.py all_gather_instance_responses). */
+int spiral_gpu_server_run_query_instances(spiral_gpu_server *s, spiral_gpu_server *const *instances, uint32_t n, int pre,
+                                          void *responses, void *finals);
 int spiral_gpu_server_fold(spiral_gpu_server *s);      /* foldOneFurtherDimension x nu2               */
 int spiral_gpu_server_finish(spiral_gpu_server *s);    /* response modulus switch, :1441-1447         */
 int spiral_gpu_server_sync(spiral_gpu_server *s);

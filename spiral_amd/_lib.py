@@ -10,8 +10,8 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# SPIRAL_LIB=<path>: load another build of the library (tuning A/B runs, tools/build_variants.sh); every process of a multi-rank run
-# inherits it.  A variant that lacks a declared entry point loses that binding with a message instead of failing the import.
+# SPIRAL_LIB=<path>: load another build of the library (tuning A/B runs, tools/build_variants.sh: -DSPIRAL_TUNING builds of the same sources);
+# every process of a multi-rank run inherits it.  Whatever is loaded must export every declared entry point.
 LIB_PATH = os.environ.get("SPIRAL_LIB") or os.path.join(HERE, "libspiral_gpu.so")
 CSRC = os.path.join(HERE, "csrc")
 
@@ -62,6 +62,8 @@ PROTOTYPES = {
     "spiral_gpu_last_error": (C.c_char_p, []),
     "spiral_gpu_device_count": (C.c_int, []),
     "spiral_gpu_get_shape": (C.c_int, [C.POINTER(Params), C.POINTER(Shape)]),
+    "spiral_gpu_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
+    "spiral_gpu_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64)]),
     "spiral_gpu_get_tables": (C.c_int, [U64P]),
     "spiral_gpu_ntt_forward": (C.c_int, [U64P, C.c_size_t]),
     "spiral_gpu_ntt_inverse": (C.c_int, [U64P, C.c_size_t]),
@@ -89,10 +91,14 @@ PROTOTYPES = {
     "spiral_gpu_server_load_db": (C.c_int, [C.c_void_p, U64P]),
     "spiral_gpu_server_gen_db": (C.c_int, [C.c_void_p, C.c_uint64]),
     "spiral_gpu_server_fill_db_random": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "spiral_gpu_server_set_db_format": (C.c_int, [C.c_void_p, C.c_int]),
+    "spiral_gpu_server_db_format": (C.c_int, [C.c_void_p]),
+    "spiral_gpu_server_db_device_bytes": (C.c_uint64, [C.c_void_p]),
     "spiral_gpu_server_share_db": (C.c_int, [C.c_void_p, C.c_void_p]),
     "spiral_gpu_server_create_lane": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "spiral_gpu_server_first_dim_batch": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32]),
     "spiral_gpu_server_run_query_batch": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32]),
+    "spiral_gpu_server_run_query_instances": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
     "spiral_gpu_response_wire_bytes": (C.c_size_t, [C.POINTER(Params), C.c_uint32]),
     "spiral_gpu_response_from_wire": (C.c_int, [C.POINTER(Params), C.c_uint32, C.c_void_p, U64P]),
     "spiral_gpu_server_read_response_wire": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -185,13 +191,7 @@ def lib() -> C.CDLL:
                 "there is no CPU fallback"
             )
         L = C.CDLL(LIB_PATH)
-        for name, (res, args) in list(PROTOTYPES.items()):
-            if os.environ.get("SPIRAL_LIB") and not hasattr(L, name):
-                import sys
-
-                print(f"spiral_amd: {LIB_PATH} does not export {name}", file=sys.stderr)
-                del PROTOTYPES[name]
-                continue
+        for name, (res, args) in PROTOTYPES.items():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args

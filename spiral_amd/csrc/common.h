@@ -110,6 +110,27 @@ __device__ __forceinline__ uint64_t db_get_word(const uint64_t* db, uint32_t z, 
     return db[db_word_index(z, j, ic, m, nic, dim0)];
 }
 
+// The same word from the limb-plane form of the image (sweep_mfma.hip: [z][16 columns][prime][piece of 128 terms t = 2 (j & 63) + m][7 x 1 KiB],
+// 1 KiB = limb i < 3 of chunk c = t >> 6 as signed bytes, the seventh the 4-bit top limbs of both chunks; lane = ((t >> 4) & 3) * 16 + (ic & 15), byte t & 15).
+// A residue a is stored as a'' = a or a - m in [-0x808080, 2^28 - 0x808080): a'' + 0x808080 = (s0 + 128) | (s1 + 128) << 8 | (s2 + 128) << 16 | u3 << 24.
+__device__ __forceinline__ uint64_t db_get_word_limbs(const uint64_t* db, uint32_t z, uint32_t j, uint32_t ic, uint32_t m, uint32_t nic, uint32_t dim0) {
+    const uint8_t* bytes = reinterpret_cast<const uint8_t*>(db);
+    const uint32_t nk2 = dim0 >> 6, t = 2u * (j & 63u) + m, c = t >> 6, lane = ((t >> 4) & 3u) * 16u + (ic & 15u), e = t & 15u;
+    uint32_t res[2];
+#pragma unroll
+    for (uint32_t pr = 0; pr < 2; pr++) {
+        const size_t piece = (((size_t)z * (nic >> 4) + (ic >> 4)) * 2u + pr) * nk2 + (j >> 6);  // 7 KiB each
+        const uint8_t* b = bytes + piece * 7168u + (size_t)lane * 16u + e;
+        uint32_t w = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 3; i++) w |= (uint32_t)(b[(2u * i + c) * 1024u] ^ 0x80u) << (8u * i);
+        w |= ((uint32_t)(b[6u * 1024u] >> (4u * c)) & 0xFu) << 24;
+        const int32_t a = (int32_t)w - 0x808080;
+        res[pr] = a < 0 ? (uint32_t)(a + (int32_t)(pr ? kB : kP)) : (uint32_t)a;
+    }
+    return pack(res[0], res[1]);
+}
+
 // Plaintext coefficient number ci of a bit-packed item stream (raw database ingest): coefficients are coeff_bits wide,
 // little-endian bit order as the reference's read_arbitrary_bits (src/core.cpp:20-30); coeff_bits == 64: plain u64 words
 // (the reference's raw MatPoly).  The staging buffer carries 16 bytes of padding, so the 12-byte window may over-read.

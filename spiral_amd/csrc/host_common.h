@@ -268,8 +268,7 @@ inline int ingest_items(const void* items, uint32_t coeff_bits, uint64_t first, 
     if (coeff_bits < 64 && (1ull << coeff_bits) < p_db) return fail("%u-bit coefficients cannot hold values below p_db", coeff_bits);
     if (lo >= hi) return 0;
     const size_t item_bytes = (size_t)polys_per_item * kN * coeff_bits / 8;
-    size_t stage_bytes = (size_t)64 << 20;
-    if (const char* e = getenv("SPIRAL_DB_STAGE_BYTES")) stage_bytes = strtoull(e, nullptr, 10);  // tests: force several passes
+    const size_t stage_bytes = options().db_stage_bytes;  // (tests force several passes)
     const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>({stage_bytes / item_bytes, (uint64_t)(1u << 16), hi - lo}));
     uint8_t* d_items = nullptr;
     uint32_t* d_err = nullptr;

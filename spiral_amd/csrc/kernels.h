@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "common.h"
 
 namespace spiral {
@@ -12,6 +13,24 @@ struct IndexMap {
     __host__ __device__ uint32_t operator()(uint32_t b) const { return (b / inner) * outer_stride + (b % inner) + off; }
 };
 inline IndexMap identity_map() { return IndexMap{1u, 1u, 0u}; }
+
+// Environment switches.  The shipped library reads exactly three, all documented in README.md: SPIRAL_FOLD_PAIR, SPIRAL_SWEEP_MFMA and
+// SPIRAL_DB_STAGE_BYTES (initial values of the options of spiral_gpu_set_option, include/spiral_gpu.h).  The thresholds that only a tuning
+// session moves (tools/build_variants.sh builds with -DSPIRAL_TUNING) are read through tuning_env, which is a constant nullptr otherwise.
+#ifdef SPIRAL_TUNING
+inline const char* tuning_env(const char* name) { return getenv(name); }
+#else
+inline const char* tuning_env(const char*) { return nullptr; }
+#endif
+// Process-wide options (spiral_gpu_set_option).  fwd2: -1 = the two-digits-per-workgroup transform kernel from kFwd2Min transforms per
+// launch (ntt.hip), 0 / 1 = never / always.  Same results either way; tests force each form.
+struct Options {
+    int fold_pair = 1, fold_chain = 1, fwd2 = -1;
+    uint32_t fold_blocks = 768, sweep_mfma_min = 2;
+    size_t db_stage_bytes = (size_t)64 << 20;
+    int one_image = 1;  // a server that batches on the matrix cores keeps ONLY the limb-plane image of its database (server.cpp)
+};
+Options& options();  // server.cpp; the three documented environment variables are read once, on first use
 
 // Query lanes of one launch (server.cpp run_query_batch).  The launch-bound stages of a query -- expansion, conversion, lift, folding: ~50
 // dependent launches that cost ~5 us each whatever they carry -- take a QUERY dimension: gridDim.z = n <= kMaxLanes queries, each with its own
@@ -286,11 +305,15 @@ bool sweep_batch_ok(uint32_t num_per, uint32_t jm_total);
 void launch_sweep_batch(const uint64_t* db, const uint32_t* const* qs, uint64_t* const* acc, uint32_t n, uint32_t num_per, uint32_t jm_total, uint32_t g_log,
                         hipStream_t s);
 // the same on the matrix cores for n = 1 .. kMaxLanes queries per pass (sweep_mfma.hip): needs the "limb plane" image of the database, built
-// from the packed one by launch_db_limb_planes (as many words); where sweep_mfma_ok (>= 64 columns, first dimension a multiple of 64)
+// from the packed one by launch_db_limb_planes (as many words); where sweep_mfma_ok (>= 64 ciphertexts per slot, first dimension a power of two in
+// [64, 2048]).  Returns the launch's error (the > 64 KiB LDS opt-in is per device).  k_log: the accumulators' stage layout, as launch_sweep
 bool sweep_mfma_ok(uint32_t num_per, uint32_t jm_total);
-void launch_db_limb_planes(const uint64_t* db_packed_img, uint64_t* db_limbs, uint32_t num_per, uint32_t jm_total, hipStream_t s);
-void launch_sweep_mfma(const uint64_t* db_limbs, const uint32_t* const* qs, uint64_t* const* acc, uint32_t n, uint32_t num_per, uint32_t jm_total, uint32_t g_log,
-                       hipStream_t s);
+// nz slots z (both pointers at the first of them; a slot's region is db_device_words / kN words in either form, so a server converts its image IN PLACE
+// a few slots at a time through a staging buffer); launch_db_limb_unplanes is the inverse map (limb planes -> packed), bit-exact both ways
+void launch_db_limb_planes(const uint64_t* db_packed_img, uint64_t* db_limbs, uint32_t num_per, uint32_t jm_total, hipStream_t s, uint32_t nz = kN);
+void launch_db_limb_unplanes(const uint64_t* db_limbs, uint64_t* db_packed_img, uint32_t num_per, uint32_t jm_total, hipStream_t s, uint32_t nz = kN);
+hipError_t launch_sweep_mfma(const uint64_t* db_limbs, const uint32_t* const* qs, uint64_t* const* acc, uint32_t n, uint32_t num_per, uint32_t jm_total, uint32_t g_log,
+                             hipStream_t s, uint32_t k_log = 0);
 // reference DB layout (src/spiral.cpp:1139-1153) -> device layout, for the j-range [j0, j0 + dim0_shard): db_ref holds the nz
 // consecutive z slabs z0 .. z0+nz-1, db_dev is the base of the shard's device database
 void launch_db_relayout(const uint64_t* db_ref, uint64_t* db_dev, uint32_t num_per, uint32_t dim0, uint32_t j0, uint32_t dim0_shard, uint32_t z0,
@@ -301,10 +324,12 @@ void launch_fill_db_random(uint64_t* db_dev, uint32_t num_per, uint32_t dim0_sha
 // read the device database back in the reference's layouts (tests, spiral_gpu_server_read_db_*): one plaintext item
 // (j local to the shard) as n0 x n2 reference NTT-form polynomials, or nz slabs z0.. of load_db's layout restricted to
 // the shard's j-range (z in the reference's slot order)
-void launch_db_read_item(const uint64_t* db_dev, uint64_t* out_ref, uint32_t num_per, uint32_t dim0_shard, uint32_t j_local, uint32_t ii, hipStream_t s);
+// limbs: the image is in limb-plane form (sweep_mfma.hip) instead of the packed one
+void launch_db_read_item(const uint64_t* db_dev, uint64_t* out_ref, uint32_t num_per, uint32_t dim0_shard, uint32_t j_local, uint32_t ii, hipStream_t s,
+                         bool limbs = false);
 // (restricted to the n_ii plaintext columns ii0 .. ii0 + n_ii - 1: the same layout with num_per = n_ii)
 void launch_db_read_slots(const uint64_t* db_dev, uint64_t* out, uint32_t num_per, uint32_t dim0_shard, uint32_t z0, uint32_t nz, uint32_t ii0, uint32_t n_ii,
-                          hipStream_t s);
+                          hipStream_t s, bool limbs = false);
 void launch_fill_db1_random(uint64_t* db_dev, uint32_t num_per, uint32_t dim0, uint64_t seed, hipStream_t s);
 // the GSW-bit ciphertexts (odd slots 2 i + 1 of cv, i < n_bits) a rank of a G-rank answer expanded itself (i = a G + rank) <->
 // its block of the all-gather buffer [rank][a < n_max][2 polynomials]; pack: cv -> this rank's block, unpack: all blocks -> cv

@@ -377,11 +377,10 @@ static int pk_front(spiral_gpu_pack_server* S, const uint64_t* query) {
     uint32_t np = s.num_per;
     const uint64_t* src = S->acc.p;
     uint32_t src_stride = s.num_per;
-    // Pair form (SPIRAL_FOLD_PAIR=0 keeps the reference's two products): folding_neg = gadget - F (:1027-1032), so
+    // Pair form (option fold_pair = 0 keeps the reference's two products): folding_neg = gadget - F (:1027-1032), so
     // F_neg G^-1(L) + F G^-1(H) = L + F (G^-1(H) - G^-1(L)) -- the unsigned digits always recompose their value -- i.e. per round one lift
     // of the 2 np ciphertexts, ell digit-difference transforms per polynomial pair (LD_PDIFF) and a product of K = 2 ell terms + L.
-    const char* pair_env = getenv("SPIRAL_FOLD_PAIR");  // (read per call: tests switch it inside one process)
-    const bool pair = pair_env ? atoi(pair_env) != 0 : true;
+    const bool pair = options().fold_pair != 0;  // (read per call: tests switch it inside one process)
     uint64_t* out = S->fold_c.p;
     for (uint32_t cur = 0; cur < p.nu2; cur++) {
         np /= 2;

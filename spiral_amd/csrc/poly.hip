@@ -512,15 +512,15 @@ void launch_expand_mac_round(const ExpandMacParams& p, hipStream_t s) {
     const uint32_t cnt = p.cnt_e + p.cnt_o;
     if (cnt == 0) return;
     static const uint32_t wide_min = [] {
-        const char* e = getenv("SPIRAL_MAC_WIDE_MIN");  // tuning only
+        const char* e = tuning_env("SPIRAL_MAC_WIDE_MIN");  // tuning only
         return e ? (uint32_t)strtoul(e, nullptr, 10) : 64u;
     }();
     static const uint32_t ct2_min = [] {
-        const char* e = getenv("SPIRAL_MAC_CT2_MIN");  // tuning only
+        const char* e = tuning_env("SPIRAL_MAC_CT2_MIN");  // tuning only
         return e ? (uint32_t)strtoul(e, nullptr, 10) : 64u;
     }();
     static const uint32_t ct4_min = [] {
-        const char* e = getenv("SPIRAL_MAC_CT4_MIN");  // tuning only
+        const char* e = tuning_env("SPIRAL_MAC_CT4_MIN");  // tuning only
         return e ? (uint32_t)strtoul(e, nullptr, 10) : 128u;
     }();
     // (the thresholds count the ciphertexts of all query lanes: what matters is how many workgroups the launch has; the groups of a batch kernel
@@ -736,7 +736,7 @@ __device__ __forceinline__ void scal2mat_rec4_body(const Scal2MatParams& p, uint
 }
 static uint32_t scal2mat_wide_min() {
     static const uint32_t v = [] {
-        const char* e = getenv("SPIRAL_S2M_WIDE_MIN");  // tuning only: smallest t_conv that takes the 64 x 16 tile
+        const char* e = tuning_env("SPIRAL_S2M_WIDE_MIN");  // tuning only: smallest t_conv that takes the 64 x 16 tile
         return e ? (uint32_t)strtoul(e, nullptr, 10) : 16u;
     }();
     return v;

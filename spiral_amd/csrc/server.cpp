@@ -9,6 +9,18 @@ using namespace spiral;
 thread_local std::string spiral::host::g_err;
 using namespace spiral::host;
 
+// the process-wide options (kernels.h); the three documented environment variables give their initial values, once
+spiral::Options& spiral::options() {
+    static Options o = [] {
+        Options v;
+        if (const char* e = getenv("SPIRAL_FOLD_PAIR")) v.fold_pair = atoi(e) != 0;
+        if (const char* e = getenv("SPIRAL_SWEEP_MFMA")) v.sweep_mfma_min = (uint32_t)strtoul(e, nullptr, 10);
+        if (const char* e = getenv("SPIRAL_DB_STAGE_BYTES")) v.db_stage_bytes = (size_t)strtoull(e, nullptr, 10);
+        return v;
+    }();
+    return o;
+}
+
 // =================================================================================================
 // resident server
 // =================================================================================================
@@ -73,13 +85,23 @@ struct spiral_gpu_server {
     // run_query_batch with this server as lane 0: the captured launch sequence and the lane set it was captured for
     hipGraphExec_t graph_batch = nullptr;
     const uint64_t* batch_key[kMaxLanes] = {};  // the lanes' arenas: every pointer the capture holds is one of them plus a fixed offset
+    const uint64_t* batch_limbs = nullptr;      // the image the captured sweep reads (null: the packed one, vector-ALU passes)
+    // run_query_instances with this server as the query's server: the captured launch sequence and what it was captured for
+    hipGraphExec_t graph_inst = nullptr;
+    std::vector<uint64_t> inst_key;
     uint32_t batch_n = 0;
     // batched sweeps of sweep_mfma_min or more queries run on the matrix cores (sweep_mfma.hip) from a second image of the database, the "limb
     // planes": built from db on first use by the image's holder (the owner of a shared image), as large as db, dropped when db is reloaded.
     // SPIRAL_SWEEP_MFMA=n sets the threshold (0 = never: at most kSweepMaxBatch queries per pass, on the vector ALU)
+    // With the option one_image (default) there is no second image: the holder converts its one image to limb-plane form IN PLACE the first time a
+    // batch wants it (srv_db_set_format; single queries then sweep it with sweep_mfma_kernel<1>, which ties with the vector-ALU kernel) and back
+    // when something needs the packed form (a partial reload, a staged sweep).
     DevBuf db_limbs;
     bool limbs_valid = false, limbs_refused = false;  // refused: the allocation failed once, do not try again
     uint32_t sweep_mfma_min = 2;
+    uint32_t db_format = SPIRAL_GPU_DB_PACKED;  // holder only: the form db is in now
+    uint64_t db_epoch = 1;    // holder only: bumped when the image is reloaded or changes form -- captured sweeps of the old form must not replay
+    uint64_t epoch_seen = 0;  // the holder's epoch this server's graphs were captured under
 };
 
 namespace {
@@ -158,6 +180,9 @@ void srv_drop_graphs(spiral_gpu_server* S) {
     if (S->graph_batch) (void)hipGraphExecDestroy(S->graph_batch);
     S->graph_batch = nullptr;
     S->batch_n = 0;
+    if (S->graph_inst) (void)hipGraphExecDestroy(S->graph_inst);
+    S->graph_inst = nullptr;
+    S->inst_key.clear();
 }
 
 void srv_free(spiral_gpu_server* S, bool keep_db = false) {
@@ -202,27 +227,105 @@ void lane_detach(spiral_gpu_server* lane) {
     }
 }
 
+spiral_gpu_server* holder_of(spiral_gpu_server* S) { return S->db_owner ? S->db_owner : S; }
+const spiral_gpu_server* holder_of(const spiral_gpu_server* S) { return S->db_owner ? S->db_owner : S; }
+
+// graphs hold a sweep kernel chosen for the image's form at capture time: drop them when the holder's image has changed since
+void srv_check_epoch(spiral_gpu_server* S) {
+    const uint64_t e = holder_of(S)->db_epoch;
+    if (S->epoch_seen != e) {
+        srv_drop_graphs(S);
+        S->epoch_seen = e;
+    }
+}
+
+// Converts the holder's database image between the packed form (common.h; the vector-ALU sweep) and the limb planes (sweep_mfma.hip; the
+// matrix-core sweep) IN PLACE: a slot z's region is the same byte range in both forms, so the image goes through a staging buffer a few slots at a
+// time -- no second image, whatever the database's size.  Offline (database load time or the first batch), never inside a capture.
+int srv_db_set_format(spiral_gpu_server* H, uint32_t fmt, hipStream_t st) {
+    if (H->db_format == fmt) return 0;
+    const uint32_t np = H->s.num_per, jm = 2 * H->dim0_shard;
+    if (!sweep_mfma_ok(np, jm)) return fail("this geometry has no limb-plane form (needs >= 64 ciphertexts per slot and a power-of-two first dimension in [64, 2048])");
+    if (hipDeviceSynchronize() != hipSuccess) return fail("hipDeviceSynchronize failed");  // whatever reads or writes the image, on whichever stream
+    const size_t per_z = H->db.words / kN;
+    const uint32_t nzc = (uint32_t)std::max<size_t>(1, std::min<size_t>(kN, ((size_t)256 << 20) / (per_z * sizeof(uint64_t))));
+    DevBuf stage;
+    if (stage.alloc(per_z * nzc)) return -1;
+    hipError_t e = hipSuccess;
+    for (uint32_t z = 0; z < kN && e == hipSuccess; z += nzc) {
+        const uint32_t nz = std::min(nzc, kN - z);
+        uint64_t* region = H->db.p + (size_t)z * per_z;
+        if (fmt == SPIRAL_GPU_DB_LIMBS)
+            launch_db_limb_planes(region, stage.p, np, jm, st, nz);
+        else
+            launch_db_limb_unplanes(region, stage.p, np, jm, st, nz);
+        e = hipMemcpyAsync(region, stage.p, (size_t)nz * per_z * sizeof(uint64_t), hipMemcpyDeviceToDevice, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    stage.release();
+    if (e != hipSuccess) return fail("converting the database image failed: %s", hipGetErrorString(e));
+    H->db_format = fmt;
+    H->db_epoch++;
+    H->db_limbs.release();  // (a second image from before the option was switched on)
+    H->limbs_valid = false;
+    return 0;
+}
+// the image was (re)written in packed form by a loader
+void srv_db_loaded(spiral_gpu_server* S) {
+    S->have_db = true;
+    S->limbs_valid = false;
+    S->db_format = SPIRAL_GPU_DB_PACKED;
+    S->db_epoch++;
+}
+
 // the first-dimension sweep of n queries against one database image: one pass on the matrix cores when the limb-plane image is given, else passes of
 // up to kSweepMaxBatch queries on the vector ALU (wide packed geometries), else one sweep per query
-void sweep_queries(const spiral_gpu_server* S, const uint64_t* limbs, const uint32_t* const* qs, uint64_t* const* acc, uint32_t n, uint32_t g_log, hipStream_t st) {
+int sweep_queries(const spiral_gpu_server* S, const uint64_t* limbs, const uint32_t* const* qs, uint64_t* const* acc, uint32_t n, uint32_t g_log, hipStream_t st,
+                  uint32_t k_log = 0) {
     const uint32_t np = S->s.num_per, jm = 2 * S->dim0_shard;
-    if (limbs) return launch_sweep_mfma(limbs, qs, acc, n, np, jm, g_log, st);
+    const spiral_gpu_server* H = holder_of(S);
+    if (!limbs && H->db_format == SPIRAL_GPU_DB_LIMBS) limbs = H->db.p;  // the one image is in limb-plane form: every sweep is the matrix-core one
+    if (limbs) {
+        const hipError_t e = launch_sweep_mfma(limbs, qs, acc, n, np, jm, g_log, st, k_log);
+        return e == hipSuccess ? 0 : fail("the matrix-core sweep could not be launched: %s", hipGetErrorString(e));
+    }
     const uint32_t step = sweep_batch_ok(np, jm) ? kSweepMaxBatch : 1;
     for (uint32_t b0 = 0; b0 < n; b0 += step) {
         const uint32_t nb = n - b0 < step ? n - b0 : step;
         if (nb == 1)
-            launch_sweep(S->db.p, qs[b0], acc[b0], np, jm, g_log, st);
+            launch_sweep(S->db.p, qs[b0], acc[b0], np, jm, g_log, st, k_log);
         else
             launch_sweep_batch(S->db.p, qs + b0, acc + b0, nb, np, jm, g_log, st);
     }
+    return 0;
 }
+// one query's sweep (all stages, or one stage of a pipelined sweep: packed image only) of the image H holds, in whichever form it is in, with S's
+// query records into S's accumulators on S's stream (H = S's own holder, or another instance of the database: run_query_instances)
+int sweep_with(spiral_gpu_server* S, const spiral_gpu_server* H, int stage) {
+    if (H->db_format == SPIRAL_GPU_DB_LIMBS) {
+        if (stage >= 0 && S->sweep_k_log)
+            return fail("a staged sweep needs the packed database image, and a batch has since converted it to limb planes: call set_sweep_stages again (or set option one_image = 0)");
+        const uint32_t* qs[1] = {(const uint32_t*)S->qs.p};
+        uint64_t* acc[1] = {S->acc};
+        const hipError_t e = launch_sweep_mfma(H->db.p, qs, acc, 1, S->s.num_per, 2 * S->dim0_shard, S->fold_g_log, S->stream, S->sweep_k_log);
+        return e == hipSuccess ? 0 : fail("the matrix-core sweep could not be launched: %s", hipGetErrorString(e));
+    }
+    launch_sweep(H->db.p, (const uint32_t*)S->qs.p, S->acc, S->s.num_per, 2 * S->dim0_shard, S->fold_g_log, S->stream, S->sweep_k_log, stage);
+    return 0;
+}
+int sweep_one(spiral_gpu_server* S, int stage) { return sweep_with(S, holder_of(S), stage); }
 
 // The limb-plane image for a batched sweep of n queries on the matrix cores, or nullptr when that sweep does not apply (threshold, geometry) --
 // then *rc stays 0 -- or could not be built (*rc = -1).  Built once per database load by the image's holder; never call this inside a capture.
 const uint64_t* limb_image(spiral_gpu_server* S, uint32_t n, int* rc) {
     *rc = 0;
+    spiral_gpu_server* H = holder_of(S);
+    if (H->db_format == SPIRAL_GPU_DB_LIMBS) return H->db.p;  // (whatever the threshold says: there is no other image to sweep)
     if (S->sweep_mfma_min == 0 || n < S->sweep_mfma_min || !sweep_mfma_ok(S->s.num_per, 2 * S->dim0_shard)) return nullptr;
-    spiral_gpu_server* H = S->db_owner ? S->db_owner : S;
+    if (options().one_image) {  // the one image changes form, in place
+        *rc = srv_db_set_format(H, SPIRAL_GPU_DB_LIMBS, S->stream);
+        return *rc ? nullptr : H->db.p;
+    }
     if (H->limbs_valid) return H->db_limbs.p;
     if (H->limbs_refused) return nullptr;
     if (!H->db_limbs.p && H->db_limbs.alloc(H->db.words)) {
@@ -296,6 +399,35 @@ int download_pk_as_ref(spiral_gpu_server* S, const uint64_t* pk, IndexMap map, u
 extern "C" {
 
 int spiral_gpu_abi_version(void) { return SPIRAL_GPU_ABI_VERSION; }
+
+int spiral_gpu_set_option(const char* name, int64_t value) {
+    if (!name) return fail("null option name");
+    Options& o = options();
+    const std::string n = name;
+    if (n == "fold_pair") o.fold_pair = value != 0;
+    else if (n == "fold_chain") o.fold_chain = value != 0;
+    else if (n == "fold_blocks" && value >= 0) o.fold_blocks = (uint32_t)value;
+    else if (n == "sweep_mfma_min" && value >= 0) o.sweep_mfma_min = (uint32_t)value;
+    else if (n == "one_image") o.one_image = value != 0;
+    else if (n == "fwd2" && value >= -1 && value <= 1) o.fwd2 = (int)value;
+    else if (n == "db_stage_bytes" && value > 0) o.db_stage_bytes = (size_t)value;
+    else return fail("unknown option '%s' or value %lld out of range", name, (long long)value);
+    return 0;
+}
+int spiral_gpu_get_option(const char* name, int64_t* value) {
+    if (!name || !value) return fail("null argument");
+    const Options& o = options();
+    const std::string n = name;
+    if (n == "fold_pair") *value = o.fold_pair;
+    else if (n == "fold_chain") *value = o.fold_chain;
+    else if (n == "fold_blocks") *value = o.fold_blocks;
+    else if (n == "sweep_mfma_min") *value = o.sweep_mfma_min;
+    else if (n == "one_image") *value = o.one_image;
+    else if (n == "fwd2") *value = o.fwd2;
+    else if (n == "db_stage_bytes") *value = (int64_t)o.db_stage_bytes;
+    else return fail("unknown option '%s'", name);
+    return 0;
+}
 const char* spiral_gpu_last_error(void) { return g_err.c_str(); }
 int spiral_gpu_device_count(void) {
     int n = 0;
@@ -569,9 +701,10 @@ int spiral_gpu_multiply_queries_by_database(uint64_t* outputs, const uint64_t* r
         acc[b] = d_acc + b * num_per * 6 * kN;
         launch_qs_from_reoriented(d_re + b * (size_t)kN * dim0 * 8, (uint32_t*)qs[b], (uint32_t)(2 * dim0), 0);
     }
-    if (mfma)
-        launch_sweep_mfma(d_limbs, qs, acc, (uint32_t)n, (uint32_t)num_per, (uint32_t)(2 * dim0), 0, 0);
-    else
+    if (mfma) {
+        const hipError_t e = launch_sweep_mfma(d_limbs, qs, acc, (uint32_t)n, (uint32_t)num_per, (uint32_t)(2 * dim0), 0, 0);
+        if (e != hipSuccess) return fail("the matrix-core sweep could not be launched: %s", hipGetErrorString(e));
+    } else
         for (size_t b0 = 0; b0 < n; b0 += 2) {
             if (n - b0 >= 2 && sweep_batch_ok((uint32_t)num_per, (uint32_t)(2 * dim0)))
                 launch_sweep_batch(d_db, qs + b0, acc + b0, 2, (uint32_t)num_per, (uint32_t)(2 * dim0), 0, 0);
@@ -741,10 +874,13 @@ static int srv_create(const spiral_gpu_params* p, int device, uint32_t j_begin, 
     S->j0 = j_begin;
     S->j1 = j_end;
     S->dim0_shard = j_end - j_begin;
-    if (const char* e = getenv("SPIRAL_FOLD_CHAIN")) S->fold_chain = atoi(e) != 0;
-    if (const char* e = getenv("SPIRAL_FOLD_PAIR")) S->fold_pair = atoi(e) != 0;
-    if (const char* e = getenv("SPIRAL_FOLD_BLOCKS")) S->fold_blocks = (uint32_t)strtoul(e, nullptr, 10);
-    if (const char* e = getenv("SPIRAL_SWEEP_MFMA")) S->sweep_mfma_min = (uint32_t)strtoul(e, nullptr, 10);
+    {  // the process-wide options as they stand now (spiral_gpu_set_option; SPIRAL_FOLD_PAIR / SPIRAL_SWEEP_MFMA give their initial values)
+        const Options& o = options();
+        S->fold_chain = o.fold_chain != 0;
+        S->fold_pair = o.fold_pair != 0;
+        S->fold_blocks = o.fold_blocks;
+        S->sweep_mfma_min = o.sweep_mfma_min;
+    }
     if (p->direct_upload || s.stopround == 0) {
         S->pos_stride = 1;
         S->pos_first = 0;
@@ -832,8 +968,7 @@ int spiral_gpu_server_load_db(spiral_gpu_server* S, const uint64_t* database) {
     HIP_OK(hipSetDevice(S->device));
     // stage the reference-layout database one z-slab group at a time and re-lay the shard
     const size_t per_z_ref = (size_t)S->s.num_per * 2 * S->s.dim0 * 2;
-    size_t stage_bytes = (size_t)64 << 20;
-    if (const char* e = getenv("SPIRAL_DB_STAGE_BYTES")) stage_bytes = strtoull(e, nullptr, 10);  // tests: force several staging passes
+    const size_t stage_bytes = options().db_stage_bytes;  // (tests force several staging passes)
     const uint32_t zchunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(kN, stage_bytes / (per_z_ref * sizeof(uint64_t))));
     DevBuf st;
     if (st.alloc(per_z_ref * zchunk)) return -1;
@@ -851,8 +986,7 @@ int spiral_gpu_server_load_db(spiral_gpu_server* S, const uint64_t* database) {
         }
     }
     st.release();
-    S->have_db = true;
-    S->limbs_valid = false;
+    srv_db_loaded(S);
     return 0;
 }
 
@@ -876,8 +1010,7 @@ int spiral_gpu_server_gen_db(spiral_gpu_server* S, uint64_t seed) {
         launch_ntt_forward(S->tb, fp, LD_DBGEN, ST_DB, (uint32_t)(std::min(chunk, items - done) * 4), S->stream);
     }
     HIP_OK(hipStreamSynchronize(S->stream));
-    S->have_db = true;
-    S->limbs_valid = false;
+    srv_db_loaded(S);
     return 0;
 }
 
@@ -899,6 +1032,8 @@ int spiral_gpu_server_load_db_items(spiral_gpu_server* S, const void* items, uin
     fp.dim0_shard = S->dim0_shard;
     fp.j0 = S->j0;
     fp.coeff_bits = coeff_bits;
+    // a partial load scatters packed words into the image: an image a batch has converted to limb planes goes back to the packed form first
+    if (S->db_format != SPIRAL_GPU_DB_PACKED && srv_db_set_format(S, SPIRAL_GPU_DB_PACKED, S->stream)) return -1;
     if (ingest_items(items, coeff_bits, first_item, lo, hi, 4, S->p.p_db, S->stream, [&](const uint8_t* d_items, uint32_t* d_err, uint64_t first, uint64_t n) {
             fp.items = d_items;
             fp.err = d_err;
@@ -906,8 +1041,7 @@ int spiral_gpu_server_load_db_items(spiral_gpu_server* S, const void* items, uin
             launch_ntt_forward(S->tb, fp, LD_DBGEN, ST_DB, (uint32_t)(n * 4), S->stream);
         }))
         return -1;
-    S->have_db = true;
-    S->limbs_valid = false;
+    srv_db_loaded(S);
     return 0;
 }
 
@@ -920,7 +1054,8 @@ int spiral_gpu_server_read_db_item(spiral_gpu_server* S, uint64_t item, uint64_t
     uint64_t* d = sc.get(4 * kRefNtt);
     if (!d) return fail("device allocation failed");
     HIP_OK(hipStreamSynchronize(S->stream));
-    launch_db_read_item(S->db.p, d, S->s.num_per, S->dim0_shard, (uint32_t)(j - S->j0), (uint32_t)(item % S->s.num_per), S->stream);
+    launch_db_read_item(S->db.p, d, S->s.num_per, S->dim0_shard, (uint32_t)(j - S->j0), (uint32_t)(item % S->s.num_per), S->stream,
+                        holder_of(S)->db_format == SPIRAL_GPU_DB_LIMBS);
     HIP_OK(hipMemcpyAsync(out, d, 4 * kRefNtt * sizeof(uint64_t), hipMemcpyDeviceToHost, S->stream));
     HIP_OK(hipStreamSynchronize(S->stream));
     return 0;
@@ -938,7 +1073,7 @@ static int read_db_region(spiral_gpu_server* S, uint32_t z_begin, uint32_t nz, u
     hipError_t e = hipSuccess;
     for (uint32_t z = 0; z < nz && e == hipSuccess; z += zchunk) {
         const uint32_t n = std::min(zchunk, nz - z);
-        launch_db_read_slots(S->db.p, st.p, S->s.num_per, S->dim0_shard, z_begin + z, n, ii0, n_ii, S->stream);
+        launch_db_read_slots(S->db.p, st.p, S->s.num_per, S->dim0_shard, z_begin + z, n, ii0, n_ii, S->stream, holder_of(S)->db_format == SPIRAL_GPU_DB_LIMBS);
         e = hipMemcpyAsync(out + (size_t)z * per_z, st.p, (size_t)n * per_z * sizeof(uint64_t), hipMemcpyDeviceToHost, S->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(S->stream);
     }
@@ -954,14 +1089,28 @@ int spiral_gpu_server_read_db_columns(spiral_gpu_server* S, uint32_t ii_begin, u
     return read_db_region(S, 0, kN, ii_begin, n_ii, out);
 }
 
+int spiral_gpu_server_set_db_format(spiral_gpu_server* S, int format) {
+    if (!S) return fail("null server");
+    if (format != SPIRAL_GPU_DB_PACKED && format != SPIRAL_GPU_DB_LIMBS) return fail("unknown database image format %d", format);
+    if (S->db_shared) return fail("this server sweeps another server's database image: convert it through the owner");
+    if (!S->have_db) return fail("no database loaded");
+    HIP_OK(hipSetDevice(S->device));
+    return srv_db_set_format(S, (uint32_t)format, S->stream);
+}
+int spiral_gpu_server_db_format(spiral_gpu_server* S) { return S ? (int)holder_of(S)->db_format : -1; }
+uint64_t spiral_gpu_server_db_device_bytes(spiral_gpu_server* S) {
+    if (!S) return 0;
+    const spiral_gpu_server* H = holder_of(S);
+    return (uint64_t)(H->db.p ? H->db.words : 0) * 8u + (uint64_t)(H->db_limbs.p ? H->db_limbs.words : 0) * 8u;
+}
+
 int spiral_gpu_server_fill_db_random(spiral_gpu_server* S, uint64_t seed) {
     if (!S) return fail("null server");
     if (S->db_shared) return fail("this server sweeps another server's database image (share_db): load it through the owner");
     HIP_OK(hipSetDevice(S->device));
     launch_fill_db_random(S->db.p, S->s.num_per, S->dim0_shard, seed, S->stream);
     HIP_OK(hipStreamSynchronize(S->stream));
-    S->have_db = true;
-    S->limbs_valid = false;
+    srv_db_loaded(S);
     return 0;
 }
 
@@ -984,6 +1133,9 @@ int spiral_gpu_server_share_db(spiral_gpu_server* S, spiral_gpu_server* owner) {
     srv_drop_graphs(S);  // captured sweeps hold the old image's address
     if (S->n_lanes > 0) return fail("share_db: this server's own image is swept by %u lanes", S->n_lanes);
     if (!S->db_shared) S->db.release();
+    S->db_limbs.release();  // (a second image of the database this server gives up)
+    S->limbs_valid = S->limbs_refused = false;
+    S->db_format = SPIRAL_GPU_DB_PACKED;
     if (S->db_owner != owner) {
         lane_detach(S);
         lane_attach(S, owner);
@@ -1162,9 +1314,8 @@ int spiral_gpu_server_first_dim(spiral_gpu_server* S) {
     if (!S) return fail("null server");
     HIP_OK(hipSetDevice(S->device));
     if (!S->have_db) return fail("no database loaded");
-    launch_sweep(S->db.p, (const uint32_t*)S->qs.p, S->acc, S->s.num_per, 2 * S->dim0_shard, S->fold_g_log, S->stream, S->sweep_k_log);
     S->raw_from_acc = false;
-    return 0;
+    return sweep_one(S, -1);
 }
 
 // Pipelined sweep (N > 1): the output columns are independent (src/spiral.cpp:628-999 loops over i and c outside j), so a rank may
@@ -1180,6 +1331,8 @@ int spiral_gpu_server_set_sweep_stages(spiral_gpu_server* S, uint32_t n_stages) 
     if (!sweep_stages_ok(S->s.num_per, 2 * S->dim0_shard, S->fold_g_log, k_log))
         return fail("%u sweep stages: needs the packed layout, whole 64-column blocks per stage (at most %u stages here) and a ciphertext per rank and stage", n_stages,
                     S->s.num_per / 32);
+    // stage-by-stage launches exist for the packed image only: an image a batch has converted to limb planes goes back (its holder's lanes re-capture)
+    if (k_log && holder_of(S)->db_format != SPIRAL_GPU_DB_PACKED && srv_db_set_format(holder_of(S), SPIRAL_GPU_DB_PACKED, S->stream)) return -1;
     S->sweep_k_log = k_log;
     srv_drop_graphs(S);
     return 0;
@@ -1198,9 +1351,8 @@ int spiral_gpu_server_first_dim_stage(spiral_gpu_server* S, uint32_t stage) {
     if (!S->have_db) return fail("no database loaded");
     if (stage >= (1u << S->sweep_k_log)) return fail("stage %u of %u", stage, 1u << S->sweep_k_log);
     if (S->sweep_k_log == 0) return spiral_gpu_server_first_dim(S);
-    launch_sweep(S->db.p, (const uint32_t*)S->qs.p, S->acc, S->s.num_per, 2 * S->dim0_shard, S->fold_g_log, S->stream, S->sweep_k_log, (int)stage);
     S->raw_from_acc = false;
-    return 0;
+    return sweep_one(S, (int)stage);
 }
 
 // One pass over the database for the queries of n servers that sweep the SAME image (an owner and its lanes, create_lane /
@@ -1232,7 +1384,7 @@ int spiral_gpu_server_first_dim_batch(spiral_gpu_server* const* servers, uint32_
     int rc = 0;
     const uint64_t* limbs = limb_image(S0, n, &rc);
     if (rc) return rc;
-    if (!limbs && !sweep_batch_ok(S0->s.num_per, 2 * S0->dim0_shard)) {
+    if (!limbs && !sweep_batch_ok(S0->s.num_per, 2 * S0->dim0_shard)) {  // (a packed image: limb planes always come back as `limbs`)
         for (uint32_t b = 0; b < n; b++)
             if (spiral_gpu_server_first_dim(servers[b])) return -1;
         return 0;
@@ -1242,7 +1394,7 @@ int spiral_gpu_server_first_dim_batch(spiral_gpu_server* const* servers, uint32_
         HIP_OK(hipEventRecord(servers[b]->ev_batch, servers[b]->stream));
         HIP_OK(hipStreamWaitEvent(S0->stream, servers[b]->ev_batch, 0));
     }
-    sweep_queries(S0, limbs, qs, acc, n, S0->fold_g_log, S0->stream);
+    if (sweep_queries(S0, limbs, qs, acc, n, S0->fold_g_log, S0->stream)) return -1;
     for (uint32_t b = 0; b < n; b++) servers[b]->raw_from_acc = false;
     HIP_OK(hipEventRecord(S0->ev_batch, S0->stream));
     for (uint32_t b = 1; b < n; b++)
@@ -1464,6 +1616,7 @@ namespace {
 template <class F>
 int run_group(spiral_gpu_server* S, int slot, hipStream_t st, F body) {
     if (!S->use_graphs) return body();
+    srv_check_epoch(S);
     if (!S->graph[slot]) {
         if (st == nullptr) return fail("graph capture needs a non-default stream");
         HIP_OK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
@@ -1475,7 +1628,7 @@ int run_group(spiral_gpu_server* S, int slot, hipStream_t st, F body) {
             return rc;
         }
         if (e != hipSuccess) return fail("hipStreamEndCapture failed: %s", hipGetErrorString(e));
-        if (const char* dot = getenv("SPIRAL_GRAPH_DOT")) {  // debugging aid: <prefix>.<slot>.dot
+        if (const char* dot = tuning_env("SPIRAL_GRAPH_DOT")) {  // debugging aid: <prefix>.<slot>.dot
             const std::string path = std::string(dot) + "." + std::to_string(slot) + ".dot";
             (void)hipGraphDebugDotPrint(g, path.c_str(), 0);
         }
@@ -1587,14 +1740,16 @@ int spiral_gpu_server_run_query_batch(spiral_gpu_server* const* servers, uint32_
             qs[b] = (const uint32_t*)(S->qs.p + lanes.off[b]);
             acc[b] = S->acc + lanes.off[b];
         }
-        sweep_queries(S, limbs, qs, acc, n, 0, S->stream);  // one pass on the matrix cores where the limb-plane image exists
+        if (sweep_queries(S, limbs, qs, acc, n, 0, S->stream)) return -1;  // one pass on the matrix cores where the limb-plane image exists
         return run_fold_rounds(S, S->s.num_per, 0, S->p.nu2, S->acc, false, true, nullptr, lanes);
     };
     int rc = 0;
     if (!S->use_graphs) {
         rc = body();
     } else {
-        bool same = S->graph_batch && S->batch_n == n;
+        srv_check_epoch(S);  // (limb_image above may just have changed the image's form)
+        // the capture bakes in the lanes' arenas, the image the sweep reads and its kernel (limbs or not)
+        bool same = S->graph_batch && S->batch_n == n && S->batch_limbs == limbs;
         for (uint32_t b = 0; same && b < n; b++) same = S->batch_key[b] == servers[b]->w_left.p;
         if (!same) {
             if (S->graph_batch) (void)hipGraphExecDestroy(S->graph_batch);
@@ -1611,6 +1766,7 @@ int spiral_gpu_server_run_query_batch(spiral_gpu_server* const* servers, uint32_
             (void)hipGraphDestroy(g);
             if (e2 != hipSuccess) return fail("hipGraphInstantiate failed: %s", hipGetErrorString(e2));
             S->batch_n = n;
+            S->batch_limbs = limbs;
             for (uint32_t b = 0; b < n; b++) S->batch_key[b] = servers[b]->w_left.p;
         }
         HIP_OK(hipGraphLaunch(S->graph_batch, S->stream));
@@ -1625,6 +1781,73 @@ int spiral_gpu_server_run_query_batch(spiral_gpu_server* const* servers, uint32_
     if (other) HIP_OK(hipEventRecord(S->ev_batch, S->stream));
     for (uint32_t b = 1; b < n; b++)
         if (servers[b]->stream != S->stream) HIP_OK(hipStreamWaitEvent(servers[b]->stream, S->ev_batch, 0));
+    return 0;
+}
+
+// One query against n INSTANCES of the database.  An item larger than one plaintext (configs[3]: 100 KB items, 15 360-byte plaintexts) is
+// factor = ceil(item / plaintext) database instances (select_params.py:297-298); the client sends ONE query, the server expands and converts it once and
+// answers it against every instance: first dimension + folding + response switch per instance, `factor` responses (the reference runs one instance and
+// multiplies fdim_us, fold_us and the response size by the factor, select_params.py:409-418).  S holds the query (its public parameters, query, records,
+// keys, accumulators); instances[k] hold the images (servers with the same geometry on the same device, each with its own database; S may be one of them).
+// pre != 0: expansion + conversion first (run_pre's work), else S must have converted its query already.  Instance k's switched response goes to
+// responses + k * 6 * 2048 words and, when finals != null, its folded ciphertext to finals + k * 6 * 2048 (device pointers).  One launch sequence on S's
+// stream, sweeps back to back; a hipGraph per (instance set, output buffers) when S has use_graphs on.
+int spiral_gpu_server_run_query_instances(spiral_gpu_server* S, spiral_gpu_server* const* instances, uint32_t n, int pre, void* responses, void* finals) {
+    if (!S || !instances || n == 0 || !responses) return fail("null argument");
+    HIP_OK(hipSetDevice(S->device));
+    if (!S->have_query || !S->have_pp) return fail("query and public parameters must be set first");
+    if (!pre && !S->have_records) return fail("run_query_instances: the query has not been converted (run_pre first, or pass pre = 1)");
+    if (S->overlap || S->fold_g_log || S->sweep_k_log || S->ex_shard.g_log || S->keep_cts || S->acc != S->acc_own.p)
+        return fail("run_query_instances needs the default schedule on the query's server (own accumulators, no split / sharded / staged options)");
+    std::vector<uint64_t> key{(uint64_t)(uintptr_t)responses, (uint64_t)(uintptr_t)finals, (uint64_t)(pre != 0)};
+    for (uint32_t k = 0; k < n; k++) {
+        const spiral_gpu_server* I = instances[k];
+        if (!I) return fail("null instance %u", k);
+        const spiral_gpu_server* H = holder_of(I);
+        if (!I->have_db) return fail("run_query_instances: instance %u has no database", k);
+        if (I->device != S->device || I->j0 != S->j0 || I->dim0_shard != S->dim0_shard || I->p.nu1 != S->p.nu1 || I->p.nu2 != S->p.nu2 || I->p.p_db != S->p.p_db ||
+            I->p.direct_upload != S->p.direct_upload)
+            return fail("run_query_instances: instance %u differs from the query's server in device, shard, database geometry or plaintext modulus", k);
+        key.push_back((uint64_t)(uintptr_t)I->db.p);
+        key.push_back(H->db_epoch);
+    }
+    if (srv_join_side(S)) return -1;
+    auto body = [&]() {
+        if (pre && expand_convert(S)) return -1;
+        for (uint32_t k = 0; k < n; k++) {
+            if (sweep_with(S, holder_of(instances[k]), -1)) return -1;
+            if (run_fold_rounds(S, S->s.num_per, 0, S->p.nu2, S->acc, false, true)) return -1;
+            HIP_OK(hipMemcpyAsync((uint64_t*)responses + (size_t)k * 6 * kN, S->resp.p, 6 * kPolyBytes, hipMemcpyDeviceToDevice, S->stream));
+            if (finals) HIP_OK(hipMemcpyAsync((uint64_t*)finals + (size_t)k * 6 * kN, S->raw.p, 6 * kPolyBytes, hipMemcpyDeviceToDevice, S->stream));
+        }
+        return 0;
+    };
+    int rc = 0;
+    if (!S->use_graphs) {
+        rc = body();
+    } else {
+        srv_check_epoch(S);
+        if (!S->graph_inst || S->inst_key != key) {
+            if (S->graph_inst) (void)hipGraphExecDestroy(S->graph_inst);
+            S->graph_inst = nullptr;
+            HIP_OK(hipStreamBeginCapture(S->stream, hipStreamCaptureModeRelaxed));
+            rc = body();
+            hipGraph_t g = nullptr;
+            const hipError_t e = hipStreamEndCapture(S->stream, &g);
+            if (rc || e != hipSuccess) {
+                if (g) (void)hipGraphDestroy(g);
+                return rc ? rc : fail("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+            }
+            const hipError_t e2 = hipGraphInstantiate(&S->graph_inst, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e2 != hipSuccess) return fail("hipGraphInstantiate failed: %s", hipGetErrorString(e2));
+            S->inst_key = key;
+        }
+        HIP_OK(hipGraphLaunch(S->graph_inst, S->stream));
+    }
+    if (rc) return rc;
+    if (pre) S->have_records = true;
+    S->raw_from_acc = false;
     return 0;
 }
 
@@ -1927,7 +2150,8 @@ int spiral_gpu_server_time_sweep(spiral_gpu_server* S, int iters, float* avg_ms)
     if (!S->have_db) return fail("no database loaded");
     HIP_OK(hipSetDevice(S->device));
     HIP_OK(hipEventRecord(S->ev[0], S->stream));
-    for (int i = 0; i < iters; i++) launch_sweep(S->db.p, (const uint32_t*)S->qs.p, S->acc, S->s.num_per, 2 * S->dim0_shard, S->fold_g_log, S->stream, S->sweep_k_log);
+    for (int i = 0; i < iters; i++)
+        if (sweep_one(S, -1)) return -1;
     S->raw_from_acc = false;
     HIP_OK(hipEventRecord(S->ev[1], S->stream));
     HIP_OK(hipStreamSynchronize(S->stream));
@@ -1957,7 +2181,8 @@ int spiral_gpu_server_time_sweep_batch(spiral_gpu_server* const* servers, uint32
     if (rc) return rc;
     HIP_OK(hipDeviceSynchronize());  // (the lanes' streams: their records are complete)
     HIP_OK(hipEventRecord(S->ev[0], S->stream));
-    for (int i = 0; i < iters; i++) sweep_queries(S, limbs, qs, acc, n, S->fold_g_log, S->stream);
+    for (int i = 0; i < iters; i++)
+        if (sweep_queries(S, limbs, qs, acc, n, S->fold_g_log, S->stream)) return -1;
     HIP_OK(hipEventRecord(S->ev[1], S->stream));
     HIP_OK(hipStreamSynchronize(S->stream));
     float ms = 0;

@@ -292,7 +292,7 @@ void launch_sweep(const uint64_t* db, const uint32_t* qs, uint64_t* acc, uint32_
     bt.acc[0] = acc;
     if (db_packed(nic, dim0)) {
         static const bool stage_recs = [] {
-            const char* e = getenv("SPIRAL_SWEEP_STAGE");  // tuning only: 0 = narrow geometries load their records per lane
+            const char* e = tuning_env("SPIRAL_SWEEP_STAGE");  // tuning only: 0 = narrow geometries load their records per lane
             return e ? atoi(e) != 0 : true;
         }();
         if (nic >= 64) {
@@ -339,17 +339,19 @@ void launch_db_relayout(const uint64_t* db_ref, uint64_t* db_dev, uint32_t num_p
 
 // ---- database read-back (tests / inspection): the inverse maps of the two loaders above ----------------------------------
 __global__ __launch_bounds__(256) void db_read_item_kernel(const uint64_t* __restrict__ dev, uint64_t* __restrict__ out, uint32_t num_per, uint32_t dim0_shard,
-                                                           uint32_t jl, uint32_t ii) {
+                                                           uint32_t jl, uint32_t ii, uint32_t limbs) {
     const uint32_t z = blockIdx.x * 256u + threadIdx.x, mc = blockIdx.y, m = mc >> 1, c = mc & 1u;  // polynomial (m, c) of the n0 x n2 plaintext
-    const uint64_t v = db_get_word(dev, pk_pos(z), jl, ii * 2u + c, m, 2u * num_per, dim0_shard);
+    const uint64_t v = limbs ? db_get_word_limbs(dev, pk_pos(z), jl, ii * 2u + c, m, 2u * num_per, dim0_shard)
+                             : db_get_word(dev, pk_pos(z), jl, ii * 2u + c, m, 2u * num_per, dim0_shard);
     out[(size_t)mc * (2 * kN) + z] = lo32(v);
     out[(size_t)mc * (2 * kN) + kN + z] = hi32(v);
 }
-void launch_db_read_item(const uint64_t* db_dev, uint64_t* out_ref, uint32_t num_per, uint32_t dim0_shard, uint32_t j_local, uint32_t ii, hipStream_t s) {
-    hipLaunchKernelGGL(db_read_item_kernel, dim3(kN / 256, 4), dim3(256), 0, s, db_dev, out_ref, num_per, dim0_shard, j_local, ii);
+void launch_db_read_item(const uint64_t* db_dev, uint64_t* out_ref, uint32_t num_per, uint32_t dim0_shard, uint32_t j_local, uint32_t ii, hipStream_t s,
+                         bool limbs) {
+    hipLaunchKernelGGL(db_read_item_kernel, dim3(kN / 256, 4), dim3(256), 0, s, db_dev, out_ref, num_per, dim0_shard, j_local, ii, limbs ? 1u : 0u);
 }
 __global__ __launch_bounds__(256) void db_read_slots_kernel(const uint64_t* __restrict__ dev, uint64_t* __restrict__ out, uint32_t num_per, uint32_t dim0_shard,
-                                                            uint32_t z0, uint32_t nz, uint32_t ii0, uint32_t n_ii) {
+                                                            uint32_t z0, uint32_t nz, uint32_t ii0, uint32_t n_ii, uint32_t limbs) {
     const size_t o = (size_t)blockIdx.x * 256u + threadIdx.x, per_z = (size_t)n_ii * 2u * dim0_shard * 2u;
     const uint32_t zl = (uint32_t)(o / per_z);
     if (zl >= nz) return;
@@ -359,12 +361,14 @@ __global__ __launch_bounds__(256) void db_read_slots_kernel(const uint64_t* __re
     const uint32_t jl = (uint32_t)(rem % dim0_shard);
     rem /= dim0_shard;
     const uint32_t c = (uint32_t)(rem & 1u), ii = ii0 + (uint32_t)(rem >> 1);
-    out[o] = db_get_word(dev, pk_pos(z0 + zl), jl, ii * 2u + c, m, 2u * num_per, dim0_shard);
+    out[o] = limbs ? db_get_word_limbs(dev, pk_pos(z0 + zl), jl, ii * 2u + c, m, 2u * num_per, dim0_shard)
+                   : db_get_word(dev, pk_pos(z0 + zl), jl, ii * 2u + c, m, 2u * num_per, dim0_shard);
 }
 void launch_db_read_slots(const uint64_t* db_dev, uint64_t* out, uint32_t num_per, uint32_t dim0_shard, uint32_t z0, uint32_t nz, uint32_t ii0, uint32_t n_ii,
-                          hipStream_t s) {
+                          hipStream_t s, bool limbs) {
     const size_t words = (size_t)nz * n_ii * 2u * dim0_shard * 2u;
-    hipLaunchKernelGGL(db_read_slots_kernel, dim3((uint32_t)((words + 255) / 256)), dim3(256), 0, s, db_dev, out, num_per, dim0_shard, z0, nz, ii0, n_ii);
+    hipLaunchKernelGGL(db_read_slots_kernel, dim3((uint32_t)((words + 255) / 256)), dim3(256), 0, s, db_dev, out, num_per, dim0_shard, z0, nz, ii0, n_ii,
+                       limbs ? 1u : 0u);
 }
 
 // reference reorientCiphertexts layout (src/spiral.cpp:410-433): z*(dim0*2*4) + j*8 + m*4 + r

@@ -24,6 +24,7 @@
 // A wave owns (z, 16 columns) and streams its 2 x K/128 x 7 KiB front to back, one 1 KiB load instruction at a time.
 // The B operands (query limbs) are built in LDS from the lanes' ordinary 48-byte query records by the workgroup (all its waves share z) and read
 // back with conflict-free ds_read_b128.
+#include <atomic>
 #include <cstdlib>
 #include "common.h"
 #include "kernels.h"
@@ -49,11 +50,11 @@ __device__ __forceinline__ void limbs_of_group(const uint32_t (&d)[28], uint32_t
 
 // packed image -> limb planes.  One wave per (z, block of 16 columns, piece of 128 terms); lane l = (column l & 15, term block l >> 4)
 // reads the two 112-byte groups (8 j each) that hold its 2 x 16 terms and writes its 16 bytes of each of the 2 x 7 pieces.
-__global__ __launch_bounds__(256) void db_limb_planes_kernel(const uint64_t* __restrict__ packed, uint4* __restrict__ limbs, uint32_t nic, uint32_t dim0) {
+__global__ __launch_bounds__(256) void db_limb_planes_kernel(const uint64_t* __restrict__ packed, uint4* __restrict__ limbs, uint32_t nic, uint32_t dim0, uint32_t nz) {
     const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t nk2 = dim0 >> 6, nblk16 = nic >> 4;
     const uint32_t kc2 = wave % nk2, icb = (wave / nk2) % nblk16, z = wave / (nk2 * nblk16);
-    if (z >= kN) return;
+    if (z >= nz) return;
     const uint32_t ic = icb * 16u + (lane & 15u), kblk = lane >> 4, groups = dim0 >> 3;
     const uint4* src = reinterpret_cast<const uint4*>(packed) + ((size_t)(z * (nic >> 6) + (ic >> 6)) * groups) * 7u * 64u + (ic & 63u);
     uint32_t lp[3][2][4] = {}, lb[3][2][4] = {}, np[4] = {}, nb[4] = {};
@@ -90,6 +91,69 @@ __global__ __launch_bounds__(256) void db_limb_planes_kernel(const uint64_t* __r
         }
     dst[(size_t)6u * 64u] = make_uint4(np[0], np[1], np[2], np[3]);
     dst[((size_t)nk2 * 7u + 6u) * 64u] = make_uint4(nb[0], nb[1], nb[2], nb[3]);
+}
+
+// limb planes -> packed image: the inverse map, same wave and lane assignment (the two forms are bijective on residues below the moduli, so
+// packed -> limbs -> packed reproduces every byte: tests/test_gpu_parity.py::test_db_format_round_trip)
+template <int T>
+__device__ __forceinline__ void put_field28(uint32_t (&d)[28], uint32_t v) {
+    constexpr uint32_t bit = 28u * T, w = bit >> 5, sh = bit & 31u;
+    d[w] |= v << sh;
+    if constexpr (sh > 4) d[w + 1] |= v >> (32u - sh);
+}
+template <int E>
+__device__ __forceinline__ void group_of_limbs(uint32_t (&d)[28], const uint32_t (&rp)[16], const uint32_t (&rb)[16]) {
+    if constexpr (E < 16) {
+        constexpr int JJ = E >> 1, M = E & 1;
+        put_field28<4 * JJ + 2 * M>(d, rp[E]);
+        put_field28<4 * JJ + 2 * M + 1>(d, rb[E]);
+        group_of_limbs<E + 1>(d, rp, rb);
+    }
+}
+__device__ __forceinline__ uint32_t residue_of_limb_word(uint32_t w, uint32_t m) {
+    const int32_t a = (int32_t)w - (int32_t)kLimbBias;
+    return a < 0 ? (uint32_t)(a + (int32_t)m) : (uint32_t)a;
+}
+__global__ __launch_bounds__(256) void db_limb_unplanes_kernel(const uint4* __restrict__ limbs, uint64_t* __restrict__ packed, uint32_t nic, uint32_t dim0, uint32_t nz) {
+    const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t nk2 = dim0 >> 6, nblk16 = nic >> 4;
+    const uint32_t kc2 = wave % nk2, icb = (wave / nk2) % nblk16, z = wave / (nk2 * nblk16);
+    if (z >= nz) return;
+    const uint32_t ic = icb * 16u + (lane & 15u), kblk = lane >> 4, groups = dim0 >> 3;
+    const uint4* src = limbs + ((size_t)(z * nblk16 + icb) * 2u * nk2 + kc2) * 7u * 64u + lane;
+    uint4* dst = reinterpret_cast<uint4*>(packed) + ((size_t)(z * (nic >> 6) + (ic >> 6)) * groups) * 7u * 64u + (ic & 63u);
+    const uint4 np4 = src[(size_t)6u * 64u], nb4 = src[((size_t)nk2 * 7u + 6u) * 64u];
+    const uint32_t np[4] = {np4.x, np4.y, np4.z, np4.w}, nb[4] = {nb4.x, nb4.y, nb4.z, nb4.w};
+#pragma unroll
+    for (uint32_t c = 0; c < 2; c++) {
+        uint32_t lp[3][4], lb[3][4];
+#pragma unroll
+        for (uint32_t i = 0; i < 3; i++) {
+            const uint4 vp = src[(size_t)(2u * i + c) * 64u], vb = src[((size_t)nk2 * 7u + 2u * i + c) * 64u];
+            lp[i][0] = vp.x, lp[i][1] = vp.y, lp[i][2] = vp.z, lp[i][3] = vp.w;
+            lb[i][0] = vb.x, lb[i][1] = vb.y, lb[i][2] = vb.z, lb[i][3] = vb.w;
+        }
+        uint32_t rp[16], rb[16];
+#pragma unroll
+        for (uint32_t e = 0; e < 16; e++) {
+            const uint32_t sh = 8u * (e & 3u);
+            uint32_t wp = 0, wb = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 3; i++) {
+                wp |= ((lp[i][e >> 2] >> sh) & 0xFFu) << (8u * i);
+                wb |= ((lb[i][e >> 2] >> sh) & 0xFFu) << (8u * i);
+            }
+            wp = (wp ^ kLimbBias) | (((np[e >> 2] >> (sh + 4u * c)) & 0xFu) << 24);
+            wb = (wb ^ kLimbBias) | (((nb[e >> 2] >> (sh + 4u * c)) & 0xFu) << 24);
+            rp[e] = residue_of_limb_word(wp, kP);
+            rb[e] = residue_of_limb_word(wb, kB);
+        }
+        uint32_t d[28] = {};
+        group_of_limbs<0>(d, rp, rb);
+        const uint32_t g = kc2 * 8u + c * 4u + kblk;
+#pragma unroll
+        for (uint32_t k = 0; k < 7; k++) dst[((size_t)g * 7u + k) * 64u] = make_uint4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]);
+    }
 }
 
 struct SweepLanes {
@@ -334,20 +398,28 @@ __global__ __launch_bounds__(512, 2) void sweep_mfma_kernel(const uint4* __restr
 }
 
 bool sweep_mfma_ok(uint32_t num_per, uint32_t jm_total) {
-    const uint32_t nic = 2 * num_per, dim0 = jm_total / 2;  // whole workgroups of 128 columns, whole pieces of 128 terms; K = 2 dim0 <= 2^12 (combine_limbs' 64-bit sums)
-    return nic >= 128 && db_packed(nic, dim0) && (dim0 & 63u) == 0 && dim0 <= 2048u;
-}
-void launch_db_limb_planes(const uint64_t* db_packed_img, uint64_t* db_limbs, uint32_t num_per, uint32_t jm_total, hipStream_t s) {
+    // whole workgroups of 128 columns, whole pieces of 128 terms; K = 2 dim0 <= 2^12 (combine_limbs' 64-bit sums); the kernel walks a work item's pieces
+    // with shifts and masks (ppi_log, nk2 - 1): the first dimension -- a shard [j0, j1) may be any range -- must be a power of two, other shards take the
+    // vector-ALU passes
     const uint32_t nic = 2 * num_per, dim0 = jm_total / 2;
-    const size_t waves = (size_t)kN * (nic >> 4) * (dim0 >> 6);
-    hipLaunchKernelGGL(db_limb_planes_kernel, dim3((uint32_t)((waves + 3) / 4)), dim3(256), 0, s, db_packed_img, reinterpret_cast<uint4*>(db_limbs), nic, dim0);
+    return nic >= 128 && db_packed(nic, dim0) && (dim0 & 63u) == 0 && (dim0 & (dim0 - 1u)) == 0 && dim0 <= 2048u;
 }
-void launch_sweep_mfma(const uint64_t* db_limbs, const uint32_t* const* qs, uint64_t* const* acc, uint32_t n, uint32_t num_per, uint32_t jm_total, uint32_t g_log,
-                       hipStream_t s) {
+void launch_db_limb_planes(const uint64_t* db_packed_img, uint64_t* db_limbs, uint32_t num_per, uint32_t jm_total, hipStream_t s, uint32_t nz) {
+    const uint32_t nic = 2 * num_per, dim0 = jm_total / 2;
+    const size_t waves = (size_t)nz * (nic >> 4) * (dim0 >> 6);
+    if (waves) hipLaunchKernelGGL(db_limb_planes_kernel, dim3((uint32_t)((waves + 3) / 4)), dim3(256), 0, s, db_packed_img, reinterpret_cast<uint4*>(db_limbs), nic, dim0, nz);
+}
+void launch_db_limb_unplanes(const uint64_t* db_limbs, uint64_t* db_packed_img, uint32_t num_per, uint32_t jm_total, hipStream_t s, uint32_t nz) {
+    const uint32_t nic = 2 * num_per, dim0 = jm_total / 2;
+    const size_t waves = (size_t)nz * (nic >> 4) * (dim0 >> 6);
+    if (waves) hipLaunchKernelGGL(db_limb_unplanes_kernel, dim3((uint32_t)((waves + 3) / 4)), dim3(256), 0, s, reinterpret_cast<const uint4*>(db_limbs), db_packed_img, nic, dim0, nz);
+}
+hipError_t launch_sweep_mfma(const uint64_t* db_limbs, const uint32_t* const* qs, uint64_t* const* acc, uint32_t n, uint32_t num_per, uint32_t jm_total, uint32_t g_log,
+                             hipStream_t s, uint32_t k_log) {
     const uint32_t nic = 2 * num_per, dim0 = jm_total / 2;
     uint32_t ls_log = 0;
     while ((1u << ls_log) < num_per) ls_log++;
-    ls_log -= g_log;
+    ls_log -= g_log + k_log;
     SweepLanes bt{};
     for (uint32_t b = 0; b < kMaxLanes; b++) {
         bt.qs[b] = qs[b < n ? b : 0];
@@ -363,10 +435,20 @@ void launch_sweep_mfma(const uint64_t* db_limbs, const uint32_t* const* qs, uint
     const size_t lds = lds_b + ((size_t)8u * nt * 64u * 8u << zs_log);
     const dim3 grid(n_wg), block(512);
     const uint4* dbl = reinterpret_cast<const uint4*>(db_limbs);
+    // more than 64 KiB of dynamic LDS has to be asked for per kernel AND per device: a process may drive servers on several GPUs, from several
+    // threads, so the opt-in is remembered per (instance, device) in an atomic bit mask (devices beyond 63 ask every time)
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
 #define SWEEP_MFMA(NTV)                                                                                                                            \
     do {                                                                                                                                           \
-        static bool big = false; /* more than 64 KiB of dynamic LDS has to be asked for once per kernel */                                       \
-        if (!big) big = hipFuncSetAttribute((const void*)sweep_mfma_kernel<NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; \
+        static std::atomic<uint64_t> big{0};                                                                                                       \
+        const uint64_t bit = dev < 64 ? 1ull << dev : 0ull;                                                                                        \
+        if (!(big.load(std::memory_order_relaxed) & bit)) {                                                                                        \
+            e = hipFuncSetAttribute((const void*)sweep_mfma_kernel<NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
+            if (e != hipSuccess) return e;                                                                                                         \
+            big.fetch_or(bit, std::memory_order_relaxed);                                                                                          \
+        }                                                                                                                                          \
         hipLaunchKernelGGL((sweep_mfma_kernel<NTV>), grid, block, lds, s, dbl, bt, n, nic, dim0, g_log, ls_log, n_work, zs_log);                  \
     } while (0)
     switch (nt) {
@@ -376,9 +458,10 @@ void launch_sweep_mfma(const uint64_t* db_limbs, const uint32_t* const* qs, uint
         case 4: SWEEP_MFMA(4); break;
         case 5: SWEEP_MFMA(5); break;
         case 6: SWEEP_MFMA(6); break;
-        default: abort();
+        default: return hipErrorInvalidValue;
     }
 #undef SWEEP_MFMA
+    return hipGetLastError();  // a launch that was refused (LDS, grid) is reported here, not at some later synchronisation
 }
 
 }  // namespace spiral

@@ -93,6 +93,31 @@ def all_gather_cts(gathered, ct, group=None):
     return gathered
 
 
+def instances_of_rank(rank: int, world: int, factor: int) -> list[int]:
+    """factor-sharded items (an item = `factor` database instances, select_params.py:297-298): rank r holds instances r, r + world, ...; the
+    instances are independent -- one query, expanded and converted on every rank, no reduce -- and their responses are gathered"""
+    return list(range(rank, factor, world))
+
+
+def all_gather_instance_responses(gathered, mine, group=None):
+    """collect every rank's block of instance responses in rank order: `mine` holds ceil(factor / world) responses of 6 x 2048 words (the ranks
+    with one instance fewer leave their last slot unused), `gathered` world such blocks; instance k = slot k // world of rank k % world.  The one
+    collective of the factor-sharded path, 96 KiB per instance"""
+    import torch.distributed as dist
+
+    _check("all_gather_instance_responses: mine", mine)
+    _check("all_gather_instance_responses: gathered", gathered, mine.numel() * dist.get_world_size(group))
+    dist.all_gather_into_tensor(gathered, mine, group=group)
+    return gathered
+
+
+def instance_response(gathered, k: int, world: int, slots: int, words: int = 6 * 2048):
+    """instance k's response inside the gathered blocks ([world][slots][words])"""
+    r, sl = k % world, k // world
+    off = (r * slots + sl) * words
+    return gathered[off:off + words]
+
+
 def fold_ranks(world: int, num_per: int) -> int:
     """ranks taking part in the distributed fold: all of them when they divide num_per, else 1 (root folds alone)"""
     return world if world >= 1 and (world & (world - 1)) == 0 and world <= num_per else 1

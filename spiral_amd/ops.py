@@ -17,6 +17,7 @@ __all__ = [
     "N", "P", "B", "Q", "make_params", "get_shape", "get_tables", "ntt_forward", "ntt_inverse", "to_ntt", "to_ntt_no_reduce", "from_ntt",
     "multiply", "add", "mul_by_const", "automorph", "invert", "gadget_invert", "getRescaled", "multiplyQueryByDatabase", "multiplyQueriesByDatabase", "split_and_crt",
     "foldOneFurtherDimension", "expandImproved", "scalToMat", "regevToGSW", "time_ntt", "time_ntt_digits", "response_wire_bytes", "response_from_wire",
+    "set_option", "get_option", "options",
 ]
 
 
@@ -27,6 +28,35 @@ def _p(a: np.ndarray):
 
 def _c(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def set_option(name: str, value: int) -> None:
+    """spiral_gpu_set_option: a process-wide schedule option (include/spiral_gpu.h lists them); servers take the values in force at creation"""
+    check(lib().spiral_gpu_set_option(name.encode(), int(value)))
+
+
+def get_option(name: str) -> int:
+    v = C.c_int64()
+    check(lib().spiral_gpu_get_option(name.encode(), C.byref(v)))
+    return v.value
+
+
+class options:
+    """with sa.options(fold_pair=0, fwd2=1): ...  -- sets the options and restores the previous values on exit"""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: get_option(k) for k in self.kw}
+        for k, v in self.kw.items():
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
 
 
 def make_params(nu1, nu2, t_gsw=8, t_conv=4, t_exp=8, t_exp_right=56, qprime_bits=20, p_db=256, direct_upload=0) -> Params:

@@ -11,6 +11,7 @@ from ._lib import U64P, Params, Shape, check, lib
 N = 2048
 
 BUF_EXPANDED, BUF_CTS, BUF_GSW, BUF_ACC, BUF_RAW, BUF_FINAL, BUF_RESPONSE = range(7)
+DB_PACKED, DB_LIMBS = 0, 1  # spiral_gpu_db_format
 STAGE_NAMES = ["expansion_us", "conversion_us", "first_dim_us", "folding_us", "response_us", "sweep_kernel_us", "total_us", "scaltomat_us"]
 
 
@@ -102,6 +103,23 @@ class Server:
 
     def fill_db_random(self, seed: int):
         check(lib().spiral_gpu_server_fill_db_random(self.h, seed))
+
+    def run_query_instances(self, instances, responses_ptr: int, finals_ptr: int = 0, pre: bool = True):
+        """this server's query against every database instance in `instances` (servers holding the images of one item's `factor` databases): expansion +
+        conversion once (pre), then sweep + folding + switch per instance; responses_ptr / finals_ptr: device memory, 6 x 2048 words per instance"""
+        arr = (C.c_void_p * len(instances))(*[s.h for s in instances])
+        check(lib().spiral_gpu_server_run_query_instances(self.h, arr, len(instances), 1 if pre else 0, C.c_void_p(responses_ptr), C.c_void_p(finals_ptr or None)))
+
+    def set_db_format(self, fmt: int):
+        """convert this server's database image in place: DB_PACKED (vector-ALU sweep) <-> DB_LIMBS (matrix-core sweep); see include/spiral_gpu.h"""
+        check(lib().spiral_gpu_server_set_db_format(self.h, fmt))
+
+    def db_format(self) -> int:
+        return lib().spiral_gpu_server_db_format(self.h)
+
+    def db_device_bytes(self) -> int:
+        """device bytes the holder of this server's image keeps for database images"""
+        return lib().spiral_gpu_server_db_device_bytes(self.h)
 
     def share_db(self, owner: "Server"):
         """sweep `owner`'s database image instead of an own copy (a second query lane on one database)"""

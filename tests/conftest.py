@@ -51,3 +51,20 @@ def oracle_mt(tmp_path_factory):
     mod.LIB_PATH = os.path.join(str(d), "liboracle_native.so")
     mod.n_threads = mod.set_threads(max(1, min(os.cpu_count() or 1, 32)))  # (scaling of this code peaks at 16-32 threads)
     return mod
+
+
+@pytest.fixture
+def opts():
+    """opts(fold_pair=0, ...): set process-wide library options (spiral_gpu_set_option) for this test, restored afterwards"""
+    import spiral_amd as sa
+
+    saved = {}
+
+    def set_(**kw):
+        for k, v in kw.items():
+            saved.setdefault(k, sa.get_option(k))
+            sa.set_option(k, v)
+
+    yield set_
+    for k, v in saved.items():
+        sa.set_option(k, v)

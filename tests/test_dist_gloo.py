@@ -302,3 +302,55 @@ def test_two_rank_sharded_expansion_equals_full_expansion():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got == {0: True, 1: True}
+
+
+def _worker_factor_shard(rank, world, port, q):
+    """factor-sharded items (bench.py --workload stream --gpus N) with the oracle as the kernels: an item = factor 3 database instances, rank r answers
+    the one query against instances r, r + world, ...; ONE all-gather of the responses; every rank can then decode the whole item"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+
+    from oracle import pyoracle as O
+    from spiral_amd import dist as sdist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    kw = dict(t_gsw=5, t_exp=2, qprime_bits=19, direct_upload=1)  # the SpiralStream form: no expansion
+    po = O.make_params(3, 2, **kw)
+    s = O.shape_of(po)
+    factor, idx = 3, 21
+    cl = O.Client(po, seed=8)  # the same client (keys, query) on both ranks
+    pp = cl.pub_params()
+    qy = cl.query(idx)
+    mine_k = sdist.instances_of_rank(rank, world, factor)
+    assert mine_k == ([0, 2] if rank == 0 else [1])
+    slots = (factor + world - 1) // world
+    mine = torch.zeros(slots * 6 * O.N, dtype=torch.int64)
+    for sl, k in enumerate(mine_k):
+        fin = O.answer(po, qy, *pp, O.gen_db(po, 100 + k))  # instance k = the database seeded 100 + k
+        mine[sl * 6 * O.N:(sl + 1) * 6 * O.N] = torch.from_numpy(O.stage_rescale(po, fin).view(np.int64).reshape(-1).copy())
+    gathered = torch.zeros(world * mine.numel(), dtype=torch.int64)
+    sdist.all_gather_instance_responses(gathered, mine)
+    ok = True
+    for k in range(factor):
+        resp = sdist.instance_response(gathered, k, world, slots).numpy().view(np.uint64).reshape(3, 2, O.N)
+        ok = ok and bool((cl.decode(resp) == O.db_item(po, 100 + k, idx)).all())
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_two_rank_factor_shard_gathers_every_instance():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_factor_shard, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == {0: True, 1: True}

@@ -300,12 +300,51 @@ def sampled_checks(sa, M, po, pg, seed, idx, cl, label, request, n_slots=6, n_it
     srv.close()
 
 
+def bench_inputs_hash(sa, M, workload, label, request, n_slots=4):
+    """bench.py's own synthetic inputs for `workload` (default_rng(1) residues, gen_db(1234)) at a size with no host-side reference database: the hash
+    bench.py prints (`answer_sha256`, also inside `config`) next to the oracle's.  The oracle computes expansion and conversion in full, the sweep on sampled
+    slots and on one complete output ciphertext from the device's own database words, and folding + response switch from the device's accumulators."""
+    import bench
+    from spiral_amd import server as SV
+
+    kw = {k: v for k, v in bench.WORKLOADS[workload].items() if k != "label"}
+    po, pg = M.make_params(**kw), sa.make_params(**kw)
+    s = M.shape_of(po)
+    pub, q = bench.synth_inputs(np, sa, pg, sa.get_shape(pg))
+    srv = sa.Server(pg)
+    srv.gen_db(bench.DB_SEED)
+    srv.set_pub_params(*pub)
+    srv.set_query(q)
+    srv.use_graphs(True)
+    for rep in range(2):
+        srv.run_query()
+    srv.sync()
+    acc, fin, resp = srv.read(SV.BUF_ACC), srv.read(SV.BUF_FINAL), srv.read(SV.BUF_RESPONSE)
+    cts, gsw = M.stage_convert(po, M.stage_expand(po, q, pub[0], pub[1]), pub[2], pub[3])
+    re = M.reorient_ciphertexts(cts)
+    rng = np.random.default_rng(5)
+    zs = sorted({0, N - 1} | {int(x) for x in rng.integers(0, N, size=n_slots)})
+    slabs = np.concatenate([srv.read_db_slots(z, 1) for z in zs]).reshape(len(zs), -1)
+    assert_eq(acc[..., zs], M.multiply_query_by_database_slots(re[zs], slabs, s.dim0, s.num_per), f"{label}: bench.py's inputs: accumulators on slots {zs}")
+    ii = int(rng.integers(0, s.num_per))
+    assert_eq(acc[ii:ii + 1], M.multiply_query_by_database(re, srv.read_db_columns(ii, 1), s.dim0, 1), f"{label}: bench.py's inputs: all slots of output ciphertext {ii}")
+    want_fin = M.stage_fold(po, M.from_ntt(acc), gsw)
+    want_resp = M.stage_rescale(po, want_fin)
+    assert_eq(fin, want_fin, f"{label}: bench.py's inputs: folded ciphertext of the replayed whole-query graph")
+    assert_eq(resp, want_resp, f"{label}: bench.py's inputs: response")
+    record(request, f"bench.py {workload} inputs (default_rng(1) residues, gen_db(1234)): oracle answer_sha256 {bench.answer_hash(np, want_fin, want_resp)} == device "
+                    f"{bench.answer_hash(np, fin, resp)} (oracle: expansion, conversion, fold, switch in full; sweep on slots {zs} + ciphertext {ii} complete)")
+    srv.close()
+
+
 def test_config3_geometry_sampled_slots(sa, oracle_mt, request):
     """configs[2]'s geometry on one MI355X: 2^24 x 256 B, nu1=9, nu2=10, t_GSW=10, q'=2^22, 32 GiB"""
     M = oracle_mt
     kw = dict(t_gsw=10, t_conv=4, t_exp=8, t_exp_right=56, qprime_bits=22, p_db=256)
     po, pg = M.make_params(9, 10, **kw), sa.make_params(9, 10, **kw)
     sampled_checks(sa, M, po, pg, 99, 424242 % (1 << 19), M.Client(po, seed=6), "config 3 geometry (32 GiB)", request, batches=(2, 4))
+    # BENCH_rNN.json's also.config3.answer_sha256 (= config.also_config3_answer_sha256) must equal this line
+    bench_inputs_hash(sa, M, "config3", "config 3 geometry (32 GiB)", request)
 
 
 def test_configs3_spiralstream_2_20_x_100KB(sa, oracle_mt, request):

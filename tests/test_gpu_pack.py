@@ -73,10 +73,11 @@ def test_pack_seam_largest_sums(sa, oracle):
         (3, 2, 12, dict(t_gsw=3, t_conv=56, t_exp=56, qprime_bits=31, p_db=524288, direct_upload=1)),  # n = 12: the "movie" set's shape of parameters
     ],
 )
-@pytest.mark.parametrize("fold_pair", ["1", "0"])  # 1: the pair form of foldCiphertextsDim1 (LD_PDIFF); 0: the reference's two products
-def test_pack_server_matches_oracle(sa, oracle, nu1, nu2, out_n, kw, fold_pair, monkeypatch):
+@pytest.mark.parametrize("fold_pair", [1, 0])  # 1: the pair form of foldCiphertextsDim1 (LD_PDIFF); 0: the reference's two products
+def test_pack_server_matches_oracle(sa, oracle, nu1, nu2, out_n, kw, fold_pair, request):
     O = oracle
-    monkeypatch.setenv("SPIRAL_FOLD_PAIR", fold_pair)
+    request.addfinalizer(lambda old=sa.get_option("fold_pair"): sa.set_option("fold_pair", old))
+    sa.set_option("fold_pair", fold_pair)
     po, pg = O.make_params(nu1, nu2, **kw), sa.make_params(nu1, nu2, **kw)
     s = O.pack_shape_of(po, out_n)
     g = sa.get_pack_shape(pg, out_n)

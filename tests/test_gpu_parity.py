@@ -316,7 +316,7 @@ def test_answer_and_device_db(sa, oracle, nu1, nu2, kw):
     srv.close()
 
 
-def test_load_db_in_several_staging_passes(sa, oracle, monkeypatch):
+def test_load_db_in_several_staging_passes(sa, oracle, opts):
     """load_db stages the reference-layout database a few z slabs at a time; every pass must land its slabs at the
     right (thread-transposed) positions of the packed device layout: answer == oracle, and == the device-generated DB"""
     O = oracle
@@ -329,7 +329,7 @@ def test_load_db_in_several_staging_passes(sa, oracle, monkeypatch):
     db = O.gen_db(po, 99)
     q = cl.query(333)
     want = O.answer(po, q, wl, wr, w, v, db)
-    monkeypatch.setenv("SPIRAL_DB_STAGE_BYTES", str(48 * 16 * 32 * 4 * 8))  # 48 slabs per pass: 43 passes, the last one short
+    opts(db_stage_bytes=48 * 16 * 32 * 4 * 8)  # 48 slabs per pass: 43 passes, the last one short
     srv = sa.Server(pg)
     srv.load_db(db)
     srv.set_pub_params(wl, wr, w, v)
@@ -345,22 +345,21 @@ def test_load_db_in_several_staging_passes(sa, oracle, monkeypatch):
 
 @pytest.mark.parametrize("env,t_gsw", [
     ({}, 8),                                    # default: pair form, unchained (lift launch + LD_SDIFF launch + product with addend)
-    ({"SPIRAL_FOLD_PAIR": "0"}, 8),             # the reference's two-product form Q_neg G^-1(L) + Q G^-1(H), lift chained (fold_chain_kernel)
-    ({"SPIRAL_FOLD_PAIR": "0", "SPIRAL_FOLD_BLOCKS": "0"}, 8),        # one block per polynomial (all digits)
-    ({"SPIRAL_FOLD_PAIR": "0", "SPIRAL_FOLD_BLOCKS": "1000000"}, 8),  # one block per (polynomial, digit)
-    ({"SPIRAL_FOLD_PAIR": "0", "SPIRAL_FOLD_BLOCKS": "300"}, 8),      # mixed chunk sizes
-    ({"SPIRAL_FOLD_CHAIN": "0"}, 8),            # two-product form as separate lift + LD_SDIGIT launches
-    ({}, 14),                                   # NO environment: ell = 14 has (ell - 1) * bits = 65 >= 64, fold_pair_exact(14) is false, so the server
+    (dict(fold_pair=0), 8),                     # the reference's two-product form Q_neg G^-1(L) + Q G^-1(H), lift chained (fold_chain_kernel)
+    (dict(fold_pair=0, fold_blocks=0), 8),        # one block per polynomial (all digits)
+    (dict(fold_pair=0, fold_blocks=1000000), 8),  # one block per (polynomial, digit)
+    (dict(fold_pair=0, fold_blocks=300), 8),      # mixed chunk sizes
+    (dict(fold_chain=0), 8),                    # two-product form as separate lift + LD_SDIGIT launches
+    ({}, 14),                                   # NO option: ell = 14 has (ell - 1) * bits = 65 >= 64, fold_pair_exact(14) is false, so the server
     ({}, 17),                                   # itself falls back to the two-product form (kernels.h fold_pair_exact); likewise ell = 17
-    ({"SPIRAL_FWD2": "1"}, 8),                  # every digit launch through the two-digits-per-workgroup kernel (default only from 8192 transforms)
-    ({"SPIRAL_FWD2": "0"}, 8),
+    (dict(fwd2=1), 8),                          # every digit launch through the two-digits-per-workgroup kernel (default only from 8192 transforms)
+    (dict(fwd2=0), 8),
 ])
-def test_fold_chain_schedules(sa, oracle, env, t_gsw, monkeypatch):
-    """the fold's forms (read from the environment when the server is created, or chosen by the server from the gadget dimension) and the two
-    digit-transform kernels all give the oracle's answer"""
+def test_fold_chain_schedules(sa, oracle, env, t_gsw, opts):
+    """the fold's forms (library options taken when the server is created -- spiral_gpu_set_option -- or chosen by the server from the gadget
+    dimension) and the two digit-transform kernels all give the oracle's answer"""
     O = oracle
-    for k, val in env.items():
-        monkeypatch.setenv(k, val)
+    opts(**env)
     kw = dict(t_gsw=t_gsw)  # (t_gsw = 4 is bit-exact too but too noisy to decode at nu2 = 6)
     po, pg = O.make_params(3, 6, **kw), sa.make_params(3, 6, **kw)
     cl = O.Client(po, seed=17)
@@ -774,8 +773,189 @@ def test_matrix_core_sweep_groups_accumulators_by_fold_rank(sa, oracle, G):
         ln.close()
 
 
-def test_batch_without_the_matrix_core_image_and_after_a_reload(sa, oracle, monkeypatch):
-    """(6, 6) is a geometry the matrix-core sweep covers.  SPIRAL_SWEEP_MFMA=0 (read when a handle is created): the same batch sweeps in passes of two on
+def test_first_dim_batch_on_a_shard_that_is_not_a_power_of_two(sa, oracle):
+    """A server may hold any first-dimension range [j0, j1).  192 of 256 indices is a multiple of 64 but not a power of two: the matrix-core kernel walks
+    a work item's pieces with shifts and masks and must NOT take such a shard (sweep_mfma_ok) -- the batch falls back to vector-ALU passes and every
+    lane's accumulators are the oracle's partial sums over j in [0, 192).  The complementary shard [192, 256) (64 indices: a power of two) does take it."""
+    O = oracle
+    from spiral_amd import server as SV
+
+    nu1, nu2, n = 8, 6, 3
+    pg = sa.make_params(nu1, nu2, t_gsw=8)
+    s = sa.get_shape(pg)
+    rng = np.random.default_rng(4242)
+    db = O.fill_db_random(77, s.dim0 * s.num_per * 4 * N).reshape(N, s.num_per, 2, s.dim0, 2)
+    mk = lambda shape: np.stack([rng.integers(0, m, size=shape + (N,), dtype=np.uint64) for m in (sa.P, sa.B)], axis=-2)
+    pps = [(mk((s.n_left, 2, pg.t_exp)), mk((s.n_right, 2, pg.t_exp_right)), mk((3, 2 * pg.t_conv)), mk((3, 2 * pg.t_conv))) for _ in range(n)]
+    qs = [mk((s.n_query_cts, 2)) for _ in range(n)]
+    po = O.make_params(nu1, nu2, t_gsw=8)
+    for j0, j1, fmt in ((0, 192, SV.DB_PACKED), (192, 256, SV.DB_LIMBS)):
+        owner = sa.Server(pg, j_begin=j0, j_end=j1)
+        owner.load_db(db)
+        lanes = [owner] + [sa.Server(pg, share_db_of=owner) for _ in range(n - 1)]
+        for ln, pp, q in zip(lanes, pps, qs):
+            ln.keep_cts(True)
+            ln.set_pub_params(*pp)
+            ln.set_query(q)
+            ln.run_pre()
+        sa.first_dim_batch(lanes)
+        assert owner.db_format() == fmt, f"shard [{j0}, {j1})"
+        sub = np.ascontiguousarray(db[:, :, :, j0:j1, :])
+        for b, ln in enumerate(lanes):
+            ln.sync()
+            cts = ln.read(SV.BUF_CTS)  # this shard's first-dimension ciphertexts, as the sweep consumed them
+            want = O.multiply_query_by_database(O.reorient_ciphertexts(cts), sub, j1 - j0, s.num_per)
+            assert_eq(ln.read(SV.BUF_ACC), want, f"shard [{j0}, {j1}), lane {b}")
+        for ln in reversed(lanes):
+            ln.close()
+
+
+def test_db_format_round_trip(sa, oracle, opts):
+    """The one database image in its two forms (include/spiral_gpu.h spiral_gpu_server_set_db_format).  packed -> limb planes -> packed in place, through a
+    staging buffer smaller than the image; in either form: read_db_slots / read_db_item give the oracle's database, a single query gives the oracle's answer
+    (vector-ALU kernel on the packed form, the one-query matrix-core kernel on the limb planes), captured graphs follow the form; a partial load_db_items and
+    set_sweep_stages take the image back to the packed form by themselves; device bytes held = ONE image throughout."""
+    O = oracle
+    from spiral_amd import server as SV
+
+    kw = dict(t_gsw=8)
+    po, pg = O.make_params(6, 6, **kw), sa.make_params(6, 6, **kw)
+    s = O.shape_of(po)
+    total = s.dim0 * s.num_per
+    db = O.gen_db(po, 21)
+    db5 = db.reshape(N, s.num_per, 2, s.dim0, 2)
+    cl = O.Client(po, seed=9)
+    pp = cl.pub_params()
+    srv = sa.Server(pg)
+    srv.gen_db(21)
+    srv.set_pub_params(*pp)
+    srv.use_graphs(True)
+    image = srv.db_device_bytes()
+    assert image == N * s.dim0 * s.num_per * 4 * 7, "3.5 bytes per residue"
+    lane = sa.Server(pg, share_db_of=srv)
+    lane.set_pub_params(*pp)
+    lane.use_graphs(True)
+    with pytest.raises(RuntimeError, match="owner"):
+        lane.set_db_format(SV.DB_LIMBS)
+
+    def check(tag, idx):
+        q = cl.query(idx)
+        want = O.answer(po, q, *pp, db)
+        for who, sv in (("owner", srv), ("lane", lane)):
+            sv.set_query(q)
+            for rnd in range(2):  # capture (or re-capture after a change of form), replay
+                sv.run_query()
+                sv.sync()
+                assert_eq(sv.read(SV.BUF_FINAL), want, f"{tag}: {who}, run {rnd}")
+        assert_eq(cl.decode(srv.read(SV.BUF_RESPONSE)), O.db_item(po, 21, idx), f"{tag}: decoded item")
+        assert_eq(srv.read_db_slots(5, 3), db5[5:8], f"{tag}: read_db_slots")
+        assert_eq(lane.read_db_item(idx), O.encode_item(po, O.db_item(po, 21, idx)), f"{tag}: read_db_item")
+        assert srv.db_device_bytes() == image == lane.db_device_bytes(), f"{tag}: one image"
+
+    check("packed", 1234)
+    for rnd in range(2):
+        srv.set_db_format(SV.DB_LIMBS)
+        assert lane.db_format() == SV.DB_LIMBS
+        check(f"limb planes {rnd}", 77 + rnd)
+        srv.set_db_format(SV.DB_PACKED)
+        check(f"packed again {rnd}", total - 1 - rnd)
+    # a batch converts by itself; a staged sweep and a partial reload convert back
+    srv.set_query(cl.query(5))
+    lane.set_query(cl.query(6))
+    sa.run_query_batch([srv, lane])
+    assert srv.db_format() == SV.DB_LIMBS
+    check("after a batch", 99)
+    srv.set_fold_ranks(2)
+    srv.set_sweep_stages(2)
+    assert srv.db_format() == SV.DB_PACKED, "stage-by-stage launches read the packed form"
+    srv.set_fold_ranks(1)
+    check("after set_sweep_stages", 100)
+    srv.set_db_format(SV.DB_LIMBS)
+    items = np.stack([O.db_item(po, 22, i) for i in range(total // 2, total // 2 + s.num_per)])  # one first-dimension index of ANOTHER database
+    srv.load_db_items(O.pack_items(items, 8), 8, first_item=total // 2)
+    assert srv.db_format() == SV.DB_PACKED, "a partial load scatters packed words"
+    j = (total // 2) // s.num_per
+    got = srv.read_db_slots(0, N)
+    want_db = db5.copy()
+    for i in range(s.num_per):
+        enc = O.encode_item(po, items[i])  # [m][c][limb][z]
+        want_db[:, i, :, j, :] = (enc[:, :, 0, :] | (enc[:, :, 1, :] << np.uint64(32))).transpose(2, 1, 0)
+    assert_eq(got, want_db, "the image after a partial load into a converted image")
+    lane.close()
+    srv.close()
+
+
+@pytest.mark.parametrize("nu1,nu2,kw,graphs", [
+    (3, 2, dict(t_gsw=5, t_exp=2, qprime_bits=19, direct_upload=1), True),   # the SpiralStream form (configs[3]): no expansion
+    (4, 3, dict(t_gsw=8), True),                                             # query compression: expansion + conversion run ONCE per rank
+    (6, 6, dict(t_gsw=8), False),                                            # a geometry with both image forms: instance 1's image in limb planes, the others packed
+])
+def test_run_query_instances_factor_3_over_two_ranks(sa, oracle, nu1, nu2, kw, graphs):
+    """configs[3] whole: an item larger than one plaintext is factor = ceil(item / plaintext) database instances (select_params.py:297-298, 409-418).  Here
+    factor 3 over 2 emulated ranks on one device: rank r holds instances r, r + 2 (own images) and one query server; every rank converts the ONE query
+    once and answers it against its instances (spiral_gpu_server_run_query_instances); the responses, gathered as spiral_amd/dist.py lays them out, decode
+    through the client to the three plaintexts of the item.  Folded ciphertexts and responses against the oracle's answer per instance."""
+    import torch
+
+    O = oracle
+    from spiral_amd import dist as sdist
+    from spiral_amd import server as SV
+
+    po, pg = O.make_params(nu1, nu2, **kw), sa.make_params(nu1, nu2, **kw)
+    s = O.shape_of(po)
+    factor, world = 3, 2
+    slots = (factor + world - 1) // world
+    cl = O.Client(po, seed=12)
+    pp = cl.pub_params()
+    words = 6 * N
+    blocks = []
+    idxs = [5, (s.dim0 * s.num_per) - 1]
+    ranks = []
+    for r in range(world):
+        inst = []
+        for k in sdist.instances_of_rank(r, world, factor):
+            sv = sa.Server(pg)
+            sv.gen_db(100 + k)
+            if k == 1 and (nu1, nu2) == (6, 6):
+                sv.set_db_format(SV.DB_LIMBS)
+            inst.append(sv)
+        qsrv = sa.Server(pg, share_db_of=inst[0])  # the query's server: a lane of this rank's first instance (no image of its own)
+        qsrv.set_pub_params(*pp)
+        qsrv.use_graphs(graphs)
+        ranks.append((qsrv, inst, torch.zeros(slots * words, dtype=torch.int64, device="cuda"), torch.zeros(slots * words, dtype=torch.int64, device="cuda")))
+    for rnd, idx in enumerate(idxs * 2):  # second pass: graph replays with new queries
+        q = cl.query(idx)
+        for qsrv, inst, resp, fins in ranks:
+            qsrv.set_query(q)
+            if rnd % 2 == 0:
+                qsrv.run_query_instances(inst, resp.data_ptr(), fins.data_ptr(), pre=True)
+            else:  # conversion as its own step, then the instances
+                qsrv.run_pre()
+                qsrv.run_query_instances(inst, resp.data_ptr(), fins.data_ptr(), pre=False)
+            qsrv.sync()
+        gathered = torch.cat([r[2] for r in ranks])  # what all_gather_instance_responses produces: [rank][slot][6 x 2048]
+        gathered_f = torch.cat([r[3] for r in ranks])
+        for k in range(factor):
+            want = O.answer(po, q, *pp, O.gen_db(po, 100 + k))
+            fin = sdist.instance_response(gathered_f, k, world, slots).cpu().numpy().view(np.uint64).reshape(3, 2, N)
+            resp = sdist.instance_response(gathered, k, world, slots).cpu().numpy().view(np.uint64).reshape(3, 2, N)
+            assert_eq(fin, want, f"round {rnd}, instance {k}: folded ciphertext")
+            assert_eq(resp, O.stage_rescale(po, want), f"round {rnd}, instance {k}: response")
+            assert_eq(cl.decode(resp), O.db_item(po, 100 + k, idx), f"round {rnd}, instance {k}: plaintext {k} of item {idx}")
+    # an instance of another geometry or without a database is refused before anything is launched
+    other = sa.Server(sa.make_params(nu1, nu2 + 1, **kw))
+    other.gen_db(1)
+    with pytest.raises(RuntimeError, match="differs"):
+        ranks[0][0].run_query_instances([ranks[0][1][0], other], ranks[0][2].data_ptr())
+    other.close()
+    for qsrv, inst, _, _ in ranks:
+        qsrv.close()
+        for sv in inst:
+            sv.close()
+
+
+def test_batch_without_the_matrix_core_image_and_after_a_reload(sa, oracle, opts):
+    """(6, 6) is a geometry the matrix-core sweep covers.  Option sweep_mfma_min = 0 (taken when a handle is created): the same batch sweeps in passes of two on
     the vector ALU (2 + 2 + 1 for five lanes).  With the image: reloading the database drops it -- the next batch rebuilds it from the new contents."""
     O = oracle
     from spiral_amd import server as SV
@@ -803,25 +983,31 @@ def test_batch_without_the_matrix_core_image_and_after_a_reload(sa, oracle, monk
         return lanes
 
     want = {seed: answers(seed) for seed in (11, 12)}
-    monkeypatch.setenv("SPIRAL_SWEEP_MFMA", "0")
+    opts(sweep_mfma_min=0)
     lanes = lanes_on(11)
     sa.run_query_batch(lanes)
     for b, srv in enumerate(lanes):
         srv.sync()
         assert_eq(srv.read(SV.BUF_FINAL), want[11][b], f"vector-ALU passes, lane {b}")
+    assert lanes[0].db_format() == SV.DB_PACKED, "no matrix-core sweep, no conversion"
     for srv in reversed(lanes):
         srv.close()
-    monkeypatch.delenv("SPIRAL_SWEEP_MFMA")
-    lanes = lanes_on(11)
-    for seed in (11, 12, 11):  # the image follows the database: built, rebuilt after each reload
-        lanes[0].gen_db(seed)
-        for rnd in range(2):  # capture, replay
-            sa.run_query_batch(lanes)
-            for b, srv in enumerate(lanes):
-                srv.sync()
-                assert_eq(srv.read(SV.BUF_FINAL), want[seed][b], f"database {seed}, run {rnd}, lane {b}")
-    for srv in reversed(lanes):
-        srv.close()
+    for one_image in (1, 0):  # the image converted in place (default) / a second image beside the packed one
+        opts(sweep_mfma_min=2, one_image=one_image)
+        lanes = lanes_on(11)
+        image = lanes[0].db_device_bytes()
+        for seed in (11, 12, 11):  # the limb planes follow the database: built, rebuilt after each reload
+            lanes[0].gen_db(seed)
+            assert lanes[-1].db_format() == SV.DB_PACKED, "a loader leaves the packed form"
+            for rnd in range(2):  # capture, replay
+                sa.run_query_batch(lanes)
+                for b, srv in enumerate(lanes):
+                    srv.sync()
+                    assert_eq(srv.read(SV.BUF_FINAL), want[seed][b], f"one_image {one_image}, database {seed}, run {rnd}, lane {b}")
+            assert lanes[-1].db_format() == (SV.DB_LIMBS if one_image else SV.DB_PACKED)
+            assert lanes[-1].db_device_bytes() == (image if one_image else 2 * image), "device bytes held for database images"
+        for srv in reversed(lanes):
+            srv.close()
 
 
 @pytest.mark.parametrize("nu1,nu2,n,kw,graphs", [
@@ -1078,7 +1264,7 @@ def test_full_size_stream_direct_upload(sa, oracle):
 
 
 @pytest.mark.parametrize("nu1,nu2,p_db,bits", [(3, 5, 256, 8), (4, 2, 32768, 15), (3, 3, 512, 9), (2, 1, 256, 64), (4, 4, 1 << 20, 20)])
-def test_raw_ingest_matches_load_db(sa, oracle, nu1, nu2, p_db, bits, monkeypatch):
+def test_raw_ingest_matches_load_db(sa, oracle, nu1, nu2, p_db, bits, opts):
     """plaintext coefficients in (bit-packed, the item size of select_params.py:297), device database out --
     the centred lift, the transforms and the layout of load_db (src/spiral.cpp:1083-1171) on the device.  Must give the
     database the reference's load_db builds: compared through read_db_slots / read_db_item and through the accumulators.
@@ -1098,7 +1284,7 @@ def test_raw_ingest_matches_load_db(sa, oracle, nu1, nu2, p_db, bits, monkeypatc
         db[:, i % s.num_per, :, i // s.num_per, :] = (enc[:, :, 0, :] | (enc[:, :, 1, :] << np.uint64(32))).transpose(2, 1, 0)
     items = O.pack_items(pts, bits)
     assert items.nbytes == total * 4 * N * bits // 8
-    monkeypatch.setenv("SPIRAL_DB_STAGE_BYTES", str(5 * 4 * N * bits // 8))  # 5 items per staging pass
+    opts(db_stage_bytes=5 * 4 * N * bits // 8)  # 5 items per staging pass
     srv = sa.Server(pg)
     srv.load_db_items(items, bits)
     assert_eq(srv.read_db_slots(0, N), db, "ingested database == load_db's")

@@ -53,8 +53,8 @@ timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ
 python tools/pmc_summary.py $O/pmc_b4/*/*_counter_collection.csv > $O/${R}_sq_counters_batch4.json
 rm -rf $O/pmc_b4
 # the fold's forms that remain, alternating on this box (group times of hipGraph replays, tools/stage_ab.py)
-python tools/stage_ab.py "" "SPIRAL_FOLD_PAIR=0" "SPIRAL_FOLD_CHAIN=0" "" "SPIRAL_FOLD_PAIR=0" > $O/${R}_fold_forms_ab.txt 2>&1
-( python tools/digits_time.py; SPIRAL_FWD2=1 python tools/digits_time.py; SPIRAL_FWD2=0 python tools/digits_time.py ) > $O/${R}_digits_time_fwd2.txt 2>&1
+python tools/stage_ab.py "" "fold_pair=0" "fold_chain=0" "" "fold_pair=0" > $O/${R}_fold_forms_ab.txt 2>&1
+( python tools/digits_time.py; python tools/digits_time.py fwd2=1; python tools/digits_time.py fwd2=0 ) > $O/${R}_digits_time_fwd2.txt 2>&1
 bash tools/run_handoff.sh > $O/${R}_handoff_probe_raw.txt 2>&1
 timeout 120 tools/grid_shape_probe > $O/${R}_grid_shape_probe.txt 2>&1
 python tools/cpu_oracle_scaling.py 1 8 16 32 > $O/${R}_cpu_oracle_scaling.txt 2>&1

@@ -1,4 +1,4 @@
-"""A/B of the launch groups under environment switches read at server creation: tools/stage_ab.py "K=V,K2=V2" "K=V" ...
+"""A/B of the launch groups under library options taken at server creation (spiral_gpu_set_option): tools/stage_ab.py "fold_pair=0,fold_blocks=300" "fold_chain=0" ...
 (an empty string = defaults).  Prints wall us per replay of run_pre / first_dim / run_post / run_query (hipGraph replays back to
 back, 40 each after warm-up) at config 2 (or --nu1/--nu2).  SPIRAL_LIB=<path> selects another build."""
 import os, sys, time
@@ -12,9 +12,10 @@ nu1, nu2 = int(opts.get("nu1", 8)), int(opts.get("nu2", 7))
 reps = int(opts.get("reps", 40))
 kw = {k: int(opts[k]) for k in ("t_gsw", "t_conv", "t_exp", "t_exp_right") if k in opts}
 for cfg in args or [""]:
-    env = dict(kv.split("=") for kv in cfg.split(",") if kv)
+    env = {k.replace("SPIRAL_", "").lower(): int(v) for k, v in (kv.split("=") for kv in cfg.split(",") if kv)}
+    old = {k: sa.get_option(k) for k in env}
     for k, v in env.items():
-        os.environ[k] = v
+        sa.set_option(k, v)
     pg = sa.make_params(nu1, nu2, **kw)
     s = sa.get_shape(pg)
     srv = sa.Server(pg)
@@ -41,5 +42,5 @@ for cfg in args or [""]:
         out[name] = round(best, 1)
     print(f"{os.environ.get('SPIRAL_LIB', 'product'):28s} {cfg or 'defaults':44s} {out}", flush=True)
     srv.close()
-    for k in env:
-        del os.environ[k]
+    for k, v in old.items():
+        sa.set_option(k, v)
