@@ -382,13 +382,144 @@ def bench_pack(args):
         print(json.dumps(out), flush=True)
 
 
+STREAM_ITEM_BYTES = 100_000  # BASELINE.json configs[3]: 2^20 x 100 KB
+
+
+def bench_stream(args, ctx, prog):
+    """--workload stream: BASELINE.json configs[3] WHOLE.  A 100 KB item is factor = ceil(100000 / 15360) = 7 plaintexts of the "Streaming 20/spiralstream" set
+    (n^2 * 2048 * log2(p) / 8 = 15 360 bytes each, select_params.py:297-298), i.e. SEVEN instances of the 2^20-item database, 64 GiB each in the reference's layout
+    (56 GiB on the device): 448 GiB.  The client sends one query; the server converts it once and answers it against every instance -- first dimension, folding
+    and response switch per instance, seven responses (the reference times one instance and multiplies fdim_us, fold_us and the response size by the factor,
+    select_params.py:409-418).  The instances are independent: rank r holds instances r, r + N, ... (spiral_amd/dist.py instances_of_rank), every rank runs
+    the conversion, ONE all-gather of the responses, no reduce.  A step = the whole item query on this rank's instances (spiral_gpu_server_run_query_instances,
+    one hipGraph); value = wall ms per item query, max over ranks.  One GPU holds four instances (4 x 56 GiB + query state of 288 GiB): a rank that is assigned more
+    instances than fit re-sweeps its resident images for the rest -- the timing of the sweep does not depend on the data -- and says so (instances_resident)."""
+    import hashlib
+
+    import numpy as np
+
+    import spiral_amd as sa
+    from spiral_amd import dist as sdist
+    from spiral_amd import server as SV
+
+    torch, dist = ctx.torch, ctx.dist
+    world, rank, dev = ctx.world, ctx.rank, ctx.dev
+    params_kw = dict(WORKLOADS["stream"])
+    label = params_kw.pop("label")
+    if args.nu1 is not None: params_kw["nu1"] = args.nu1  # (self-tests: a geometry whose seven instances fit one GPU)
+    if args.nu2 is not None: params_kw["nu2"] = args.nu2
+    if (args.nu1, args.nu2) != (None, None): label += f" with nu1={params_kw['nu1']}, nu2={params_kw['nu2']}"
+    pg = sa.make_params(**params_kw)
+    shp = sa.get_shape(pg)
+    plain_bytes = 4 * sa.N * 15 // 8  # n0 * n2 * 2048 coefficients of log2(p) = 15 bits
+    factor = -(-STREAM_ITEM_BYTES // plain_bytes)
+    mine = sdist.instances_of_rank(rank, world, factor)
+    slots = -(-factor // world)
+    prog.arm("stream/set-up", 6.0)
+    image_bytes = sa.N * shp.dim0 * shp.num_per * 4 * 7  # 3.5 bytes per residue
+    free, _total = torch.cuda.mem_get_info(dev)
+    if args.shared_device: free //= world  # (self-test: the ranks share one device)
+    fit = max(1, int((free - (8 << 30)) // (image_bytes + (4 << 30))))  # an image + a server's query state (~3 GiB at these parameters), 8 GiB of headroom
+    stream = torch.cuda.Stream(device=dev)
+    inst = []
+    for k in mine[:fit]:
+        sv = sa.Server(pg, ctx.local_rank)
+        sv.set_stream(stream.cuda_stream)
+        sv.gen_db(DB_SEED + k)  # instance k = its own database
+        inst.append(sv)
+    resident = len(inst)
+    swept = [inst[i % resident] for i in range(len(mine))] if mine else []  # (instances beyond the resident ones re-sweep resident images)
+    qsrv = inst[0] if inst else None
+    steps, warmup = args.steps, args.warmup
+    resp = torch.zeros(slots * 6 * sa.N, dtype=torch.int64, device=dev)
+    gathered = torch.zeros(world * resp.numel(), dtype=torch.int64, device=dev) if ctx.use_dist else resp
+    if qsrv is not None:
+        pub, query = synth_inputs(np, sa, pg, shp)
+        qsrv.set_pub_params(*pub)
+        qsrv.set_query(query)
+        qsrv.use_graphs(not args.no_graphs)
+
+    def step():
+        if qsrv is not None:
+            qsrv.run_query_instances(swept, resp.data_ptr(), pre=True)
+        if ctx.use_dist:
+            sdist.all_gather_instance_responses(gathered, resp)
+
+    with torch.cuda.stream(stream):
+        prog.arm("stream/timed")
+        step()  # graph capture, untimed
+        for _ in range(warmup):
+            step()
+        ctx.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        ctx.fence()
+        ms = ctx.max_over_ranks(time.perf_counter() - t0) * 1e3 / steps
+        prog.arm("stream/stage split", 3.0)
+        out_h = None
+        if rank == 0:
+            h = hashlib.sha256()
+            for k in range(factor):
+                h.update(sdist.instance_response(gathered, k, world, slots).cpu().numpy().astype("<i8").tobytes())
+            out_h = h.hexdigest()
+        # stage split on rank 0's first instance, outside the timed region: conversion alone, one instance's sweep + fold + switch, the sweep kernel alone
+        pre_us = inst_us = sweep_ms = None
+        if rank == 0 and qsrv is not None:
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            qsrv.run_pre(); qsrv.run_query_instances(swept[:1], resp.data_ptr(), pre=False)  # captures
+            torch.cuda.synchronize()
+            n = 5
+            e[0].record(stream)
+            for _ in range(n): qsrv.run_pre()
+            e[1].record(stream)
+            for _ in range(n): qsrv.run_query_instances(swept[:1], resp.data_ptr(), pre=False)
+            e[2].record(stream)
+            torch.cuda.synchronize()
+            pre_us, inst_us = e[0].elapsed_time(e[1]) * 1e3 / n, e[1].elapsed_time(e[2]) * 1e3 / n
+            sweep_ms = qsrv.time_sweep(5)
+    line = None
+    if rank == 0:
+        bytes_sweep, dev_bytes = qsrv.sweep_bytes(), qsrv.sweep_device_bytes()
+        achieved = bytes_sweep / (sweep_ms * 1e-3) / 1e9
+        wire = int(sa.response_wire_bytes(pg))
+        line = {
+            "metric": "server ms/query + DB GB/s vs HBM roofline (stream: configs[3], whole 100 KB items)", "value": round(ms, 4), "unit": "ms/query", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(ms, 4), "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u32 residues, 32x32->64-bit integer MAC (two 28-bit CRT primes)", "data": "synthetic",
+            "config": {"workload": label + f"; an item = factor {factor} instances of the 2^20 x {plain_bytes} B database ({factor} x 64 GiB NTT form), explicit DBs generated on device",
+                       "answer_sha256": out_h, "db_bytes_ntt_form": factor * int(shp.dim0) * int(shp.num_per) * 4 * sa.N * 8,
+                       "parallelism": f"instances x{world} (rank r: instances r, r + {world}, ...), conversion on every rank, one all-gather of the {factor} responses, no reduce" if ctx.use_dist else
+                                      f"one GPU: {factor} instances swept one after the other"},
+            "item": {"factor": factor, "item_bytes": STREAM_ITEM_BYTES, "plaintext_bytes": plain_bytes, "instances_of_rank0": mine, "instances_resident": resident,
+                     "instances_swept_per_query_rank0": len(swept), "image_bytes_per_instance": image_bytes, "db_device_bytes_rank0": int(sum(sv.db_device_bytes() for sv in inst)),
+                     "conversion_us": round(pre_us, 1), "per_instance_us": round(inst_us, 1), "sweep_kernel_ms": round(sweep_ms, 4),
+                     "item_ms_by_the_reference_formula": round((pre_us + factor * inst_us) / 1e3, 4), "response_bytes": factor * wire,
+                     "note": "value = one timed item query on this many GPUs.  item_ms_by_the_reference_formula = conversion + factor x (first dimension + folding + switch) of ONE instance, "
+                             "the way select_params.py:409-426 prices an item from a single-instance run.  instances_resident < instances_swept: the rank re-sweeps resident images for "
+                             "the instances that do not fit (one GPU holds four 56 GiB images), the sweep's time does not depend on the data"},
+            "answer_sha256": out_h,
+            "roofline": {"bound": "hbm", "kernel": "sweep_kernel (one instance)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "frac_device_bytes": round(dev_bytes / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None, "algorithmic_bytes_per_launch": int(bytes_sweep),
+                         "device_bytes_per_launch": int(dev_bytes), "avg_launch_ms": round(sweep_ms, 4), "launches_timed": 5,
+                         "database_bytes_per_s_over_the_item_query": round(len(swept) * bytes_sweep / (ms * 1e-3) / 1e9, 1)},
+        }
+        if ctx.use_dist:
+            line["rccl"] = ctx.rccl
+    for sv in inst:
+        sv.close()
+    torch.cuda.empty_cache()
+    return line
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS) + ["pack"], help="config2 = BASELINE.json configs[1], the one the metric is quoted on; "
-                    "config3 / stream / pack = configs[2] / [3] / [4]")
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS) + ["pack", "stream-instance"], help="config2 = BASELINE.json configs[1], the one the metric is quoted on; "
+                    "config3 / stream / pack = configs[2] / [3] / [4]; stream = a whole 100 KB item (7 database instances, factor-sharded over the GPUs), "
+                    "stream-instance = one of its instances through the j-shard path (the figure of rounds 1-5)")
     ap.add_argument("--headline", default=None, choices=["config2", "config3"], help="which of the two base geometries is `value` when both are timed (default config2 = configs[1], "
                     "the one the metric is quoted on, with configs[2]'s geometry under `also.config3`); --headline config3 swaps them: `value` is then the 2^24 x 256 B geometry, "
                     "whose sweep is 75 %% of the query -- the one a j-shard over N GPUs CAN scale -- and configs[1] goes under `also.config2`")
@@ -1084,6 +1215,19 @@ def main(argv=None):
     prog.arm("process group set-up", 3.0)
     ctx = Ctx(args, prog)
     prog.arm("set-up", 3.0)
+    if args.workload == "stream":
+        out = bench_stream(args, ctx, prog)
+        prog.arm("process group tear-down", 1.0)
+        ctx.close()
+        prog.disarm()
+        if ctx.rank == 0:
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)
+            print(json.dumps(out), flush=True)
+        return
+    if args.workload == "stream-instance":
+        args.workload = "stream"
     out, params_kw = bench_base(args, ctx, args.workload, args.steps, args.warmup, True, prog)
     if ctx.world > 1 and "config2" in (args.workload, args.secondary) and not args.no_replicas and (args.nu1, args.nu2) == (None, None):
         out["replicas"] = bench_replicas(args, ctx, prog)  # no collective on its data path: cannot hang where the j-shard schedules did not

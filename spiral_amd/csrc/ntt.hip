@@ -328,17 +328,52 @@ __global__ __launch_bounds__(256, 8) void ntt_forward_kernel(Tables t, FwdParams
     }
 }
 
-// Two gadget digits of one source polynomial per workgroup (LD_DIGIT / LD_EXPAND, ST_PK): the source is read once for both and
+// Two gadget digits of one source polynomial per workgroup (LD_DIGIT / LD_EXPAND / LD_SDIFF, ST_PK): the source is read once for both and
 // the two forward transforms share every twiddle fetch (ntt_forward_block2).  Job b2 = (source, digit pair kk): digits 2kk and
 // 2kk + 1 (the second absent when the digit count is odd); destinations and results exactly those of ntt_forward_kernel.
+// LD_SDIFF (round 6): the fold's digit-difference transforms, two digits of one polynomial PAIR per workgroup -- the wide rounds of a batch
+// are thousands of such transforms per launch, where the shared twiddle fetch is worth what it is for the expansion's digits.
 template <uint32_t LOAD>
 __global__ __launch_bounds__(256) void ntt_forward2_kernel(Tables t, FwdParams p) {
     __shared__ uint64_t sh[2][kLdsWords];
-    const uint32_t tid = threadIdx.x, b2 = blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+    uint32_t b2 = blockIdx.x;
     {
         const int64_t lane = p.lanes.here();
         lane_shift(p.src, lane);
         lane_shift(p.dst, lane);
+    }
+    if constexpr (LOAD == LD_SDIFF) {
+        // the digit-pair jobs of a polynomial pair re-read the same 32 KiB: consecutive jobs on one XCD (as ntt_forward_kernel does)
+        if ((gridDim.x & 7u) == 0) b2 = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+        const uint32_t tdim = p.n_digits, jp = (tdim + 1u) >> 1, s = b2 / jp, kk = b2 - s * jp, k0 = 2u * kk, k1 = k0 + 1u;
+        const bool two = k1 < tdim;
+        const uint32_t i = s / 6u, rc = s - i * 6u;  // source s = (pair i, r, c): L = raw[i][r][c], H = raw[np + i][r][c]
+        const uint64_t* sl = p.src + ((size_t)i * 6u + rc) * kN;
+        const uint64_t* sh_ = p.src + ((size_t)(p.fold_np + i) * 6u + rc) * kN;
+        uint64_t rl[8], rh[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            rl[r] = sl[ix_a(tid, r)];
+            rh[r] = sh_[ix_a(tid, r)];
+        }
+        uint32_t lo0[8], hi0[8], lo1[8], hi1[8];
+        sdigit_diff8([&](int r) { return rh[r]; }, [&](int r) { return rl[r]; }, k0, p.bits, p.ell, lo0, hi0);
+        sdigit_diff8([&](int r) { return rh[r]; }, [&](int r) { return rl[r]; }, two ? k1 : k0, p.bits, p.ell, lo1, hi1);
+        ntt_forward_block2<false>(lo0, hi0, lo1, hi1, sh[0], sh[1], t.fwd, tid);
+        if (!p.lazy_out) {
+            canonicalize8(lo0, hi0);
+            canonicalize8(lo1, hi1);
+        }
+        const uint32_t d0 = (i * 3u * p.ell + (rc >> 1) + 3u * k0) * 2u + (rc & 1u);  // operand layout D'[i][r + 3k][c]
+        uint64_t v[8];
+        pk_pack8(lo0, hi0, v);
+        pk_store8(p.dst + (size_t)d0 * kN, tid, v);
+        if (two) {
+            pk_pack8(lo1, hi1, v);
+            pk_store8(p.dst + (size_t)(d0 + 6u) * kN, tid, v);  // digit k + 1: three rows x two columns further
+        }
+        return;
     }
     uint32_t tdim, kk, ob;  // digits per source, pair index, job id of digit 0 of this source in ntt_forward_kernel's numbering
     const uint64_t* src;
@@ -627,6 +662,11 @@ void launch_ntt_forward(const DeviceTables& t, const FwdParams& p_in, uint32_t l
     if (fwd2 && store == ST_PK && load == LD_DIGIT && p.n_digits >= 2) {
         const uint32_t nsrc = nblocks / p.n_digits;
         hipLaunchKernelGGL((ntt_forward2_kernel<LD_DIGIT>), dim3(nsrc * ((p.n_digits + 1u) / 2u), 1, p.lanes.n), dim3(256), 0, s, tb, p);
+        return;
+    }
+    if (fwd2 && store == ST_PK && load == LD_SDIFF && p.n_digits >= 2) {
+        const uint32_t nsrc = nblocks / p.n_digits;
+        hipLaunchKernelGGL((ntt_forward2_kernel<LD_SDIFF>), dim3(nsrc * ((p.n_digits + 1u) / 2u), 1, p.lanes.n), dim3(256), 0, s, tb, p);
         return;
     }
     if (fwd2 && store == ST_PK && load == LD_EXPAND) {

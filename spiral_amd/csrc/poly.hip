@@ -750,9 +750,13 @@ __global__ __launch_bounds__(kTpb) void scal2mat_rec_kernel(Scal2MatParams p) {
     scal2mat_rec_body(p, blockIdx.x, blockIdx.y);
 }
 static bool scal2mat_rec_ok(const Scal2MatParams& p) { return p.count && p.count % 16 == 0 && p.qs && !p.out; }
+// The 64 x 16 tile (a W word fetched once per four digit words, 512-byte runs per wave) for large t_conv -- and for ANY t_conv once the launch is big
+// enough to fill the chip with its fewer, larger workgroups (48 KiB of LDS, 160 VGPRs: three per CU): the conversion of an eight-query batch at
+// t_conv = 4 takes 167 us with it against 202 us with the 16 x 16 tile, which wins at one query (512 workgroups of the wide tile would leave half the CUs idle)
+static bool scal2mat_wide(const Scal2MatParams& p) { return p.t_conv >= scal2mat_wide_min() || (kN / 64u) * (p.count / 16u) * p.lanes.n >= 2048u; }
 void launch_scal2mat(const Scal2MatParams& p, hipStream_t s) {
     if (scal2mat_rec_ok(p)) {
-        if (p.t_conv >= scal2mat_wide_min())
+        if (scal2mat_wide(p))
             hipLaunchKernelGGL(scal2mat_rec4_kernel, dim3(kN / 64, p.count / 16, p.lanes.n), dim3(kTpb), 0, s, p);
         else
             hipLaunchKernelGGL(scal2mat_rec_kernel, dim3(kN / 16, p.count / 16, p.lanes.n), dim3(kTpb), 0, s, p);
@@ -804,9 +808,13 @@ __global__ __launch_bounds__(kTpb) void regev_to_gsw_kernel(GswParams p) {
 // the two conversion products are independent: one launch, the first n1 blocks ScalToMat, the rest Regev->GSW
 template <bool WIDE>
 __global__ __launch_bounds__(kTpb) void convert_products_kernel(Scal2MatParams sp, GswParams gp, uint32_t n1) {
-    const uint32_t b = blockIdx.x;
     scal2mat_lane(sp);
     gsw_lane(gp);
+#ifdef CONVERT_GSW_FIRST  // (variant: the latency-bound Regev->GSW workgroups dispatched first, the streaming ScalToMat ones fill in behind them)
+    const uint32_t n2 = gridDim.x - n1, b = blockIdx.x < n2 ? blockIdx.x + n1 : blockIdx.x - n2;
+#else
+    const uint32_t b = blockIdx.x;
+#endif
     if (b < n1) {
         if constexpr (WIDE)
             scal2mat_rec4_body(sp, b % (kN / 64u), b / (kN / 64u));
@@ -819,7 +827,7 @@ __global__ __launch_bounds__(kTpb) void convert_products_kernel(Scal2MatParams s
 }
 void launch_convert_products(const Scal2MatParams& sp, const GswParams& gp, hipStream_t s) {
     if (scal2mat_rec_ok(sp) && gp.dims) {
-        const bool wide = sp.t_conv >= scal2mat_wide_min();
+        const bool wide = scal2mat_wide(sp);
         const uint32_t n1 = (kN / (wide ? 64u : 16u)) * (sp.count / 16u), n2 = kBpp * gp.dims * gp.ell;
         if (wide)
             hipLaunchKernelGGL(convert_products_kernel<true>, dim3(n1 + n2, 1, sp.lanes.n), dim3(kTpb), 0, s, sp, gp, n1);

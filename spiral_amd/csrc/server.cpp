@@ -1172,17 +1172,17 @@ int spiral_gpu_server_set_query(spiral_gpu_server* S, const uint64_t* query) {
 }  // extern "C"
 
 namespace {
-// expandImproved for the query lanes `lanes` of S (lane 0 = S itself)
-int expand_lanes(spiral_gpu_server* S, const Lanes& lanes) {
+// expandImproved for the query lanes `lanes` of S (lane 0 = S itself); rounds [r_begin, r_end) of it
+int expand_lanes(spiral_gpu_server* S, const Lanes& lanes, uint32_t r_begin = 0, uint32_t r_end = 0xffffffffu) {
     const spiral_gpu_params& p = S->p;
     if (p.direct_upload || S->s.g == 0) {  // nothing to expand: the query ciphertexts are the expanded ones
         const size_t n = p.direct_upload ? (size_t)S->s.n_bits * 2 : 2;
-        for (uint32_t q = 0; q < lanes.n; q++)
+        for (uint32_t q = 0; q < lanes.n && r_begin == 0; q++)
             HIP_OK(hipMemcpyAsync(S->cv.p + lanes.off[q], S->query.p + lanes.off[q], n * kPolyBytes, hipMemcpyDeviceToDevice, S->stream));
         return 0;
     }
     ExpandWork wk{S->ex_raw.p, S->ex_g.p};
-    run_expand(S->tb, S->cv.p, S->s.g, p.t_exp, S->w_left.p, p.t_exp_right, S->w_right.p, S->s.ell * p.nu2, S->s.stopround, wk, S->stream, S->query.p, 0, 0xffffffffu,
+    run_expand(S->tb, S->cv.p, S->s.g, p.t_exp, S->w_left.p, p.t_exp_right, S->w_right.p, S->s.ell * p.nu2, S->s.stopround, wk, S->stream, S->query.p, r_begin, r_end,
                S->ex_shard, 3, lanes);
     return 0;
 }
@@ -1731,9 +1731,21 @@ int spiral_gpu_server_run_query_batch(spiral_gpu_server* const* servers, uint32_
     int rc_l = 0;
     const uint64_t* limbs = limb_image(S, n, &rc_l);  // (not inside the capture below: it may build the image)
     if (rc_l) return rc_l;
+    // Batches of four or more: the Regev->GSW conversion runs as soon as the odd (GSW-bit) tree of the expansion is complete, after round `stopround`
+    // (src/spiral.cpp:1700-1702: no odd ciphertext is touched later), and ScalToMat after the last round.  The same launches' work in another order -- at
+    // these sizes none of them is launch-bound -- but the 24 MiB of GSW matrices and keys per query are then written ~0.3 ms before the sweep instead of
+    // right in front of it: dirty lines draining into the database stream cost the matrix-core sweep 30-70 us (profiles/r06_sweep_in_situ_batch.txt).
+    const bool gsw_early = n >= 4 && !S->p.direct_upload && S->s.stopround > 0 && S->s.stopround + 1 < S->s.g && S->p.nu2 > 0;
     auto body = [&]() {
-        if (expand_lanes(S, lanes)) return -1;
-        if (convert_part(S, CONV_BOTH, S->stream, false, lanes)) return -1;
+        if (gsw_early) {
+            if (expand_lanes(S, lanes, 0, S->s.stopround + 1)) return -1;
+            if (convert_part(S, CONV_GSW, S->stream, false, lanes)) return -1;
+            if (expand_lanes(S, lanes, S->s.stopround + 1)) return -1;
+            if (convert_part(S, CONV_S2M, S->stream, false, lanes)) return -1;
+        } else {
+            if (expand_lanes(S, lanes)) return -1;
+            if (convert_part(S, CONV_BOTH, S->stream, false, lanes)) return -1;
+        }
         const uint32_t* qs[kMaxLanes];
         uint64_t* acc[kMaxLanes];
         for (uint32_t b = 0; b < n; b++) {

@@ -246,7 +246,12 @@ struct RecPlan {
 #pragma unroll
         for (int i = 0; i < R; i++) {
             const uint32_t* rec = src[i] + block;
+#ifdef SWEEP_ABL_QUAD  // ablation (tools/build_variants.sh): the time the kernel would take if a thread's four values arrived as one 16-byte load of ready limbs; results are garbage
+            const uint4 x = *reinterpret_cast<const uint4*>(reinterpret_cast<uintptr_t>(rec) & ~(uintptr_t)15);
+            v[i][0] = x.x, v[i][1] = x.y, v[i][2] = x.z, v[i][3] = x.w;
+#else
             v[i][0] = rec[0], v[i][1] = rec[6], v[i][2] = rec[12], v[i][3] = rec[18];
+#endif
         }
     }
     __device__ __forceinline__ void store(uint4* buf) const {
@@ -254,6 +259,11 @@ struct RecPlan {
 #pragma unroll
         for (int i = 0; i < R; i++) {
             if (lds[i] != ~0u) {
+#ifdef SWEEP_ABL_QUAD
+                uint32_t* oa = out + lds[i];
+                oa[0] = v[i][0], oa[4] = v[i][1], oa[8] = v[i][2], oa[12] = v[i][3];
+                continue;
+#endif
                 const uint32_t x0 = (v[i][0] + kLimbBias) ^ kLimbBias, x1 = (v[i][1] + kLimbBias) ^ kLimbBias, x2 = (v[i][2] + kLimbBias) ^ kLimbBias,
                                x3 = (v[i][3] + kLimbBias) ^ kLimbBias;
                 const uint32_t a_lo = __builtin_amdgcn_perm(x1, x0, 0x05010400u), a_hi = __builtin_amdgcn_perm(x1, x0, 0x07030602u);

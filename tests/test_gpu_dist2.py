@@ -286,3 +286,63 @@ def test_bench_pack_trial_shards():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 1 and "trials x1 (16 per rank)" in out["config"]["parallelism"] and out["roofline"]["frac"] > 0.5
+
+
+def test_bench_watchdog_names_the_rank_that_never_joined():
+    """the process-group set-up has its own short watchdog: with SPIRAL_BENCH_INJECT_HANG=pg-setup:1 rank 1 never calls init_process_group; rank 0's
+    watchdog fires after --pg-watchdog seconds with a line that says which rank never checked in, and the job exits non-zero -- a fresh exit, nothing re-exec'd"""
+    import json
+    import subprocess
+    import time
+
+    env = dict({k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")},
+               SPIRAL_BENCH_INJECT_HANG="pg-setup:1", SPIRAL_BENCH_PG_WATCHDOG_S="20")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--shared-device", "--prewarm", "2", "--nu1", "7", "--nu2", "6", "--no-config3"]
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
+    assert r.returncode != 0 and time.time() - t0 < 240
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["partial"] is True and out["hung_in"] == "process group set-up" and out["watchdog_s"] == 20
+    assert out["ranks_never_joined"] == [1] and out["ranks_checked_in"] == [0]
+    assert "made no progress in 'process group set-up'" in r.stderr
+
+
+def test_bench_collective_smoke_and_headline_swap():
+    """two ranks on the one device (gloo): the collective smoke test ran and is in `rccl`; --headline config3 makes the 2^24 x 256 B geometry the `value`
+    (here shrunk with --nu1/--nu2, which disables the secondary leg) -- and `config` carries the answer hash and the no-pre-warm value for the driver's record"""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--shared-device", "--prewarm", "2", "--headline", "config3",
+           "--nu1", "7", "--nu2", "6"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["rccl"]["collective_smoke"]["ok"] is True and out["rccl"]["world_size"] == 2
+    assert "configs[2]" in out["config"]["workload"] and "t_GSW=10" in out["config"]["workload"]
+    assert out["config"]["answer_sha256"] == out["answer_sha256"] and len(out["answer_sha256"]) == 64
+    assert out["config"]["value_no_prewarm"] == out["value_no_prewarm"]["value"] > 0
+
+
+def test_bench_stream_item_factor_sharded_over_two_ranks():
+    """bench.py --workload stream: a 100 KB item = 7 database instances; two ranks (one device, gloo) hold instances {0, 2, 4, 6} and {1, 3, 5}, every rank
+    converts the one query, ONE all-gather of the seven responses, no reduce.  At a geometry small enough for all seven instances to be resident on the one
+    device; the same answer hash as the one-rank run (which sweeps the seven instances one after the other)."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "stream", "--steps", "3", "--warmup", "1", "--nu1", "6", "--nu2", "6"]
+    r2 = subprocess.run(base + ["--gpus", "2", "--backend", "gloo", "--shared-device"], capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-2000:]
+    o2 = json.loads([ln for ln in r2.stdout.splitlines() if ln.startswith("{")][-1])
+    r1 = subprocess.run(base + ["--gpus", "1"], capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-2000:]
+    o1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][-1])
+    for o, world, mine in ((o2, 2, [0, 2, 4, 6]), (o1, 1, list(range(7)))):
+        it = o["item"]
+        assert o["n_gpus"] == world and it["factor"] == 7 and it["instances_of_rank0"] == mine and it["instances_resident"] == len(mine) == it["instances_swept_per_query_rank0"]
+        assert it["db_device_bytes_rank0"] == len(mine) * it["image_bytes_per_instance"] and o["value"] > 0 and o["roofline"]["achieved"] > 0
+    assert o1["answer_sha256"] == o2["answer_sha256"] == o2["config"]["answer_sha256"] and len(o1["answer_sha256"]) == 64
+    assert "no reduce" in o2["config"]["parallelism"] and o2["rccl"]["collective_smoke"]["ok"] is True

@@ -354,6 +354,8 @@ def test_load_db_in_several_staging_passes(sa, oracle, opts):
     ({}, 17),                                   # itself falls back to the two-product form (kernels.h fold_pair_exact); likewise ell = 17
     (dict(fwd2=1), 8),                          # every digit launch through the two-digits-per-workgroup kernel (default only from 8192 transforms)
     (dict(fwd2=0), 8),
+    (dict(fwd2=1), 7),                          # odd digit counts: the last job of a source carries one digit (the fold's LD_SDIFF and the conversion's LD_DIGIT
+    (dict(fwd2=1), 9),                          # through the two-digit kernel)
 ])
 def test_fold_chain_schedules(sa, oracle, env, t_gsw, opts):
     """the fold's forms (library options taken when the server is created -- spiral_gpu_set_option -- or chosen by the server from the gadget

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 constexpr uint32_t kN = 2048;
@@ -66,8 +67,15 @@ __global__ __launch_bounds__(256) void split_kernel(const uint64_t* key, const u
     }
 }
 
-int main() {
-    const uint32_t K = 48, max_out = 768;
+// usage: tools/mac_gather_probe [K=48] [outputs ...]   (round 6: K = 8 with 2 .. 128 outputs = the even tree of expansion rounds 0 .. 5, both rows;
+// K = 24 + addend ~ the pair-form fold's narrow rounds)
+int main(int argc, char** argv) {
+    const uint32_t K = argc > 1 ? (uint32_t)atoi(argv[1]) : 48u;
+    std::vector<uint32_t> outs;
+    for (int i = 2; i < argc; i++) outs.push_back((uint32_t)atoi(argv[i]));
+    if (outs.empty()) outs = {6u, 12u, 48u, 96u, 192u, 384u, 768u};
+    uint32_t max_out = 0;
+    for (uint32_t n : outs) max_out = n > max_out ? n : max_out;
     uint64_t *key, *d, *out;
     hipMalloc(&key, (size_t)K * kN * 8);
     hipMalloc(&d, (size_t)max_out * K * kN * 8);
@@ -77,11 +85,11 @@ int main() {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    printf("K = %u terms per output polynomial (2 m2 of config 2's fold): %.2f MiB gathered per output polynomial\n", K, 2.0 * K * kN * 8 / (1 << 20));
+    printf("K = %u terms per output polynomial: %.2f MiB gathered per output polynomial\n", K, 2.0 * K * kN * 8 / (1 << 20));
     printf("%10s %28s %28s\n", "outputs", "consumer-side gather (us)", "split over 32 workgroups (us)");
     // output polynomials per launch: config 2's fold rounds hold 6 np' of them, np' = 64 ... 1; one digit job per block in the
     // narrow rounds repeats the gather ell = 8 times (48 blocks for np' = 1)
-    for (uint32_t n : {6u, 12u, 48u, 96u, 192u, 384u, 768u}) {
+    for (uint32_t n : outs) {
         float ms[2];
         for (int which = 0; which < 2; which++) {
             const int iters = 20;
