@@ -72,7 +72,8 @@ int spiral_gpu_get_shape(const spiral_gpu_params *p, spiral_gpu_shape *out);
  *   "sweep_mfma_min"  batches of at least this many queries sweep on the matrix cores (default 2; 0 = never).  Initial value: SPIRAL_SWEEP_MFMA.
  *   "one_image"       1 (default) a server that batches on the matrix cores keeps ONE image of its database and converts it in place between the
  *                     packed and the limb-plane form (spiral_gpu_server_set_db_format); 0 = a second image beside the first
- *   "fwd2"            -1 (default) the two-digits-per-workgroup transform kernel from 8192 transforms per launch; 0 never; 1 always
+ *   "fwd2"            -1 (default) the two-digits-per-workgroup transform kernel from "fwd2_min" transforms per launch; 0 never; 1 always
+ *   "fwd2_min"        that threshold (default 8192 transforms per launch, all query lanes together)
  *   "db_stage_bytes"  bytes of the staging buffer of load_db / load_db_items (default 64 MiB).  Initial value: SPIRAL_DB_STAGE_BYTES.
  * These three environment variables are the only ones the library reads. */
 int spiral_gpu_set_option(const char *name, int64_t value);

@@ -26,7 +26,7 @@ inline const char* tuning_env(const char*) { return nullptr; }
 // launch (ntt.hip), 0 / 1 = never / always.  Same results either way; tests force each form.
 struct Options {
     int fold_pair = 1, fold_chain = 1, fwd2 = -1;
-    uint32_t fold_blocks = 768, sweep_mfma_min = 2;
+    uint32_t fold_blocks = 768, sweep_mfma_min = 2, fwd2_min = 8192;
     size_t db_stage_bytes = (size_t)64 << 20;
     int one_image = 1;  // a server that batches on the matrix cores keeps ONLY the limb-plane image of its database (server.cpp)
 };
@@ -277,7 +277,7 @@ struct GswParams {
     const uint64_t* chat;  // [dims*ell][2*t_conv] PK digits (cv row 0 digits, then row 1 digits)
     const uint64_t* cv;
     IndexMap cv_pos;       // i (over dims*ell) -> ct index
-    uint64_t* gsw;         // [dims][3][3*ell] PK, dimension d stored at index (dims-1-d)  (src/spiral.cpp:2324)
+    uint64_t* gsw;         // optional: [dims][3][3*ell] PK, dimension d stored at index (dims-1-d)  (src/spiral.cpp:2324)
     uint64_t* key;         // optional: the fold key of the same matrices, written in the same pass: key[d][r][0..m2) = G2 - gsw (= Q_neg, src/spiral.cpp:2361-2379), key[d][r][m2..2*m2) = gsw
     uint32_t t_conv, ell, dims;
     Lanes lanes;  // every pointer per query lane

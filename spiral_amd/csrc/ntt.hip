@@ -649,11 +649,10 @@ void launch_ntt_forward(const DeviceTables& t, const FwdParams& p_in, uint32_t l
     p.inv_to = inv(p.t_o);
     Tables tb{t.fwd, t.inv};
     // Two digits per workgroup on one twiddle fetch (ntt_forward2_kernel) pay in steady state only -- 14-24 % from 16 k transforms up, nothing
-    // at one or two generations of resident workgroups (profiles/r04_twiddle_sharing.txt): used from kFwd2Min transforms per launch (all
+    // at one or two generations of resident workgroups (profiles/r04_twiddle_sharing.txt): used from option fwd2_min = 8192 transforms per launch (all
     // query lanes together).  Option "fwd2" = 0 / 1 forces it off / on (read per call: tests, A/B).  Same results either way.
-    constexpr uint32_t kFwd2Min = 8192;
     const int fwd2_opt = options().fwd2;
-    const bool fwd2 = (fwd2_opt >= 0 ? fwd2_opt != 0 : (uint64_t)nblocks * p.lanes.n >= kFwd2Min) && p.tinv == 0;  // (the two-digit loader has no automorphism gather)
+    const bool fwd2 = (fwd2_opt >= 0 ? fwd2_opt != 0 : (uint64_t)nblocks * p.lanes.n >= options().fwd2_min) && p.tinv == 0;  // (the two-digit loader has no automorphism gather)
     // udiv_small is exact for job indices below 2^32 / d: far above any launch of the server, checked here because the seams take caller sizes
     if ((uint64_t)nblocks * std::max({p.n_digits, p.t_e, p.t_o, 1u}) >= (1ull << 32)) {
         fprintf(stderr, "launch_ntt_forward: %u jobs exceed the range of the job-index division\n", nblocks);

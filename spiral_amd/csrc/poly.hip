@@ -766,6 +766,8 @@ void launch_scal2mat(const Scal2MatParams& p, hipStream_t s) {
 }
 
 // ---- regevToGSW (src/spiral.cpp:1985-2025) ------------------------------------------------------------------------
+// HOIST: the V product's operands requested up front (the conversion's own launch in a batch: 104 VGPRs); the merged single-query launch keeps the loop (78)
+template <bool HOIST>
 __device__ __forceinline__ void regev_to_gsw_body(const GswParams& p, uint32_t bx, uint32_t by) {
     const uint32_t z = bx * kTpb + threadIdx.x, di = by;  // di = d*ell + i
     const uint32_t d = di / p.ell, i = di - d * p.ell, tc = p.t_conv;
@@ -774,13 +776,32 @@ __device__ __forceinline__ void regev_to_gsw_body(const GswParams& p, uint32_t b
     uint64_t s2m[3][2];
     scal2mat_slot(p.w, chat, tc, cv1, z, s2m);
     Acc2 accv[3];
-    for (uint32_t k = 0; k < 2 * tc; k++) {
-        uint64_t cvv = chat[(size_t)k * kN];
+    if (HOIST && tc <= 4) {
+        // as scal2mat_slot: all 2 t_conv digit words and their 6 t_conv V words requested before the first multiply (inside the loop the
+        // compiler waits for each term before requesting the next: eight dependent round trips per thread at t_conv = 4)
+        uint64_t cvv[8], vv[8][3];
 #pragma unroll
-        for (uint32_t r = 0; r < 3; r++) accv[r].mac(p.v[((size_t)r * 2 * tc + k) * kN + z], cvv);
+        for (uint32_t u = 0; u < 8; u++) {
+            const uint32_t k = min(u, 2 * tc - 1);
+            cvv[u] = chat[(size_t)k * kN];
+#pragma unroll
+            for (uint32_t r = 0; r < 3; r++) vv[u][r] = p.v[((size_t)r * 2 * tc + k) * kN + z];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++)
+            if (u < 2 * tc) {
+#pragma unroll
+                for (uint32_t r = 0; r < 3; r++) accv[r].mac(vv[u][r], cvv[u]);
+            }
+    } else {
+        for (uint32_t k = 0; k < 2 * tc; k++) {
+            uint64_t cvv = chat[(size_t)k * kN];
+#pragma unroll
+            for (uint32_t r = 0; r < 3; r++) accv[r].mac(p.v[((size_t)r * 2 * tc + k) * kN + z], cvv);
+        }
     }
     const uint32_t cols = 3 * p.ell;
-    uint64_t* g = p.gsw + (size_t)(p.dims - 1 - d) * 3 * cols * kN + z;
+    uint64_t* g = p.gsw ? p.gsw + (size_t)(p.dims - 1 - d) * 3 * cols * kN + z : nullptr;  // (the resident server keeps the matrices only as the Q half of the fold key)
     // fold key of the same columns (src/spiral.cpp:2361-2379): key[r][mm] = G2[r][mm] - gsw[r][mm] (= Q_neg; the NTT is
     // linear and a constant c is c in every slot), key[r][m2 + mm] = gsw[r][mm]; G2[r][3i + c] = 2^(bits*i) iff c == r
     uint64_t* key = p.key ? p.key + (size_t)(p.dims - 1 - d) * 3 * (2 * cols) * kN + z : nullptr;
@@ -792,7 +813,7 @@ __device__ __forceinline__ void regev_to_gsw_body(const GswParams& p, uint32_t b
 #pragma unroll
         for (uint32_t c = 0; c < 3; c++) {
             const uint64_t q = col[c];
-            g[((size_t)r * cols + 3 * i + c) * kN] = q;
+            if (g) g[((size_t)r * cols + 3 * i + c) * kN] = q;
             if (key) {
                 const uint32_t gp = c == r ? g2p : 0u, gb = c == r ? g2b : 0u;
                 key[((size_t)r * 2 * cols + 3 * i + c) * kN] = pack(csub(gp + kP - lo32(q), kP), csub(gb + kB - hi32(q), kB));
@@ -803,7 +824,7 @@ __device__ __forceinline__ void regev_to_gsw_body(const GswParams& p, uint32_t b
 }
 __global__ __launch_bounds__(kTpb) void regev_to_gsw_kernel(GswParams p) {
     gsw_lane(p);
-    regev_to_gsw_body(p, blockIdx.x, blockIdx.y);
+    regev_to_gsw_body<true>(p, blockIdx.x, blockIdx.y);
 }
 // the two conversion products are independent: one launch, the first n1 blocks ScalToMat, the rest Regev->GSW
 template <bool WIDE>
@@ -822,7 +843,7 @@ __global__ __launch_bounds__(kTpb) void convert_products_kernel(Scal2MatParams s
             scal2mat_rec_body(sp, b % (kN / 16u), b / (kN / 16u));
     } else {
         const uint32_t bb = b - n1;
-        regev_to_gsw_body(gp, bb % kBpp, bb / kBpp);
+        regev_to_gsw_body<false>(gp, bb % kBpp, bb / kBpp);
     }
 }
 void launch_convert_products(const Scal2MatParams& sp, const GswParams& gp, hipStream_t s) {

@@ -48,7 +48,7 @@ struct spiral_gpu_server {
     // fixed order (srv_alloc): servers with equal parameters and shard have equal layouts, which is what run_query_batch relies on
     DevBuf arena;
     DevBuf db, w_left, w_right, w, v, query, cv, ex_raw, ex_g, ex_raw2, ex_g2;  // (the second work set: the odd tree of a split expansion)
-    DevBuf cv_raw, cv_g, gsw, key, cts_keep;
+    DevBuf cv_raw, cv_g, key, cts_keep;  // key: [d][3][Q_neg | Q]: the GSW matrices Q (src/spiral.cpp:2324) and G2 - Q (:2361-2379)
     uint64_t *gs_raw_p = nullptr, *gs_chat_p = nullptr;  // the Regev->GSW halves of cv_raw / cv_g
     DevBuf qs, acc_own, raw, fold_d, fold_c, fold_c2, resp, stage;
     uint64_t* acc = nullptr;
@@ -148,7 +148,6 @@ int srv_alloc(spiral_gpu_server* S, const spiral_gpu_server* db_owner) {
         // launch and one digit-transform launch
         a.carve(S->cv_raw, ((size_t)S->dim0_shard + ngs * 2) * kN);
         a.carve(S->cv_g, ((size_t)S->dim0_shard + ngs * 2) * p.t_conv * kN);
-        a.carve(S->gsw, (size_t)p.nu2 * 3 * s.m2 * kN);
         a.carve(S->key, (size_t)p.nu2 * 3 * 2 * s.m2 * kN);
         a.carve(S->qs, (size_t)kN * S->dim0_shard * 6);  // 12 u32 per (z, j)
         a.carve(S->acc_own, (size_t)s.num_per * 6 * kN);
@@ -194,7 +193,7 @@ void srv_free(spiral_gpu_server* S, bool keep_db = false) {
         S->db.p = S->db_limbs.p = nullptr;
     }
     DevBuf* all[] = {&S->db, &S->w_left, &S->w_right, &S->w, &S->v, &S->query, &S->cv, &S->ex_raw, &S->ex_g, &S->ex_raw2, &S->ex_g2, &S->cv_raw,
-                     &S->cv_g, &S->gsw, &S->key, &S->cts_keep, &S->qs, &S->acc_own, &S->raw, &S->fold_d, &S->fold_c, &S->fold_c2,
+                     &S->cv_g, &S->key, &S->cts_keep, &S->qs, &S->acc_own, &S->raw, &S->fold_d, &S->fold_c, &S->fold_c2,
                      &S->resp, &S->stage, &S->wire, &S->db_limbs, &S->arena};  // (the arena after its pieces)
     if (S->db_shared) S->db.p = nullptr;
     for (DevBuf* b : all) b->release();
@@ -410,6 +409,7 @@ int spiral_gpu_set_option(const char* name, int64_t value) {
     else if (n == "sweep_mfma_min" && value >= 0) o.sweep_mfma_min = (uint32_t)value;
     else if (n == "one_image") o.one_image = value != 0;
     else if (n == "fwd2" && value >= -1 && value <= 1) o.fwd2 = (int)value;
+    else if (n == "fwd2_min" && value >= 0) o.fwd2_min = (uint32_t)value;
     else if (n == "db_stage_bytes" && value > 0) o.db_stage_bytes = (size_t)value;
     else return fail("unknown option '%s' or value %lld out of range", name, (long long)value);
     return 0;
@@ -424,6 +424,7 @@ int spiral_gpu_get_option(const char* name, int64_t* value) {
     else if (n == "sweep_mfma_min") *value = o.sweep_mfma_min;
     else if (n == "one_image") *value = o.one_image;
     else if (n == "fwd2") *value = o.fwd2;
+    else if (n == "fwd2_min") *value = o.fwd2_min;
     else if (n == "db_stage_bytes") *value = (int64_t)o.db_stage_bytes;
     else return fail("unknown option '%s'", name);
     return 0;
@@ -1250,7 +1251,7 @@ int convert_part(spiral_gpu_server* S, uint32_t what, hipStream_t st, bool mark_
     gp.chat = S->gs_chat_p;
     gp.cv = S->cv.p;
     gp.cv_pos = IndexMap{1, ps, S->pos_rest};
-    gp.gsw = S->gsw.p;
+    gp.gsw = nullptr;  // the GSW matrices are kept once, as the Q half of the fold key [Q_neg | Q] (8 MiB less to write per query at config 2)
     gp.t_conv = p.t_conv;
     gp.ell = s.ell;
     gp.dims = p.nu2;
@@ -2103,7 +2104,8 @@ int spiral_gpu_server_read(spiral_gpu_server* S, int which, uint64_t* out) {
         case SPIRAL_GPU_BUF_CTS:
             if (!S->keep_cts) return fail("keep_cts is off");
             return download_pk_as_ref(S, S->cts_keep.p, identity_map(), out, (size_t)S->dim0_shard * 6);
-        case SPIRAL_GPU_BUF_GSW: return download_pk_as_ref(S, S->gsw.p, identity_map(), out, (size_t)S->p.nu2 * 3 * s.m2);
+        case SPIRAL_GPU_BUF_GSW:  // row (d, r) of the matrices = columns [m2, 2 m2) of row (d, r) of the key
+            return download_pk_as_ref(S, S->key.p, IndexMap{s.m2, 2 * s.m2, s.m2}, out, (size_t)S->p.nu2 * 3 * s.m2);
         case SPIRAL_GPU_BUF_ACC: return download_pk_as_ref(S, S->acc, identity_map(), out, (size_t)s.num_per * 6);
         case SPIRAL_GPU_BUF_RAW: HIP_OK(hipMemcpy(out, S->raw.p, (size_t)s.num_per * 6 * kPolyBytes, hipMemcpyDeviceToHost)); return 0;
         case SPIRAL_GPU_BUF_FINAL: HIP_OK(hipMemcpy(out, S->raw.p, 6 * kPolyBytes, hipMemcpyDeviceToHost)); return 0;

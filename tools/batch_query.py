@@ -1,5 +1,5 @@
 """B whole queries per launch sequence (spiral_gpu_server_run_query_batch) at config 2 (or --nu1/--nu2): wall us per batch over hipGraph replays.
-usage: tools/batch_query.py [B ...] [--reps=40] [--nu1=8 --nu2=7] [--streams=1]      (under rocprofv3 --kernel-trace for the timeline: tools/trace_summary.py)
+usage: tools/batch_query.py [B ...] [--reps=40] [--opt:NAME=VALUE ...] [--nu1=8 --nu2=7] [--streams=1]      (under rocprofv3 --kernel-trace for the timeline: tools/trace_summary.py)
 --streams=1: every lane on its own stream, as a serving loop would hold them (the batch call orders them around its launch sequence with events)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +8,11 @@ import torch  # (before the library initialises the device)
 import spiral_amd as sa
 
 Bs = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [1, 2, 4, 8]
-opts = dict(a[2:].split("=") for a in sys.argv[1:] if a.startswith("--"))
+opts = dict(a[2:].split("=") for a in sys.argv[1:] if a.startswith("--") and not a.startswith("--opt:"))
+for a in sys.argv[1:]:
+    if a.startswith("--opt:"):  # library options (spiral_gpu_set_option) before any server exists, e.g. --opt:fwd2_min=4096
+        k, v = a[6:].split("=")
+        sa.set_option(k, int(v))
 nu1, nu2, reps = int(opts.get("nu1", 8)), int(opts.get("nu2", 7)), int(opts.get("reps", 40))
 kw = {k: int(opts[k]) for k in ("t_gsw", "t_conv", "t_exp", "t_exp_right") if k in opts}
 pg = sa.make_params(nu1, nu2, **kw)
