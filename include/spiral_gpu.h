@@ -167,6 +167,8 @@ int spiral_gpu_server_create(const spiral_gpu_params *p, int device, uint32_t j_
 void spiral_gpu_server_destroy(spiral_gpu_server *s);
 /* use an external HIP stream (hipStream_t as void*); NULL = the server's own stream */
 int spiral_gpu_server_set_stream(spiral_gpu_server *s, void *hip_stream);
+/* the stream the server launches on now (hipStream_t as void*): e.g. to put the lanes of a batch on lanes[0]'s stream */
+void *spiral_gpu_server_get_stream(spiral_gpu_server *s);
 
 /* database producers: load_db, src/spiral.cpp:1028-1172 */
 int spiral_gpu_server_load_db(spiral_gpu_server *s, const uint64_t *database /* full, reference layout */);
@@ -272,6 +274,10 @@ int spiral_gpu_server_run_query_batch(spiral_gpu_server *const *servers, uint32_
  * gathered -- no reduce (spiral_amd/dist.py all_gather_instance_responses). */
 int spiral_gpu_server_run_query_instances(spiral_gpu_server *s, spiral_gpu_server *const *instances, uint32_t n, int pre,
                                           void *responses, void *finals);
+/* the same from host buffers (as spiral_gpu_server_answer): the query in, the n responses (n x n1 x n2 x 2048 words) and optionally the folded
+ * ciphertexts out; total_us (may be NULL): device time of the whole item query */
+int spiral_gpu_server_answer_instances(spiral_gpu_server *s, spiral_gpu_server *const *instances, uint32_t n,
+                                       const uint64_t *query, uint64_t *responses, uint64_t *finals, double *total_us);
 int spiral_gpu_server_fold(spiral_gpu_server *s);      /* foldOneFurtherDimension x nu2               */
 int spiral_gpu_server_finish(spiral_gpu_server *s);    /* response modulus switch, :1441-1447         */
 int spiral_gpu_server_sync(spiral_gpu_server *s);

@@ -88,6 +88,7 @@ PROTOTYPES = {
     "spiral_gpu_server_create": (C.c_int, [C.POINTER(Params), C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     "spiral_gpu_server_destroy": (None, [C.c_void_p]),
     "spiral_gpu_server_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "spiral_gpu_server_get_stream": (C.c_void_p, [C.c_void_p]),
     "spiral_gpu_server_load_db": (C.c_int, [C.c_void_p, U64P]),
     "spiral_gpu_server_gen_db": (C.c_int, [C.c_void_p, C.c_uint64]),
     "spiral_gpu_server_fill_db_random": (C.c_int, [C.c_void_p, C.c_uint64]),
@@ -99,6 +100,7 @@ PROTOTYPES = {
     "spiral_gpu_server_first_dim_batch": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32]),
     "spiral_gpu_server_run_query_batch": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32]),
     "spiral_gpu_server_run_query_instances": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
+    "spiral_gpu_server_answer_instances": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, U64P, U64P, U64P, C.POINTER(C.c_double)]),
     "spiral_gpu_response_wire_bytes": (C.c_size_t, [C.POINTER(Params), C.c_uint32]),
     "spiral_gpu_response_from_wire": (C.c_int, [C.POINTER(Params), C.c_uint32, C.c_void_p, U64P]),
     "spiral_gpu_server_read_response_wire": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

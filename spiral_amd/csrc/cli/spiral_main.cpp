@@ -1,7 +1,7 @@
 // ./spiral -- drop-in for the reference executable's command line and text summary (src/spiral.cpp:1228-1346,
 // 209-265), with the server-answer path running on an MI355X through libspiral_gpu.so.
 //
-//   ./spiral <nu1> <nu2> <IDX_TARGET> <dbfile|"a"> [--random-data] [--direct-upload] [--nonoise] [--show-diff] [--seed N] [--batch B]
+//   ./spiral <nu1> <nu2> <IDX_TARGET> <dbfile|"a"> [--random-data] [--direct-upload] [--nonoise] [--show-diff] [--seed N] [--batch B] [--instances F]
 //
 // The reference fixes its scheme parameters at compile time (-DTEXP ... -DOUTN, include/values.h:78-93,
 // select_params.py:337); here the same nine values are read at run time from the environment variables or
@@ -143,7 +143,7 @@ int main(int argc, char** argv) {
     const uint64_t total_n = (1ull << nu1) * (1ull << nu2);
     const uint64_t idx_target = strtoull(argv[3], nullptr, 10);
     bool nonoise = false, random_data = false, show_diff = false, direct_flag = false, high_rate = false;
-    uint32_t batch = 0;
+    uint32_t batch = 0, instances = 0;
     // as the reference (random_device, src/core.cpp:202; it labels its own generator NOT SECURE): two words of it.
     // This client is a test harness for the server path, not a hardened client.
     std::random_device rd;
@@ -158,6 +158,10 @@ int main(int argc, char** argv) {
         // --batch B (2 .. 8; not a flag of the reference, which answers one query per process): after the reference's own single-query run, B clients --
         // own keys, own indices -- are answered by ONE call of spiral_gpu_server_run_query_batch and each is decoded and checked
         if (!strcmp(argv[i], "--batch") && i + 1 < argc) batch = (uint32_t)strtoul(argv[++i], nullptr, 10);
+        // --instances F (2 .. 16; not a flag of the reference either: select_params.py:297-298 runs ONE instance and multiplies by factor = ceil(item size /
+        // plaintext size)): an item of F plaintexts = F instances of the database; the one query is converted once and answered against all of them by ONE
+        // call of spiral_gpu_server_answer_instances, every plaintext of the item is decoded and checked
+        if (!strcmp(argv[i], "--instances") && i + 1 < argc) instances = (uint32_t)strtoul(argv[++i], nullptr, 10);
         // --output-err F (src/spiral.cpp:1287-1291) asks the reference to dump its empirical noise statistics (analyze_err.py's
         // input): those are outside this path.  The flag and its file name are consumed so that a driver's
         // command line parses the same way, and the file is not written.
@@ -265,6 +269,7 @@ int main(int argc, char** argv) {
             if (b) {
                 spiral_gpu_server* lane = nullptr;
                 GPU_OK(spiral_gpu_server_create_lane(srv, &lane));
+                GPU_OK(spiral_gpu_server_set_stream(lane, spiral_gpu_server_get_stream(srv)));  // the lanes of a batch on one stream: no event ordering around the launch sequence
                 lanes.push_back(lane);
             }
             clients.emplace_back(p, seed + 1 + b, nonoise);
@@ -300,6 +305,35 @@ int main(int argc, char** argv) {
         for (uint32_t b = 1; b < batch; b++) spiral_gpu_server_destroy(lanes[b]);
     } else if (batch) {
         fprintf(stderr, "spiral: --batch takes 2 .. 8\n");
+        return 1;
+    }
+
+    // ---- --instances F: the item at idx_target = plaintext idx_target of F databases (instance k seeded db_seed + k; instance 0 is the server above)
+    double item_us = 0;
+    bool item_corr = true;
+    if (instances >= 2 && instances <= 16) {
+        std::vector<spiral_gpu_server*> inst{srv};
+        for (uint32_t k = 1; k < instances; k++) {
+            spiral_gpu_server* sv = nullptr;
+            GPU_OK(spiral_gpu_server_create(&p, 0, 0, 0, &sv));
+            GPU_OK(spiral_gpu_server_gen_db(sv, db_seed + k));
+            inst.push_back(sv);
+        }
+        std::vector<uint64_t> resps((size_t)instances * 6 * N);
+        GPU_OK(spiral_gpu_server_use_graphs(srv, 1));
+        for (int it = 0; it < 3; it++)  // capture, a replay, the timed replay
+            GPU_OK(spiral_gpu_server_answer_instances(srv, inst.data(), instances, query.data(), resps.data(), nullptr, &item_us));
+        cout << "Item of " << instances << " plaintexts, Is correct?:";
+        for (uint32_t k = 0; k < instances; k++) {
+            const bool ok = cl.decode(resps.data() + (size_t)k * 6 * N) == db_item(db_seed + k, idx_target, p.p_db);
+            item_corr = item_corr && ok;
+            cout << " " << (ok ? 1 : 0);
+        }
+        cout << endl;
+        GPU_OK(spiral_gpu_server_use_graphs(srv, 0));
+        for (uint32_t k = 1; k < instances; k++) spiral_gpu_server_destroy(inst[k]);
+    } else if (instances) {
+        fprintf(stderr, "spiral: --instances takes 2 .. 16\n");
         return 1;
     }
 
@@ -348,6 +382,7 @@ int main(int argc, char** argv) {
     cout << "      Response switch kernel (GPU·us): " << us[4] << endl;
     cout << "        Whole answer, device (GPU·us): " << us[6] << endl;
     if (batch_us > 0) cout << "   Batch of " << batch << " queries, wall (GPU·us): " << batch_us << endl;
+    if (item_us > 0) cout << "   Item of " << instances << " plaintexts (one query, " << instances << " database instances), device (GPU·us): " << item_us << endl;
     spiral_gpu_server_destroy(srv);
-    return (is_corr && batch_corr) ? 0 : 2;
+    return (is_corr && batch_corr && item_corr) ? 0 : 2;
 }

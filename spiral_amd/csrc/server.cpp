@@ -956,6 +956,8 @@ int spiral_gpu_server_set_stream(spiral_gpu_server* S, void* hip_stream) {
     return 0;
 }
 
+void* spiral_gpu_server_get_stream(spiral_gpu_server* S) { return S ? (void*)S->stream : nullptr; }
+
 int spiral_gpu_server_use_graphs(spiral_gpu_server* S, int on) {
     if (!S) return fail("null server");
     S->use_graphs = on != 0;
@@ -1861,6 +1863,31 @@ int spiral_gpu_server_run_query_instances(spiral_gpu_server* S, spiral_gpu_serve
     if (rc) return rc;
     if (pre) S->have_records = true;
     S->raw_from_acc = false;
+    return 0;
+}
+
+// the same from host buffers, as spiral_gpu_server_answer is to the stages: upload the query, answer it against the n instances, download the n
+// responses (n x 6 x 2048 words) and, when finals != null, the folded ciphertexts; total_us (optional): device time of the whole item query
+int spiral_gpu_server_answer_instances(spiral_gpu_server* S, spiral_gpu_server* const* instances, uint32_t n, const uint64_t* query, uint64_t* responses,
+                                       uint64_t* finals, double* total_us) {
+    if (!S || !instances || n == 0 || !query || !responses) return fail("null argument");
+    HIP_OK(hipSetDevice(S->device));
+    if (spiral_gpu_server_set_query(S, query)) return -1;
+    Scratch sc;
+    uint64_t* d_resp = sc.get((size_t)n * 6 * kN);
+    uint64_t* d_fin = finals ? sc.get((size_t)n * 6 * kN) : nullptr;
+    if (!d_resp || (finals && !d_fin)) return fail("device allocation failed");
+    HIP_OK(hipEventRecord(S->ev[0], S->stream));
+    if (spiral_gpu_server_run_query_instances(S, instances, n, 1, d_resp, d_fin)) return -1;
+    HIP_OK(hipEventRecord(S->ev[1], S->stream));
+    HIP_OK(hipMemcpyAsync(responses, d_resp, (size_t)n * 6 * kPolyBytes, hipMemcpyDeviceToHost, S->stream));
+    if (finals) HIP_OK(hipMemcpyAsync(finals, d_fin, (size_t)n * 6 * kPolyBytes, hipMemcpyDeviceToHost, S->stream));
+    HIP_OK(hipStreamSynchronize(S->stream));
+    if (total_us) {
+        float ms = 0;
+        HIP_OK(hipEventElapsedTime(&ms, S->ev[0], S->ev[1]));
+        *total_us = ms * 1e3;
+    }
     return 0;
 }
 

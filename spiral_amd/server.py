@@ -110,6 +110,14 @@ class Server:
         arr = (C.c_void_p * len(instances))(*[s.h for s in instances])
         check(lib().spiral_gpu_server_run_query_instances(self.h, arr, len(instances), 1 if pre else 0, C.c_void_p(responses_ptr), C.c_void_p(finals_ptr or None)))
 
+    def answer_instances(self, instances, query):
+        """host-buffer form of run_query_instances: (responses [n][3][2][N], folded ciphertexts [n][3][2][N], device us of the item query)"""
+        arr = (C.c_void_p * len(instances))(*[s.h for s in instances])
+        n = len(instances)
+        resp, fin, us = np.zeros((n, 3, 2, N), dtype=np.uint64), np.zeros((n, 3, 2, N), dtype=np.uint64), C.c_double()
+        check(lib().spiral_gpu_server_answer_instances(self.h, arr, n, _p(np.ascontiguousarray(query, dtype=np.uint64)), _p(resp), _p(fin), C.byref(us)))
+        return resp, fin, us.value
+
     def set_db_format(self, fmt: int):
         """convert this server's database image in place: DB_PACKED (vector-ALU sweep) <-> DB_LIMBS (matrix-core sweep); see include/spiral_gpu.h"""
         check(lib().spiral_gpu_server_set_db_format(self.h, fmt))

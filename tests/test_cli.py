@@ -45,6 +45,9 @@ def test_cli_refuses_to_run_without_gpu_or_args():
     (["5", "6", "1234", "a", "--seed", "11", "--batch", "4"], {}),  # + four clients answered by one spiral_gpu_server_run_query_batch call (C++ consumer of the batch entry point)
     (["4", "2", "3", "a", "--direct-upload", "--seed", "12", "--batch", "3"], {"TEXP": "2", "TGSW": "5", "QPBITS": "19"}),
     (["5", "6", "99", "a", "--seed", "13", "--batch", "7"], {}),
+    # an item of three plaintexts = three database instances, one query (the SpiralStream form and with query compression): C++ consumer of answer_instances
+    (["5", "2", "7", "a", "--direct-upload", "--seed", "5", "--instances", "3"], {"TEXP": "2", "TGSW": "5", "QPBITS": "19"}),
+    (["4", "3", "40", "a", "--seed", "14", "--instances", "4"], {}),
 ])
 def test_cli_end_to_end(args, env):
     e = dict(os.environ)
@@ -59,6 +62,10 @@ def test_cli_end_to_end(args, env):
         n = int(args[args.index("--batch") + 1])
         assert re.search(r"Batch of %d queries, Is correct\?:( 1){%d}\n" % (n, n), r.stdout), r.stdout[-1500:]
         assert re.search(r"Batch of %d queries, wall \(GPU·us\): (\d+)" % n, r.stdout)
+    if "--instances" in args:
+        n = int(args[args.index("--instances") + 1])
+        assert re.search(r"Item of %d plaintexts, Is correct\?:( 1){%d}\n" % (n, n), r.stdout), r.stdout[-1500:]
+        assert re.search(r"Item of %d plaintexts \(one query, %d database instances\), device \(GPU·us\): (\d+)" % (n, n), r.stdout)
     if "--output-err" in args:
         assert "noise statistics are not produced" in r.stdout and not os.path.exists(args[args.index("--output-err") + 1])
     assert int(got["resp_sz"].group(1)) == int((2 * 2 * 2048 * (8 + 2) + 2 * 2048 * int(env.get("QPBITS", 20))) / 8)
