@@ -360,6 +360,45 @@ def test_configs3_spiralstream_2_20_x_100KB(sa, oracle_mt, request):
     sampled_checks(sa, M, po, pg, 777, 31337 % (1 << 20), M.Client(po, seed=4), "configs[3] SpiralStream 2^20 x 100KB (64 GiB)", request, n_slots=4, n_items=8)
 
 
+def test_configs3_item_of_three_instances_at_full_size(sa, oracle_mt, request):
+    """configs[3] WHOLE at its real geometry: an item = `factor` instances of the 2^20-plaintext database (select_params.py:297-298; 7 for 100 KB items, three
+    of them here: 3 x 56 GiB resident on the one device).  ONE query, converted once, answered against the three 64 GiB instances by one
+    spiral_gpu_server_run_query_instances sequence (host-buffer form): every plaintext of the item decodes through the oracle's client, every response is the
+    oracle's modulus switch of its folded ciphertext, and instance 0's folded ciphertext and response equal answer()'s on the same server (whose stages the test
+    above checks against the oracle slot by slot at this size)."""
+    M = oracle_mt
+    from spiral_amd import server as SV
+
+    kw = dict(t_gsw=4, t_conv=56, t_exp=2, t_exp_right=56, qprime_bits=27, p_db=32768, direct_upload=1)
+    po, pg = M.make_params(11, 9, **kw), sa.make_params(11, 9, **kw)
+    factor, idx = 3, 271828 % (1 << 20)
+    cl = M.Client(po, seed=14)
+    pp = cl.pub_params()
+    q = cl.query(idx)
+    inst = []
+    for k in range(factor):
+        sv = sa.Server(pg)
+        sv.gen_db(4000 + k)
+        inst.append(sv)
+    inst[0].set_pub_params(*pp)
+    inst[0].use_graphs(True)
+    image = inst[0].db_device_bytes()
+    for rnd in range(2):  # capture, replay
+        resp, fin, us = inst[0].answer_instances(inst, q)
+    for k in range(factor):
+        assert_eq(cl.decode(resp[k]), M.db_item(po, 4000 + k, idx), f"plaintext {k} of item {idx} (instance seeded {4000 + k})")
+        assert_eq(resp[k], M.stage_rescale(po, fin[k]), f"instance {k}: response = the switch of its folded ciphertext")
+    inst[0].use_graphs(False)
+    fin0, resp0, _ = inst[0].answer(q)
+    assert_eq(fin[0], fin0, "instance 0: the item query's folded ciphertext == answer()'s")
+    assert_eq(resp[0], resp0, "instance 0: response == answer()'s")
+    assert sum(sv.db_device_bytes() for sv in inst) == factor * image
+    record(request, f"configs[3] whole, {factor} of 7 instances at full size ({factor} x {image / 2**30:.0f} GiB on the device): one query, every plaintext of the item decoded; "
+                    f"item query {us / 1e3:.1f} ms on the device = conversion + {factor} x (sweep + fold + switch); sha256 of the {factor} responses {sha(resp)}")
+    for sv in inst:
+        sv.close()
+
+
 def test_config5_pack_bit_exact(sa, oracle_mt, request):
     """configs[4]: SpiralPack 2^18 x 30 KB (all_parameter_choices.txt:610-624: nu1=10, nu2=8, n=4, p=256, q'=2^20, t_GSW=8,
     t_conv=4, t_exp=16), 16 trial databases of 4 GiB"""
