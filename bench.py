@@ -385,7 +385,7 @@ def bench_pack(args):
 STREAM_ITEM_BYTES = 100_000  # BASELINE.json configs[3]: 2^20 x 100 KB
 
 
-def bench_stream(args, ctx, prog):
+def bench_stream(args, ctx, prog, steps=None, warmup=None):
     """--workload stream: BASELINE.json configs[3] WHOLE.  A 100 KB item is factor = ceil(100000 / 15360) = 7 plaintexts of the "Streaming 20/spiralstream" set
     (n^2 * 2048 * log2(p) / 8 = 15 360 bytes each, select_params.py:297-298), i.e. SEVEN instances of the 2^20-item database, 64 GiB each in the reference's layout
     (56 GiB on the device): 448 GiB.  The client sends one query; the server converts it once and answers it against every instance -- first dimension, folding
@@ -430,7 +430,7 @@ def bench_stream(args, ctx, prog):
     resident = len(inst)
     swept = [inst[i % resident] for i in range(len(mine))] if mine else []  # (instances beyond the resident ones re-sweep resident images)
     qsrv = inst[0] if inst else None
-    steps, warmup = args.steps, args.warmup
+    steps, warmup = steps or args.steps, args.warmup if warmup is None else warmup
     resp = torch.zeros(slots * 6 * sa.N, dtype=torch.int64, device=dev)
     gathered = torch.zeros(world * resp.numel(), dtype=torch.int64, device=dev) if ctx.use_dist else resp
     if qsrv is not None:
@@ -550,6 +550,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-config3", action="store_true", help="skip the secondary leg (`also.config3`: BASELINE.json configs[2]'s 2^24 x 256 B geometry, the one whose "
                     "sweep is most of the query, timed after the headline workload in the same invocation so that the N = 1, 2, 4, 8 runs give its curve too)")
     ap.add_argument("--config3-steps", type=int, default=10)
+    ap.add_argument("--no-stream-item", action="store_true", help="skip the last leg (`also.stream_item`: BASELINE.json configs[3] whole -- a 100 KB item = 7 instances of the 64 GiB "
+                    "database, factor-sharded over the ranks, one all-gather and no reduce: the configuration whose N-GPU scaling is near-linear up to 7)")
     ap.add_argument("--no-replicas", action="store_true", help="N > 1: skip the `replicas` block (every rank answering batches of whole queries on its own full copy of the database)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the one-GPU self-test)")
     ap.add_argument("--shared-device", action="store_true", help="self-test: all ranks use device 0")
@@ -1252,6 +1254,16 @@ def main(argv=None):
         o3, _ = bench_base(args, ctx, sec, args.config3_steps if sec == "config3" else args.steps, min(args.warmup, 2) if sec == "config3" else args.warmup, False, prog)
         prog.wrap = lambda line: line
         out = nest(o3)
+    if args.workload in ("config2", "config3") and not args.no_stream_item and not args.no_config3 and (args.nu1, args.nu2) == (None, None):  # (--no-config3 = no extra legs at all)
+        # last leg: configs[3] WHOLE (bench_stream): one query against the 7 instances of a 100 KB item's database; rank r holds instances r, r + N, ...
+        prog.update(out)
+        st = bench_stream(args, ctx, prog, steps=3, warmup=1)
+        if ctx.rank == 0:
+            out = dict(out, also=dict(out.get("also", {}), stream_item={k: st[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "item", "answer_sha256")}))
+            out["also"]["stream_item"]["workload"] = st["config"]["workload"]
+            out["also"]["stream_item"]["parallelism"] = st["config"]["parallelism"]
+            out["also"]["stream_item"]["roofline"] = {k: st["roofline"][k] for k in ("kernel", "achieved", "frac", "frac_device_bytes", "avg_launch_ms", "database_bytes_per_s_over_the_item_query")}
+            out["config"] = dict(out["config"], also_stream_item_value=st["value"], also_stream_item_answer_sha256=st["answer_sha256"])
     prog.update(out)
     prog.arm("process group tear-down", 1.0)
     ctx.close()
