@@ -223,6 +223,10 @@ void launch_matmul(const MatmulParams& p, uint32_t batch, hipStream_t s);
 // addend: optional [np][3][2] PK polynomials added to the products (fields may be any u32: lazy sums are fine)
 void launch_fold_mac(const uint64_t* key, const uint64_t* d, uint64_t* out, uint32_t K, uint32_t np, hipStream_t s, uint32_t key_stride = 0,
                      const uint64_t* addend = nullptr, const Lanes& lanes = Lanes{});
+// the reference's two-product fold round Q_neg D_L + Q D_H from the matrices q[3][m2] alone (Q_neg = G2 - Q is derived: poly.hip fold_mac_two_kernel);
+// d: [np][2 halves][m2][2] (the LD_SDIGIT / fold_chain operand layout)
+void launch_fold_mac_two(const uint64_t* q, const uint64_t* d, uint64_t* out, uint32_t m2, uint32_t ell, uint32_t bits, uint32_t np, hipStream_t s,
+                         const Lanes& lanes = Lanes{});
 // out = (a + b) mod m ; out = single * a (src/poly.cpp:138,190)
 void launch_add(const uint64_t* a, const uint64_t* b, uint64_t* out, uint32_t npolys, hipStream_t s);
 void launch_mul_by_const(const uint64_t* single, const uint64_t* a, uint64_t* out, uint32_t npolys, hipStream_t s);

@@ -155,6 +155,58 @@ __global__ __launch_bounds__(kTpb) void fold_mac_kernel(FoldMacParams p) {
                 }
     }
 }
+// The reference's two-product round from the matrices Q alone (the resident server keeps no Q_neg): with Q_neg = G2 - Q slot by slot (src/spiral.cpp:2361-2379)
+//     Q_neg D_L + Q D_H  =  G2 D_L + Q (D_H - D_L),      (G2 D_L)[r][c] = sum_k 2^(bits k) D_L[3 k + r][c]      (G2[r][3 k + r'] = 2^(bits k) iff r' == r)
+// in exact arithmetic mod p and mod b: the same canonical residues as the stored-Q_neg form, for any gadget dimension (no recomposition is assumed: D_L, D_H are
+// whatever digits the round's loader produced).  This is the fallback form -- fold_root's first round, the stage API's fold() without transform-domain words,
+// option fold_pair = 0, gadgets without the pair identity -- so it is written for clarity: one thread per slot, one ciphertext per block row, no k-split.
+// d: the two-product operand layout D[i][(L | H) half][m2 rows][2 columns]; its words may be lazy ([0, 2m)): canonicalised on load.
+__global__ __launch_bounds__(kTpb) void fold_mac_two_kernel(FoldMacParams p, uint32_t ell, uint32_t bits) {
+    const uint32_t z = blockIdx.x * kTpb + threadIdx.x, i = blockIdx.y, m2 = p.K;
+    {
+        const int64_t lane = p.lanes.here();
+        lane_shift(p.key, lane);
+        lane_shift(p.d, lane);
+        lane_shift(p.out, lane);
+    }
+    const uint64_t* dl = p.d + (size_t)i * 2 * m2 * 2 * kN + z;
+    const uint64_t* dh = dl + (size_t)m2 * 2 * kN;
+    const uint64_t* kp = p.key + z;
+    Acc2 acc[3][2];
+    for (uint32_t mm = 0; mm < m2; mm++) {
+        uint64_t kv[3], lv[2], df[2];
+#pragma unroll
+        for (uint32_t r = 0; r < 3; r++) kv[r] = kp[((size_t)r * p.ks + mm) * kN];
+#pragma unroll
+        for (uint32_t c = 0; c < 2; c++) {
+            const uint64_t l = dl[((size_t)mm * 2 + c) * kN], h = dh[((size_t)mm * 2 + c) * kN];
+            const uint32_t lp = csub(lo32(l), kP), lb = csub(hi32(l), kB), hp = csub(lo32(h), kP), hb = csub(hi32(h), kB);
+            lv[c] = pack(lp, lb);
+            df[c] = pack(csub(hp + kP - lp, kP), csub(hb + kB - lb, kB));  // D_H - D_L, canonical
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < 3; r++) {
+            acc[r][0].mac(kv[r], df[0]);
+            acc[r][1].mac(kv[r], df[1]);
+        }
+        const uint32_t k = mm / 3u, r = mm - 3u * k, sh = bits * k;  // row 3 k + r of D_L is digit k of the ciphertext's row r
+        if (sh < 64u) {
+            const uint64_t g2 = pack(mod_p(1ull << sh), mod_b(1ull << sh));
+            acc[r][0].mac(g2, lv[0]);
+            acc[r][1].mac(g2, lv[1]);
+        }
+    }
+    (void)ell;  // (m2 = 3 ell: at most 4 ell <= 112 canonical products per accumulator, far inside the u64 bound)
+#pragma unroll
+    for (uint32_t r = 0; r < 3; r++)
+#pragma unroll
+        for (uint32_t c = 0; c < 2; c++) p.out[((size_t)i * 6 + r * 2 + c) * kN + z] = acc[r][c].reduced();
+}
+void launch_fold_mac_two(const uint64_t* q, const uint64_t* d, uint64_t* out, uint32_t m2, uint32_t ell, uint32_t bits, uint32_t np, hipStream_t s, const Lanes& lanes) {
+    if (np == 0) return;
+    FoldMacParams p{q, d, out, m2, m2, nullptr, lanes};
+    hipLaunchKernelGGL(fold_mac_two_kernel, dim3(kBpp, np, lanes.n), dim3(kTpb), 0, s, p, ell, bits);
+}
 void launch_fold_mac(const uint64_t* key, const uint64_t* d, uint64_t* out, uint32_t K, uint32_t np, hipStream_t s, uint32_t key_stride, const uint64_t* addend,
                      const Lanes& lanes) {
     if (np == 0) return;
@@ -802,8 +854,8 @@ __device__ __forceinline__ void regev_to_gsw_body(const GswParams& p, uint32_t b
     }
     const uint32_t cols = 3 * p.ell;
     uint64_t* g = p.gsw ? p.gsw + (size_t)(p.dims - 1 - d) * 3 * cols * kN + z : nullptr;  // (the resident server keeps the matrices only as the Q half of the fold key)
-    // fold key of the same columns (src/spiral.cpp:2361-2379): key[r][mm] = G2[r][mm] - gsw[r][mm] (= Q_neg; the NTT is
-    // linear and a constant c is c in every slot), key[r][m2 + mm] = gsw[r][mm]; G2[r][3i + c] = 2^(bits*i) iff c == r
+    // (the host-buffer fold seam's key: key[r][mm] = G2[r][mm] - gsw[r][mm] (= Q_neg, src/spiral.cpp:2361-2379; the NTT is linear and a constant c is c in
+    // every slot), key[r][m2 + mm] = gsw[r][mm]; G2[r][3i + c] = 2^(bits*i) iff c == r.  The resident server passes no key: it folds with the matrices alone)
     uint64_t* key = p.key ? p.key + (size_t)(p.dims - 1 - d) * 3 * (2 * cols) * kN + z : nullptr;
     const uint32_t sh = get_bits_per(p.ell) * i;
     const uint32_t g2p = sh < 64 ? mod_p(1ull << sh) : 0u, g2b = sh < 64 ? mod_b(1ull << sh) : 0u;

@@ -48,7 +48,7 @@ struct spiral_gpu_server {
     // fixed order (srv_alloc): servers with equal parameters and shard have equal layouts, which is what run_query_batch relies on
     DevBuf arena;
     DevBuf db, w_left, w_right, w, v, query, cv, ex_raw, ex_g, ex_raw2, ex_g2;  // (the second work set: the odd tree of a split expansion)
-    DevBuf cv_raw, cv_g, key, cts_keep;  // key: [d][3][Q_neg | Q]: the GSW matrices Q (src/spiral.cpp:2324) and G2 - Q (:2361-2379)
+    DevBuf cv_raw, cv_g, key, cts_keep;  // key: [d][3][m2]: the GSW matrices Q (src/spiral.cpp:2324) -- the fold key; Q_neg = G2 - Q (:2361-2379) is never stored (poly.hip fold_mac_two_kernel)
     uint64_t *gs_raw_p = nullptr, *gs_chat_p = nullptr;  // the Regev->GSW halves of cv_raw / cv_g
     DevBuf qs, acc_own, raw, fold_d, fold_c, fold_c2, resp, stage;
     uint64_t* acc = nullptr;
@@ -148,7 +148,7 @@ int srv_alloc(spiral_gpu_server* S, const spiral_gpu_server* db_owner) {
         // launch and one digit-transform launch
         a.carve(S->cv_raw, ((size_t)S->dim0_shard + ngs * 2) * kN);
         a.carve(S->cv_g, ((size_t)S->dim0_shard + ngs * 2) * p.t_conv * kN);
-        a.carve(S->key, (size_t)p.nu2 * 3 * 2 * s.m2 * kN);
+        a.carve(S->key, (size_t)p.nu2 * 3 * s.m2 * kN);
         a.carve(S->qs, (size_t)kN * S->dim0_shard * 6);  // 12 u32 per (z, j)
         a.carve(S->acc_own, (size_t)s.num_per * 6 * kN);
         a.carve(S->raw, (size_t)s.num_per * 6 * kN);
@@ -1253,11 +1253,11 @@ int convert_part(spiral_gpu_server* S, uint32_t what, hipStream_t st, bool mark_
     gp.chat = S->gs_chat_p;
     gp.cv = S->cv.p;
     gp.cv_pos = IndexMap{1, ps, S->pos_rest};
-    gp.gsw = nullptr;  // the GSW matrices are kept once, as the Q half of the fold key [Q_neg | Q] (8 MiB less to write per query at config 2)
+    gp.gsw = S->key.p;  // the GSW matrices ARE the fold key: written once (the reference also keeps Q_neg = G2 - Q, src/spiral.cpp:2361-2379: derived here where a round needs it)
     gp.t_conv = p.t_conv;
     gp.ell = s.ell;
     gp.dims = p.nu2;
-    gp.key = S->key.p;  // fold keys in the same pass
+    gp.key = nullptr;
     gp.lanes = lanes;
     if (what == CONV_BOTH && !mark_split) {  // the two products are independent: one launch
         launch_convert_products(sp, gp, st);
@@ -1453,7 +1453,7 @@ int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t ro
     for (uint32_t d = d0; d < d0 + rounds; d++) {
         np /= 2;
         const uint32_t n_src = 2 * np * 6;
-        const uint64_t* key = S->key.p + (size_t)d * 3 * 2 * s.m2 * kN;
+        const uint64_t* key = S->key.p + (size_t)d * 3 * s.m2 * kN;
         if (src_pk == out_pk) out_pk = out_pk == S->fold_c.p ? S->fold_c2.p : S->fold_c.p;  // the pair form's product reads its source
         const bool from_raw = !src_pk && raw_addend && S->fold_pair && fold_pair_exact(s.ell);  // lifted already, transform-domain words at hand
         if (from_raw || (src_pk && S->fold_chain && S->fold_pair && fold_pair_exact(s.ell))) {
@@ -1481,7 +1481,7 @@ int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t ro
             fp.lazy_out = lazy_ok(3 * s.ell + 1) ? 1 : 0;
             fp.lanes = lanes;
             launch_ntt_forward(S->tb, fp, LD_SDIFF, ST_PK, (n_src / 2) * s.ell, S->stream);
-            launch_fold_mac(key + (size_t)s.m2 * kN, S->fold_d.p, out_pk, s.m2, np, S->stream, 2 * s.m2, low, lanes);
+            launch_fold_mac(key, S->fold_d.p, out_pk, s.m2, np, S->stream, s.m2, low, lanes);
             src_pk = out_pk;
             pre_reduce = false;
             continue;
@@ -1511,7 +1511,7 @@ int run_fold_rounds(spiral_gpu_server* S, uint32_t np0, uint32_t d0, uint32_t ro
             fp.lanes = lanes;
             launch_ntt_forward(S->tb, fp, LD_SDIGIT, ST_PK, n_src * s.ell, S->stream);
         }
-        launch_fold_mac(key, S->fold_d.p, out_pk, 2 * s.m2, np, S->stream, 0, nullptr, lanes);
+        launch_fold_mac_two(key, S->fold_d.p, out_pk, s.m2, s.ell, get_bits_per(s.ell), np, S->stream, lanes);  // the reference's two products, Q_neg derived
         src_pk = out_pk;
         pre_reduce = false;
     }
@@ -2131,8 +2131,7 @@ int spiral_gpu_server_read(spiral_gpu_server* S, int which, uint64_t* out) {
         case SPIRAL_GPU_BUF_CTS:
             if (!S->keep_cts) return fail("keep_cts is off");
             return download_pk_as_ref(S, S->cts_keep.p, identity_map(), out, (size_t)S->dim0_shard * 6);
-        case SPIRAL_GPU_BUF_GSW:  // row (d, r) of the matrices = columns [m2, 2 m2) of row (d, r) of the key
-            return download_pk_as_ref(S, S->key.p, IndexMap{s.m2, 2 * s.m2, s.m2}, out, (size_t)S->p.nu2 * 3 * s.m2);
+        case SPIRAL_GPU_BUF_GSW: return download_pk_as_ref(S, S->key.p, identity_map(), out, (size_t)S->p.nu2 * 3 * s.m2);
         case SPIRAL_GPU_BUF_ACC: return download_pk_as_ref(S, S->acc, identity_map(), out, (size_t)s.num_per * 6);
         case SPIRAL_GPU_BUF_RAW: HIP_OK(hipMemcpy(out, S->raw.p, (size_t)s.num_per * 6 * kPolyBytes, hipMemcpyDeviceToHost)); return 0;
         case SPIRAL_GPU_BUF_FINAL: HIP_OK(hipMemcpy(out, S->raw.p, 6 * kPolyBytes, hipMemcpyDeviceToHost)); return 0;
