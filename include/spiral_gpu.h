@@ -230,7 +230,7 @@ int spiral_gpu_server_set_query(spiral_gpu_server *s, const uint64_t *query);
 
 /* stages, asynchronous on the server stream */
 int spiral_gpu_server_expand(spiral_gpu_server *s);    /* expandImproved + reorderFromStopround      */
-int spiral_gpu_server_convert(spiral_gpu_server *s);   /* scalToMat x dim0, regevToGSW x nu2, Q_neg   */
+int spiral_gpu_server_convert(spiral_gpu_server *s);   /* scalToMat x dim0, regevToGSW x nu2 (Q_neg = G2 - Q is derived where a fold round needs it) */
 int spiral_gpu_server_first_dim(spiral_gpu_server *s); /* multiplyQueryByDatabase on this shard       */
 int spiral_gpu_server_lift(spiral_gpu_server *s, int reduce_first); /* nttInvAndCrtLiftCiphertexts     */
 /* Throughput, beyond the reference (which answers one query at a time): multiplyQueryByDatabase for the queries of n <= 8
