@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256, 8) void ntt_forward_kernel(Tables t, FwdParams
     }
 }
 
-// Two gadget digits of one source polynomial per workgroup (LD_DIGIT / LD_EXPAND / LD_SDIFF, ST_PK): the source is read once for both and
+// Two gadget digits of one source polynomial per workgroup (LD_DIGIT / LD_EXPAND / LD_SDIFF / LD_PDIFF, ST_PK): the source is read once for both and
 // the two forward transforms share every twiddle fetch (ntt_forward_block2).  Job b2 = (source, digit pair kk): digits 2kk and
 // 2kk + 1 (the second absent when the digit count is odd); destinations and results exactly those of ntt_forward_kernel.
 // LD_SDIFF (round 6): the fold's digit-difference transforms, two digits of one polynomial PAIR per workgroup -- the wide rounds of a batch
@@ -372,6 +372,54 @@ __global__ __launch_bounds__(256) void ntt_forward2_kernel(Tables t, FwdParams p
         if (two) {
             pk_pack8(lo1, hi1, v);
             pk_store8(p.dst + (size_t)(d0 + 6u) * kN, tid, v);  // digit k + 1: three rows x two columns further
+        }
+        return;
+    }
+    if constexpr (LOAD == LD_PDIFF) {
+        // SpiralPack's fold in pair form (foldCiphertextsDim1): two unsigned digit differences of one polynomial pair; source s = (trial t, pair i, row)
+        if ((gridDim.x & 7u) == 0) b2 = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+        const uint32_t tdim = p.n_digits, jp = (tdim + 1u) >> 1, s = b2 / jp, kk = b2 - s * jp, k0 = 2u * kk, k1 = k0 + 1u;
+        const bool two = k1 < tdim;
+        const uint32_t ti = s >> 1, row = s & 1u, tr = ti / p.fold_np, i = ti - tr * p.fold_np;
+        const uint64_t* sl = p.src + ((size_t)(tr * 2u * p.fold_np + i) * 2u + row) * kN;
+        const uint64_t* sh_ = p.src + ((size_t)(tr * 2u * p.fold_np + p.fold_np + i) * 2u + row) * kN;
+        uint64_t rl[8], rh[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            rl[r] = sl[ix_a(tid, r)];
+            rh[r] = sh_[ix_a(tid, r)];
+        }
+        const uint64_t mask = (1ull << p.bits) - 1;
+        uint32_t lo0[8], hi0[8], lo1[8], hi1[8];
+        auto diff = [&](uint32_t k, uint32_t* lo, uint32_t* hi) {
+            if (p.bits <= kSmallDigitBits) {
+#pragma unroll
+                for (int r = 0; r < 8; r++)
+                    signed_residues((int32_t)(uint32_t)digit_of(rh[r], k, p.bits, mask) - (int32_t)(uint32_t)digit_of(rl[r], k, p.bits, mask), lo[r], hi[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const uint32_t dh = (uint32_t)digit_of(rh[r], k, p.bits, mask), dl = (uint32_t)digit_of(rl[r], k, p.bits, mask);
+                    const uint32_t dp = dh % kP - dl % kP, db = dh % kB - dl % kB;
+                    lo[r] = min(dp, dp + kP);
+                    hi[r] = min(db, db + kB);
+                }
+            }
+        };
+        diff(k0, lo0, hi0);
+        diff(two ? k1 : k0, lo1, hi1);
+        ntt_forward_block2<false>(lo0, hi0, lo1, hi1, sh[0], sh[1], t.fwd, tid);
+        if (!p.lazy_out) {
+            canonicalize8(lo0, hi0);
+            canonicalize8(lo1, hi1);
+        }
+        const uint32_t d0 = (s >> 1) * (2u * p.n_digits) + 2u * k0 + (s & 1u);  // operand layout D'[t][i][row + 2k]
+        uint64_t v[8];
+        pk_pack8(lo0, hi0, v);
+        pk_store8(p.dst + (size_t)d0 * kN, tid, v);
+        if (two) {
+            pk_pack8(lo1, hi1, v);
+            pk_store8(p.dst + (size_t)(d0 + 2u) * kN, tid, v);
         }
         return;
     }
@@ -666,6 +714,11 @@ void launch_ntt_forward(const DeviceTables& t, const FwdParams& p_in, uint32_t l
     if (fwd2 && store == ST_PK && load == LD_SDIFF && p.n_digits >= 2) {
         const uint32_t nsrc = nblocks / p.n_digits;
         hipLaunchKernelGGL((ntt_forward2_kernel<LD_SDIFF>), dim3(nsrc * ((p.n_digits + 1u) / 2u), 1, p.lanes.n), dim3(256), 0, s, tb, p);
+        return;
+    }
+    if (fwd2 && store == ST_PK && load == LD_PDIFF && p.n_digits >= 2) {
+        const uint32_t nsrc = nblocks / p.n_digits;
+        hipLaunchKernelGGL((ntt_forward2_kernel<LD_PDIFF>), dim3(nsrc * ((p.n_digits + 1u) / 2u), 1, p.lanes.n), dim3(256), 0, s, tb, p);
         return;
     }
     if (fwd2 && store == ST_PK && load == LD_EXPAND) {

@@ -73,11 +73,13 @@ def test_pack_seam_largest_sums(sa, oracle):
         (3, 2, 12, dict(t_gsw=3, t_conv=56, t_exp=56, qprime_bits=31, p_db=524288, direct_upload=1)),  # n = 12: the "movie" set's shape of parameters
     ],
 )
-@pytest.mark.parametrize("fold_pair", [1, 0])  # 1: the pair form of foldCiphertextsDim1 (LD_PDIFF); 0: the reference's two products
+@pytest.mark.parametrize("fold_pair", [1, 0, 2])  # 1: the pair form of foldCiphertextsDim1 (LD_PDIFF); 0: the reference's two products;
+                                                   # 2: the pair form with every digit launch through the two-digits-per-workgroup kernel (option fwd2 = 1; by default only from 8192 transforms)
 def test_pack_server_matches_oracle(sa, oracle, nu1, nu2, out_n, kw, fold_pair, request):
     O = oracle
-    request.addfinalizer(lambda old=sa.get_option("fold_pair"): sa.set_option("fold_pair", old))
-    sa.set_option("fold_pair", fold_pair)
+    request.addfinalizer(lambda old=(sa.get_option("fold_pair"), sa.get_option("fwd2")): (sa.set_option("fold_pair", old[0]), sa.set_option("fwd2", old[1])))
+    sa.set_option("fold_pair", 1 if fold_pair else 0)
+    sa.set_option("fwd2", 1 if fold_pair == 2 else -1)
     po, pg = O.make_params(nu1, nu2, **kw), sa.make_params(nu1, nu2, **kw)
     s = O.pack_shape_of(po, out_n)
     g = sa.get_pack_shape(pg, out_n)
