@@ -131,7 +131,7 @@ int spiral_gpu_response_from_wire(const spiral_gpu_params *p, uint32_t out_n, co
  * [num_per][n1][n2][2][N]. */
 int spiral_gpu_multiply_query_by_database(uint64_t *output, const uint64_t *reorientedCiphertexts,
                                           const uint64_t *database, size_t dim0, size_t num_per);
-/* The same for n <= 16 queries against ONE pass over the database per eight queries (no reference counterpart: the reference answers one query per
+/* The same for n <= 8 queries against ONE pass over the database (no reference counterpart: the reference answers one query per
  * call): reorientedCts = the n queries' buffers one after the other, outputs = [n][num_per][n1][n2][2][N].  Where the geometry allows
  * (num_per >= 64, dim0 a multiple of 64, <= 2048) the pass runs on the matrix cores (csrc/sweep_mfma.hip), else as passes of two /
  * one on the vector ALU; every output equals multiply_query_by_database's for that query. */
@@ -233,8 +233,8 @@ int spiral_gpu_server_expand(spiral_gpu_server *s);    /* expandImproved + reord
 int spiral_gpu_server_convert(spiral_gpu_server *s);   /* scalToMat x dim0, regevToGSW x nu2 (Q_neg = G2 - Q is derived where a fold round needs it) */
 int spiral_gpu_server_first_dim(spiral_gpu_server *s); /* multiplyQueryByDatabase on this shard       */
 int spiral_gpu_server_lift(spiral_gpu_server *s, int reduce_first); /* nttInvAndCrtLiftCiphertexts     */
-/* Throughput, beyond the reference (which answers one query at a time): multiplyQueryByDatabase for the queries of n <= 16
- * servers that share one database image (an owner and its lanes, create_lane) in ONE pass over the database per eight queries -- server b's
+/* Throughput, beyond the reference (which answers one query at a time): multiplyQueryByDatabase for the queries of n <= 8
+ * servers that share one database image (an owner and its lanes, create_lane) in ONE pass over the database -- server b's
  * converted query against the image into server b's accumulators, each bit-identical to its own first_dim().  The pass runs on
  * the matrix cores (csrc/sweep_mfma.hip: both operands as signed 8-bit limbs, v_mfma_i32_16x16x64_i8, exact recombination mod
  * the primes): at config 2 two to five queries take the time of one (0.30 ms), eight take 0.39 ms.  It reads the database as "limb
@@ -252,10 +252,10 @@ int spiral_gpu_server_lift(spiral_gpu_server *s, int reduce_first); /* nttInvAnd
  * costs none): call it OUTSIDE stream capture (none of the lanes' streams may be capturing a hipGraph; run_pre / run_post capture
  * and replay their own groups either side of it). */
 int spiral_gpu_server_first_dim_batch(spiral_gpu_server *const *servers, uint32_t n);
-/* The same idea for the WHOLE answer: n <= 16 queries -- one per server, an owner and its lanes (create_lane), equal parameters, each with its
+/* The same idea for the WHOLE answer: n <= 8 queries -- one per server, an owner and its lanes (create_lane), equal parameters, each with its
  * own client's public parameters and query -- as one launch sequence in which every launch carries all n queries: the expansion, conversion,
  * lift, folding and switch kernels take a query dimension (the reference runs them once per query, src/spiral.cpp:1664-1743, 1850-2025,
- * 1349-1410, inside process_crtd_query :2337-2406) and the sweep is first_dim_batch's: one pass over the database per eight queries on the matrix
+ * 1349-1410, inside process_crtd_query :2337-2406) and the sweep is first_dim_batch's: one pass over the database for all n on the matrix
  * cores.  A query's ~50 dependent launches outside the sweep are
  * launch-bound (~5 us each whatever they carry), so n queries cost little more than one there.  Throughput only: each query's latency is the
  * batch's.  Afterwards every server's buffers (accumulators, GSW matrices, final ciphertext, response) hold exactly what its own run_query

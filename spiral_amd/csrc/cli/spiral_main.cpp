@@ -155,7 +155,7 @@ int main(int argc, char** argv) {
         if (!strcmp(argv[i], "--show-diff")) { cout << "Showing diff..." << endl; show_diff = true; }
         if (!strcmp(argv[i], "--direct-upload")) { cout << "Direct uploading of query (no compression)" << endl; direct_flag = true; }
         if (!strcmp(argv[i], "--seed") && i + 1 < argc) seed = strtoull(argv[++i], nullptr, 10);
-        // --batch B (2 .. 16; not a flag of the reference, which answers one query per process): after the reference's own single-query run, B clients --
+        // --batch B (2 .. 8; not a flag of the reference, which answers one query per process): after the reference's own single-query run, B clients --
         // own keys, own indices -- are answered by ONE call of spiral_gpu_server_run_query_batch and each is decoded and checked
         if (!strcmp(argv[i], "--batch") && i + 1 < argc) batch = (uint32_t)strtoul(argv[++i], nullptr, 10);
         // --instances F (2 .. 16; not a flag of the reference either: select_params.py:297-298 runs ONE instance and multiplies by factor = ceil(item size /
@@ -260,7 +260,7 @@ int main(int argc, char** argv) {
     // ---- --batch B: the same server, B queries of B clients in one launch sequence (include/spiral_gpu.h, spiral_gpu_server_run_query_batch)
     double batch_us = 0;
     bool batch_corr = true;
-    if (batch >= 2 && batch <= 16) {
+    if (batch >= 2 && batch <= 8) {
         std::vector<spiral_gpu_server*> lanes{srv};
         std::vector<Client> clients;
         std::vector<uint64_t> idxs;
@@ -304,7 +304,7 @@ int main(int argc, char** argv) {
         GPU_OK(spiral_gpu_server_use_graphs(srv, 0));
         for (uint32_t b = 1; b < batch; b++) spiral_gpu_server_destroy(lanes[b]);
     } else if (batch) {
-        fprintf(stderr, "spiral: --batch takes 2 .. 16\n");
+        fprintf(stderr, "spiral: --batch takes 2 .. 8\n");
         return 1;
     }
 

@@ -37,11 +37,10 @@ Options& options();  // server.cpp; the three documented environment variables a
 // keys, ciphertexts and scratch.  Every per-query buffer of a server lives in one arena with the same internal layout (srv_alloc), so lane q's
 // buffer is lane 0's pointer + off[q] words: a kernel shifts every non-table pointer of its parameters by off[blockIdx.z] and is otherwise
 // unchanged (n = 1, off = 0: the single-query launch).  The reference answers one query per process_crtd_query (src/spiral.cpp:2337-2406).
-constexpr uint32_t kMaxLanes = 16;   // queries per launch sequence (run_query_batch)
-constexpr uint32_t kSweepLanes = 8;  // queries one pass of the matrix-core sweep takes (sweep_mfma.hip: 12 operand columns per query, six 16-column tiles); more lanes = more passes
+constexpr uint32_t kMaxLanes = 8;  // (= the queries one pass of the matrix-core sweep takes, sweep_mfma.hip)
 struct Lanes {
     uint32_t n = 1;
-    int64_t off[kMaxLanes] = {};  // u64 words from lane 0's arena to lane q's
+    int64_t off[kMaxLanes] = {0, 0, 0, 0, 0, 0, 0, 0};  // u64 words from lane 0's arena to lane q's
 #ifdef __HIPCC__
     // (a select chain on constant indices: indexing the by-value kernel argument with blockIdx.z would make the compiler keep the whole
     // parameter struct in scratch memory -- 232 bytes per lane and transforms twice as slow, measured)
@@ -309,7 +308,7 @@ constexpr uint32_t kSweepMaxBatch = 2;
 bool sweep_batch_ok(uint32_t num_per, uint32_t jm_total);
 void launch_sweep_batch(const uint64_t* db, const uint32_t* const* qs, uint64_t* const* acc, uint32_t n, uint32_t num_per, uint32_t jm_total, uint32_t g_log,
                         hipStream_t s);
-// the same on the matrix cores for n = 1 .. kSweepLanes queries per pass (sweep_mfma.hip): needs the "limb plane" image of the database, built
+// the same on the matrix cores for n = 1 .. kMaxLanes queries per pass (sweep_mfma.hip): needs the "limb plane" image of the database, built
 // from the packed one by launch_db_limb_planes (as many words); where sweep_mfma_ok (>= 64 ciphertexts per slot, first dimension a power of two in
 // [64, 2048]).  Returns the launch's error (the > 64 KiB LDS opt-in is per device).  k_log: the accumulators' stage layout, as launch_sweep
 bool sweep_mfma_ok(uint32_t num_per, uint32_t jm_total);

@@ -285,11 +285,8 @@ int sweep_queries(const spiral_gpu_server* S, const uint64_t* limbs, const uint3
     const spiral_gpu_server* H = holder_of(S);
     if (!limbs && H->db_format == SPIRAL_GPU_DB_LIMBS) limbs = H->db.p;  // the one image is in limb-plane form: every sweep is the matrix-core one
     if (limbs) {
-        for (uint32_t b0 = 0; b0 < n; b0 += kSweepLanes) {  // passes of up to eight queries (one pass for a batch of eight or fewer)
-            const hipError_t e = launch_sweep_mfma(limbs, qs + b0, acc + b0, std::min(kSweepLanes, n - b0), np, jm, g_log, st, k_log);
-            if (e != hipSuccess) return fail("the matrix-core sweep could not be launched: %s", hipGetErrorString(e));
-        }
-        return 0;
+        const hipError_t e = launch_sweep_mfma(limbs, qs, acc, n, np, jm, g_log, st, k_log);
+        return e == hipSuccess ? 0 : fail("the matrix-core sweep could not be launched: %s", hipGetErrorString(e));
     }
     const uint32_t step = sweep_batch_ok(np, jm) ? kSweepMaxBatch : 1;
     for (uint32_t b0 = 0; b0 < n; b0 += step) {
@@ -706,10 +703,8 @@ int spiral_gpu_multiply_queries_by_database(uint64_t* outputs, const uint64_t* r
         launch_qs_from_reoriented(d_re + b * (size_t)kN * dim0 * 8, (uint32_t*)qs[b], (uint32_t)(2 * dim0), 0);
     }
     if (mfma) {
-        for (size_t b0 = 0; b0 < n; b0 += kSweepLanes) {
-            const hipError_t e = launch_sweep_mfma(d_limbs, qs + b0, acc + b0, (uint32_t)std::min<size_t>(kSweepLanes, n - b0), (uint32_t)num_per, (uint32_t)(2 * dim0), 0, 0);
-            if (e != hipSuccess) return fail("the matrix-core sweep could not be launched: %s", hipGetErrorString(e));
-        }
+        const hipError_t e = launch_sweep_mfma(d_limbs, qs, acc, (uint32_t)n, (uint32_t)num_per, (uint32_t)(2 * dim0), 0, 0);
+        if (e != hipSuccess) return fail("the matrix-core sweep could not be launched: %s", hipGetErrorString(e));
     } else
         for (size_t b0 = 0; b0 < n; b0 += 2) {
             if (n - b0 >= 2 && sweep_batch_ok((uint32_t)num_per, (uint32_t)(2 * dim0)))

@@ -157,15 +157,15 @@ __global__ __launch_bounds__(256) void db_limb_unplanes_kernel(const uint4* __re
 }
 
 struct SweepLanes {
-    const uint32_t* qs[kSweepLanes];
-    uint64_t* acc[kSweepLanes];
+    const uint32_t* qs[kMaxLanes];
+    uint64_t* acc[kMaxLanes];
 };
 
 template <typename T>
-__device__ __forceinline__ T pick_lane(const T (&a)[kSweepLanes], uint32_t q) {  // (a dynamic index would put the argument struct in scratch)
+__device__ __forceinline__ T pick_lane(const T (&a)[kMaxLanes], uint32_t q) {  // (a dynamic index would put the argument struct in scratch)
     T p = a[0];
 #pragma unroll
-    for (uint32_t i = 1; i < kSweepLanes; i++) p = q == i ? a[i] : p;
+    for (uint32_t i = 1; i < kMaxLanes; i++) p = q == i ? a[i] : p;
     return p;
 }
 
@@ -427,12 +427,11 @@ void launch_db_limb_unplanes(const uint64_t* db_limbs, uint64_t* db_packed_img, 
 hipError_t launch_sweep_mfma(const uint64_t* db_limbs, const uint32_t* const* qs, uint64_t* const* acc, uint32_t n, uint32_t num_per, uint32_t jm_total, uint32_t g_log,
                              hipStream_t s, uint32_t k_log) {
     const uint32_t nic = 2 * num_per, dim0 = jm_total / 2;
-    if (n == 0 || n > kSweepLanes) return hipErrorInvalidValue;
     uint32_t ls_log = 0;
     while ((1u << ls_log) < num_per) ls_log++;
     ls_log -= g_log + k_log;
     SweepLanes bt{};
-    for (uint32_t b = 0; b < kSweepLanes; b++) {
+    for (uint32_t b = 0; b < kMaxLanes; b++) {
         bt.qs[b] = qs[b < n ? b : 0];
         bt.acc[b] = acc[b < n ? b : 0];
     }

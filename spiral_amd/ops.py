@@ -182,7 +182,7 @@ def multiplyQueryByDatabase(reoriented_cts, database, dim0, num_per) -> np.ndarr
 
 
 def multiplyQueriesByDatabase(reoriented_cts_list, database, dim0, num_per) -> np.ndarray:
-    """n <= 16 queries against one pass over the database per eight (the matrix-core sweep where the geometry allows): [n][num_per][3][2][2][N]"""
+    """n <= 8 queries against one pass over the database (the matrix-core sweep where the geometry allows): [n][num_per][3][2][2][N]"""
     n = len(reoriented_cts_list)
     re = np.ascontiguousarray(np.stack([_c(r).reshape(-1) for r in reoriented_cts_list]))
     out = np.zeros((n, num_per, 3, 2, 2, N), dtype=np.uint64)

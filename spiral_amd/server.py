@@ -21,7 +21,7 @@ def _p(a: np.ndarray):
 
 
 def first_dim_batch(servers):
-    """one pass over the database for the (converted) queries of up to sixteen servers sharing one image (eight per pass); see include/spiral_gpu.h"""
+    """one pass over the database for the (converted) queries of up to eight servers sharing one image; see include/spiral_gpu.h"""
     arr = (C.c_void_p * len(servers))(*[s.h for s in servers])
     check(lib().spiral_gpu_server_first_dim_batch(arr, len(servers)))
 
@@ -35,7 +35,7 @@ def time_sweep_batch(servers, iters: int = 20) -> float:
 
 
 def run_query_batch(servers):
-    """the whole answer for the queries of up to sixteen servers sharing one image, every launch carrying all of them; see include/spiral_gpu.h"""
+    """the whole answer for the queries of up to eight servers sharing one image, every launch carrying all of them; see include/spiral_gpu.h"""
     arr = (C.c_void_p * len(servers))(*[s.h for s in servers])
     check(lib().spiral_gpu_server_run_query_batch(arr, len(servers)))
 

@@ -45,7 +45,6 @@ def test_cli_refuses_to_run_without_gpu_or_args():
     (["5", "6", "1234", "a", "--seed", "11", "--batch", "4"], {}),  # + four clients answered by one spiral_gpu_server_run_query_batch call (C++ consumer of the batch entry point)
     (["4", "2", "3", "a", "--direct-upload", "--seed", "12", "--batch", "3"], {"TEXP": "2", "TGSW": "5", "QPBITS": "19"}),
     (["5", "6", "99", "a", "--seed", "13", "--batch", "7"], {}),
-    (["6", "6", "99", "a", "--seed", "15", "--batch", "12"], {}),  # more than eight clients per launch sequence: the sweep in passes of eight
     # an item of three plaintexts = three database instances, one query (the SpiralStream form and with query compression): C++ consumer of answer_instances
     (["5", "2", "7", "a", "--direct-upload", "--seed", "5", "--instances", "3"], {"TEXP": "2", "TGSW": "5", "QPBITS": "19"}),
     (["4", "3", "40", "a", "--seed", "14", "--instances", "4"], {}),

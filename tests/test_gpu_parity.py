@@ -135,7 +135,7 @@ def test_multiply_query_by_database(sa, oracle, nu1, nu2):
 # one workgroup column group; (7,6): two pieces; (6,7): two column groups per z; n = 1 .. 8 queries = 1 .. 6 column tiles, the last one part
 # empty for n = 3, 5, 6, 7.  (5,6) and (6,5) fall back to the vector ALU (first dimension / columns too small) through the same entry point.
 @pytest.mark.parametrize("nu1,nu2,n", [(6, 6, 1), (6, 6, 2), (6, 6, 3), (6, 6, 4), (6, 6, 5), (6, 6, 6), (6, 6, 7), (6, 6, 8), (7, 6, 4), (6, 7, 8), (8, 6, 5),
-                                       (5, 6, 3), (6, 5, 4), (6, 6, 13), (6, 5, 9)])  # (more than eight queries: passes of eight on the matrix cores, of two on the vector ALU)
+                                       (5, 6, 3), (6, 5, 4)])
 def test_multiply_queries_by_database(sa, oracle, nu1, nu2, n):
     """n queries against one pass over the database == the oracle's multiplyQueryByDatabase (src/spiral.cpp:628-999) of every query"""
     O = oracle
@@ -1021,8 +1021,6 @@ def test_batch_without_the_matrix_core_image_and_after_a_reload(sa, oracle, opts
     (3, 6, 8, dict(t_gsw=8), True), (5, 6, 5, dict(t_gsw=8), True), (4, 5, 7, dict(t_gsw=8), False),  # more than two lanes: the vector-ALU sweep in passes of two
     (6, 6, 3, dict(t_gsw=8), True), (6, 6, 8, dict(t_gsw=8), True), (7, 6, 5, dict(t_gsw=8), False),  # the sweep on the matrix cores, one pass for all lanes
     (5, 3, 6, dict(t_gsw=4), True),                                                       # six lanes on the per-lane sweep fallback
-    (6, 6, 12, dict(t_gsw=8), True), (6, 6, 16, dict(t_gsw=8), True), (6, 7, 9, dict(t_gsw=8), False),  # more than eight lanes: the matrix-core sweep in passes of eight (8 + 4, 8 + 8, 8 + 1)
-    (4, 5, 11, dict(t_gsw=8), True), (2, 2, 16, dict(t_gsw=5, t_exp=2, qprime_bits=19, direct_upload=1), True),  # and on the vector-ALU / per-lane fallbacks
 ])
 def test_run_query_batch_equals_single_queries(sa, oracle, nu1, nu2, n, kw, graphs):
     """run_query_batch: n whole queries (different clients: own keys, own query) in one launch sequence whose every launch carries all of them
