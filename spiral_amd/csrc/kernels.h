@@ -37,10 +37,13 @@ Options& options();  // server.cpp; the three documented environment variables a
 // keys, ciphertexts and scratch.  Every per-query buffer of a server lives in one arena with the same internal layout (srv_alloc), so lane q's
 // buffer is lane 0's pointer + off[q] words: a kernel shifts every non-table pointer of its parameters by off[blockIdx.z] and is otherwise
 // unchanged (n = 1, off = 0: the single-query launch).  The reference answers one query per process_crtd_query (src/spiral.cpp:2337-2406).
-constexpr uint32_t kMaxLanes = 8;  // (= the queries one pass of the matrix-core sweep takes, sweep_mfma.hip)
+#ifndef SPIRAL_MAX_LANES
+#define SPIRAL_MAX_LANES 8
+#endif
+constexpr uint32_t kMaxLanes = SPIRAL_MAX_LANES;  // (= the queries one pass of the matrix-core sweep takes, sweep_mfma.hip)
 struct Lanes {
     uint32_t n = 1;
-    int64_t off[kMaxLanes] = {0, 0, 0, 0, 0, 0, 0, 0};  // u64 words from lane 0's arena to lane q's
+    int64_t off[kMaxLanes] = {};  // u64 words from lane 0's arena to lane q's
 #ifdef __HIPCC__
     // (a select chain on constant indices: indexing the by-value kernel argument with blockIdx.z would make the compiler keep the whole
     // parameter struct in scratch memory -- 232 bytes per lane and transforms twice as slow, measured)
@@ -59,6 +62,23 @@ __device__ __forceinline__ void lane_shift(T*& p, int64_t words) {  // optional 
     if (p) p = reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + (intptr_t)words * 8);
 }
 #endif
+// ONE query's launches carry no lane machinery at all.  A query is ~50 dependent launch-bound launches, and each pays for every byte of its kernel
+// arguments and every instruction of its prologue: with the eight offsets (72 bytes + a select chain) in every launch one query took 748 us, without
+// them 725 (round 6, same box, alternating builds).  So every kernel that takes lanes is instantiated twice -- `Lanes` for batches, `NoLanes` (no
+// offsets, here() == 0, the shifts fold away) for n == 1 -- and every parameter struct is `XCore` (the fields) + `XT<L>` (the fields and an L); the
+// host fills an `X = XT<Lanes>` as before and the launcher picks the instantiation (no_lanes() copies the fields).
+struct NoLanes {
+    uint32_t n = 1;
+#ifdef __HIPCC__
+    __device__ __forceinline__ int64_t here() const { return 0; }
+#endif
+};
+template <class P>
+inline typename P::NoLanesT no_lanes(const P& p) {
+    typename P::NoLanesT q{};
+    static_cast<typename P::Core&>(q) = static_cast<const typename P::Core&>(p);
+    return q;
+}
 
 struct DeviceTables {
     uint4* fwd = nullptr;      // [2048] forward twiddles {W_p, W'_p, W_b, W'_b}
@@ -106,7 +126,7 @@ enum PackMap : uint32_t {
     PM_FOLD = 1,  // s = (trial, ct i' < 2np', row); dst = D[trial][i' % np'][(i' / np') * 2ell + row + 2k]
     PM_PACK = 2,  // s = trial; source = row 0 of the trial's folded ct; dst = ginv[trial][k]   (pack)
 };
-struct FwdParams {
+struct FwdParamsCore {
     const uint64_t* src;
     uint64_t* dst;
     IndexMap src_map;   // s -> source polynomial index
@@ -137,8 +157,14 @@ struct FwdParams {
     uint64_t seed, p_db;
     uint64_t item_base;                 // first item handled by this launch
     uint32_t num_per, dim0_shard, j0;   // DB geometry of this shard
-    Lanes lanes;                        // src, dst per query lane
 };
+template <class L>
+struct FwdParamsT : FwdParamsCore {
+    using Core = FwdParamsCore;
+    using NoLanesT = FwdParamsT<NoLanes>;
+    L lanes;                        // src, dst per query lane
+};
+using FwdParams = FwdParamsT<Lanes>;
 void launch_ntt_forward(const DeviceTables& t, const FwdParams& p, uint32_t load, uint32_t store, uint32_t nblocks, hipStream_t s);
 
 // Which ciphertexts of an expansion round a launch works on (src/spiral.cpp:1700-1702 enumerates i < 2^(r+1), odd i only up to
@@ -158,7 +184,7 @@ enum InvStore : uint32_t {
     IST_CRT = 0,    // CRT-lifted raw coefficient in [0, Q)   (from_ntt, src/poly.cpp:357)
     IST_LIMBS = 1,  // reference layout [2][N] u64 residues   (ntt_inverse)
 };
-struct InvParams {
+struct InvParamsCore {
     const uint64_t* src;
     uint64_t* dst;
     IndexMap src_map, dst_map;
@@ -177,14 +203,20 @@ struct InvParams {
     uint32_t auto_t;  // the round's automorphism x -> x^t
     uint32_t create_here;  // 1: cts with i >= num_in do not exist yet (round 0); 0: the previous round's MAC wrote them
     const uint64_t* query;  // create_here only, optional: cv[0] is read from here (and written to cv) instead of from cv
-    Lanes lanes;            // src, dst, cv, query per query lane (neg1 / neg1s are shared tables)
 };
+template <class L>
+struct InvParamsT : InvParamsCore {
+    using Core = InvParamsCore;
+    using NoLanesT = InvParamsT<NoLanes>;
+    L lanes;            // src, dst, cv, query per query lane (neg1 / neg1s are shared tables)
+};
+using InvParams = InvParamsT<Lanes>;
 void launch_ntt_inverse(const DeviceTables& t, const InvParams& p, uint32_t store, uint32_t nblocks, hipStream_t s);
 void launch_ntt_inverse_expand(const DeviceTables& t, const InvParams& p, uint32_t nblocks, hipStream_t s);
 
 // fold chain (ntt.hip): PK polynomials [2*np][3][2] -> inverse transform, CRT lift, balanced digits, forward transforms
 // into the fold operand layout D (as LD_SDIGIT); a workgroup handles one polynomial and dpb consecutive digits
-struct FoldChainParams {
+struct FoldChainParamsCore {
     const uint64_t* src;
     uint64_t* dst;
     uint32_t ell, bits, fold_np;
@@ -194,8 +226,14 @@ struct FoldChainParams {
     // SpiralPack fold (foldCiphertextsDim1): sources are [trial][2*np][2] 2 x 1 ciphertexts with a trial stride of src_stride
     // ciphertexts, unsigned digits, operand layout as LD_PDIGIT / PM_FOLD
     uint32_t pack, src_stride;
-    Lanes lanes;
 };
+template <class L>
+struct FoldChainParamsT : FoldChainParamsCore {
+    using Core = FoldChainParamsCore;
+    using NoLanesT = FoldChainParamsT<NoLanes>;
+    L lanes;
+};
+using FoldChainParams = FoldChainParamsT<Lanes>;
 void launch_fold_chain(const DeviceTables& t, const FoldChainParams& p, uint32_t n_src, hipStream_t s);
 
 // The fold round in pair form (ntt.hip LD_SDIFF + launch_fold_mac with an addend): out[i] = C[i] + Q * NTT(G^-1(C[np + i]) - G^-1(C[i])).
@@ -244,7 +282,7 @@ void launch_rescale2(const uint64_t* in, uint64_t* out, uint32_t n0, uint32_t n,
 // ---- expansion / conversion / fold specials ----------------------------------------------------------
 // the same for a whole round in one launch: active ct a < cnt_e even (W_left, t_e digits) else odd (W_right, t_o);
 // g holds t digit polynomials per ct in LD_EXPAND job order; a1[2a + 1] is NTT(automorph(c_1)) of active ct a
-struct ExpandMacParams {
+struct ExpandMacParamsCore {
     uint64_t* cv;
     const uint64_t* w_e;
     const uint64_t* w_o;
@@ -258,12 +296,18 @@ struct ExpandMacParams {
     const uint64_t* neg1n;
     const uint64_t* neg1ns;  // Shoup companions
     uint32_t next_num_in, next_cnt_o;
-    Lanes lanes;  // cv, w_e, w_o, g, a1 per query lane (neg1n / neg1ns are shared tables)
 };
+template <class L>
+struct ExpandMacParamsT : ExpandMacParamsCore {
+    using Core = ExpandMacParamsCore;
+    using NoLanesT = ExpandMacParamsT<NoLanes>;
+    L lanes;  // cv, w_e, w_o, g, a1 per query lane (neg1n / neg1ns are shared tables)
+};
+using ExpandMacParams = ExpandMacParamsT<Lanes>;
 void launch_expand_mac_round(const ExpandMacParams& p, hipStream_t s);
 // scalToMat product: out[a][r][c] = sum_k W[r][2k+c] * G[a][k] + pad(cv[pos(a)][1])   (src/spiral.cpp:1850-1885)
 // qs != null: also (or instead, out may be null) write the sweep's query records (see sweep)
-struct Scal2MatParams {
+struct Scal2MatParamsCore {
     const uint64_t* w;    // [3][2*t_conv] PK
     const uint64_t* g;    // [count][t_conv] PK digits of cv row 0
     const uint64_t* cv;   // expanded cts
@@ -271,11 +315,17 @@ struct Scal2MatParams {
     uint64_t* out;        // [count][3][2] PK or null
     uint32_t* qs;         // sweep query records [N][jm_total/2][12] u32 or null
     uint32_t t_conv, count, jm_total, j_base;
-    Lanes lanes;  // every pointer per query lane
 };
+template <class L>
+struct Scal2MatParamsT : Scal2MatParamsCore {
+    using Core = Scal2MatParamsCore;
+    using NoLanesT = Scal2MatParamsT<NoLanes>;
+    L lanes;  // every pointer per query lane
+};
+using Scal2MatParams = Scal2MatParamsT<Lanes>;
 void launch_scal2mat(const Scal2MatParams& p, hipStream_t s);
 // regevToGSW assembly for one dimension: gsw[r][3i] = sum_k V[r][k] * chat[i][k], gsw[r][3i+1+c] = scalToMat(cv_i)[r][c]
-struct GswParams {
+struct GswParamsCore {
     const uint64_t* w;     // [3][2*t_conv]
     const uint64_t* v;     // [3][2*t_conv]
     const uint64_t* chat;  // [dims*ell][2*t_conv] PK digits (cv row 0 digits, then row 1 digits)
@@ -284,8 +334,14 @@ struct GswParams {
     uint64_t* gsw;         // optional: [dims][3][3*ell] PK, dimension d stored at index (dims-1-d)  (src/spiral.cpp:2324)
     uint64_t* key;         // optional: the fold key of the same matrices, written in the same pass: key[d][r][0..m2) = G2 - gsw (= Q_neg, src/spiral.cpp:2361-2379), key[d][r][m2..2*m2) = gsw
     uint32_t t_conv, ell, dims;
-    Lanes lanes;  // every pointer per query lane
 };
+template <class L>
+struct GswParamsT : GswParamsCore {
+    using Core = GswParamsCore;
+    using NoLanesT = GswParamsT<NoLanes>;
+    L lanes;  // every pointer per query lane
+};
+using GswParams = GswParamsT<Lanes>;
 void launch_regev_to_gsw(const GswParams& p, hipStream_t s);
 // both conversion products in one launch when the record-writing ScalToMat applies (else the two launches)
 void launch_convert_products(const Scal2MatParams& sp, const GswParams& gp, hipStream_t s);

@@ -26,8 +26,8 @@ __device__ __forceinline__ void pk_load8_red(const uint64_t* poly, bool reduce, 
     }
 }
 
-template <uint32_t LOAD, uint32_t STORE>
-__global__ __launch_bounds__(256, 8) void ntt_forward_kernel(Tables t, FwdParams p) {
+template <uint32_t LOAD, uint32_t STORE, class L>  // L: Lanes (a batch: gridDim.z lanes) or NoLanes (one query: no lane arguments at all, kernels.h)
+__global__ __launch_bounds__(256, 8) void ntt_forward_kernel(Tables t, FwdParamsT<L> p) {
     __shared__ uint64_t sh[kLdsWords];
     const uint32_t tid = threadIdx.x;
     uint32_t b = blockIdx.x;
@@ -333,8 +333,8 @@ __global__ __launch_bounds__(256, 8) void ntt_forward_kernel(Tables t, FwdParams
 // 2kk + 1 (the second absent when the digit count is odd); destinations and results exactly those of ntt_forward_kernel.
 // LD_SDIFF (round 6): the fold's digit-difference transforms, two digits of one polynomial PAIR per workgroup -- the wide rounds of a batch
 // are thousands of such transforms per launch, where the shared twiddle fetch is worth what it is for the expansion's digits.
-template <uint32_t LOAD>
-__global__ __launch_bounds__(256) void ntt_forward2_kernel(Tables t, FwdParams p) {
+template <uint32_t LOAD, class L>
+__global__ __launch_bounds__(256) void ntt_forward2_kernel(Tables t, FwdParamsT<L> p) {
     __shared__ uint64_t sh[2][kLdsWords];
     const uint32_t tid = threadIdx.x;
     uint32_t b2 = blockIdx.x;
@@ -486,8 +486,8 @@ __global__ __launch_bounds__(256) void ntt_forward2_kernel(Tables t, FwdParams p
 }
 
 // (8 workgroups per CU: the second launch bound keeps the kernel at 64 VGPRs, where the compiler's own choice was 65)
-template <uint32_t STORE, bool EXPAND = false>
-__global__ __launch_bounds__(256, 8) void ntt_inverse_kernel(Tables t, InvParams p) {
+template <uint32_t STORE, bool EXPAND, class L>
+__global__ __launch_bounds__(256, 8) void ntt_inverse_kernel(Tables t, InvParamsT<L> p) {
     __shared__ uint64_t sh[kLdsWords];
     const uint32_t tid = threadIdx.x, b = blockIdx.x;
     {
@@ -616,7 +616,8 @@ __global__ __launch_bounds__(256, 8) void ntt_inverse_kernel(Tables t, InvParams
 // (register budget: 103 VGPRs = 4 workgroups per CU.  Forcing 5 or 6 through the launch bound spills 24 / 84 bytes per thread and
 // measured 0 / +30 us on the fold, profiles/r03_variants.txt; holding one twiddle row set instead of two does not lower the count.
 // Since round 4 this two-product form is the fallback of the pair form (LD_SDIFF): SPIRAL_FOLD_PAIR=0, gadget dimensions whose digits do not recompose.)
-__global__ __launch_bounds__(256) void fold_chain_kernel(Tables t, FoldChainParams p) {
+template <class L>
+__global__ __launch_bounds__(256) void fold_chain_kernel(Tables t, FoldChainParamsT<L> p) {
     __shared__ uint64_t sh[kLdsWords];
     const uint32_t tid = threadIdx.x, b = blockIdx.x;
     {
@@ -682,10 +683,18 @@ __global__ __launch_bounds__(256) void pk_to_ref_kernel(const uint64_t* pk, uint
     ref[poly * (2 * kN) + kN + z] = hi32(v);
 }
 
-#define FWD_CASE(L, S)                                                                                  \
-    if (load == L && store == S) {                                                                      \
-        hipLaunchKernelGGL((ntt_forward_kernel<L, S>), dim3(nblocks, 1, p.lanes.n), dim3(256), 0, s, tb, p);          \
-        return;                                                                                         \
+// one query: the instantiation without lane arguments (kernels.h NoLanes); a batch: gridDim.z = the lanes
+#define LAUNCH_LANES(KERNEL, GRIDX, TB, P, ...)                                                                                          \
+    do {                                                                                                                                 \
+        if ((P).lanes.n > 1)                                                                                                             \
+            hipLaunchKernelGGL((KERNEL<__VA_ARGS__, Lanes>), dim3((GRIDX), 1, (P).lanes.n), dim3(256), 0, s, TB, P);                     \
+        else                                                                                                                             \
+            hipLaunchKernelGGL((KERNEL<__VA_ARGS__, NoLanes>), dim3((GRIDX), 1, 1), dim3(256), 0, s, TB, no_lanes(P));                   \
+    } while (0)
+#define FWD_CASE(L, S)                                                   \
+    if (load == L && store == S) {                                       \
+        LAUNCH_LANES(ntt_forward_kernel, nblocks, tb, p, L, S);          \
+        return;                                                          \
     }
 
 void launch_ntt_forward(const DeviceTables& t, const FwdParams& p_in, uint32_t load, uint32_t store, uint32_t nblocks, hipStream_t s) {
@@ -708,22 +717,22 @@ void launch_ntt_forward(const DeviceTables& t, const FwdParams& p_in, uint32_t l
     }
     if (fwd2 && store == ST_PK && load == LD_DIGIT && p.n_digits >= 2) {
         const uint32_t nsrc = nblocks / p.n_digits;
-        hipLaunchKernelGGL((ntt_forward2_kernel<LD_DIGIT>), dim3(nsrc * ((p.n_digits + 1u) / 2u), 1, p.lanes.n), dim3(256), 0, s, tb, p);
+        LAUNCH_LANES(ntt_forward2_kernel, nsrc * ((p.n_digits + 1u) / 2u), tb, p, LD_DIGIT);
         return;
     }
     if (fwd2 && store == ST_PK && load == LD_SDIFF && p.n_digits >= 2) {
         const uint32_t nsrc = nblocks / p.n_digits;
-        hipLaunchKernelGGL((ntt_forward2_kernel<LD_SDIFF>), dim3(nsrc * ((p.n_digits + 1u) / 2u), 1, p.lanes.n), dim3(256), 0, s, tb, p);
+        LAUNCH_LANES(ntt_forward2_kernel, nsrc * ((p.n_digits + 1u) / 2u), tb, p, LD_SDIFF);
         return;
     }
     if (fwd2 && store == ST_PK && load == LD_PDIFF && p.n_digits >= 2) {
         const uint32_t nsrc = nblocks / p.n_digits;
-        hipLaunchKernelGGL((ntt_forward2_kernel<LD_PDIFF>), dim3(nsrc * ((p.n_digits + 1u) / 2u), 1, p.lanes.n), dim3(256), 0, s, tb, p);
+        LAUNCH_LANES(ntt_forward2_kernel, nsrc * ((p.n_digits + 1u) / 2u), tb, p, LD_PDIFF);
         return;
     }
     if (fwd2 && store == ST_PK && load == LD_EXPAND) {
         const uint32_t cnt_o = p.t_o ? (nblocks - p.cnt_e * p.t_e) / p.t_o : 0u;
-        hipLaunchKernelGGL((ntt_forward2_kernel<LD_EXPAND>), dim3(p.cnt_e * ((p.t_e + 1u) / 2u) + cnt_o * ((p.t_o + 1u) / 2u), 1, p.lanes.n), dim3(256), 0, s, tb, p);
+        LAUNCH_LANES(ntt_forward2_kernel, p.cnt_e * ((p.t_e + 1u) / 2u) + cnt_o * ((p.t_o + 1u) / 2u), tb, p, LD_EXPAND);
         return;
     }
     FWD_CASE(LD_RAW, ST_PK)
@@ -744,22 +753,25 @@ void launch_ntt_forward(const DeviceTables& t, const FwdParams& p_in, uint32_t l
 void launch_ntt_inverse_expand(const DeviceTables& t, const InvParams& p, uint32_t nblocks, hipStream_t s) {
     if (nblocks == 0) return;
     Tables tb{t.fwd, t.inv};
-    hipLaunchKernelGGL((ntt_inverse_kernel<IST_CRT, true>), dim3(nblocks, 1, p.lanes.n), dim3(256), 0, s, tb, p);
+    LAUNCH_LANES(ntt_inverse_kernel, nblocks, tb, p, IST_CRT, true);
 }
 
 void launch_ntt_inverse(const DeviceTables& t, const InvParams& p, uint32_t store, uint32_t nblocks, hipStream_t s) {
     if (nblocks == 0) return;
     Tables tb{t.fwd, t.inv};
     if (store == IST_CRT)
-        hipLaunchKernelGGL((ntt_inverse_kernel<IST_CRT>), dim3(nblocks, 1, p.lanes.n), dim3(256), 0, s, tb, p);
+        LAUNCH_LANES(ntt_inverse_kernel, nblocks, tb, p, IST_CRT, false);
     else
-        hipLaunchKernelGGL((ntt_inverse_kernel<IST_LIMBS>), dim3(nblocks), dim3(256), 0, s, tb, p);
+        hipLaunchKernelGGL((ntt_inverse_kernel<IST_LIMBS, false, NoLanes>), dim3(nblocks), dim3(256), 0, s, tb, no_lanes(p));
 }
 
 void launch_fold_chain(const DeviceTables& t, const FoldChainParams& p, uint32_t n_src, hipStream_t s) {
     if (n_src == 0) return;
     Tables tb{t.fwd, t.inv};
-    hipLaunchKernelGGL(fold_chain_kernel, dim3(n_src * ((p.ell + p.dpb - 1u) / p.dpb), 1, p.lanes.n), dim3(256), 0, s, tb, p);
+    if (p.lanes.n > 1)
+        hipLaunchKernelGGL(fold_chain_kernel<Lanes>, dim3(n_src * ((p.ell + p.dpb - 1u) / p.dpb), 1, p.lanes.n), dim3(256), 0, s, tb, p);
+    else
+        hipLaunchKernelGGL(fold_chain_kernel<NoLanes>, dim3(n_src * ((p.ell + p.dpb - 1u) / p.dpb), 1, 1), dim3(256), 0, s, tb, no_lanes(p));
 }
 
 void launch_ref_to_pk(const uint64_t* ref, uint64_t* pk, uint32_t npolys, IndexMap pk_map, hipStream_t s) {

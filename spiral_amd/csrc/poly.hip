@@ -43,18 +43,24 @@ void launch_matmul(const MatmulParams& p, uint32_t batch, hipStream_t s) {
 // ---- fold product (cpu_mul_query_by_ct x2 + add, src/spiral.cpp:464-582, 1361-1383) ------------------
 // out[i][r][c] = sum_{mm < K} key[r][mm] * D[i][mm][c], K = 2*m2 (Q_neg half then Q half).  One workgroup =
 // 64 slots x 4 k-groups; every D word feeds 3 rows and every key word 2 columns; partial sums meet in LDS.
-struct FoldMacParams {
+struct FoldMacParamsCore {
     const uint64_t* key;  // [3][K]
     const uint64_t* d;    // [np][K][2]
     uint64_t* out;        // [np][3][2]
     uint32_t K;
     uint32_t ks;          // polynomials between key rows (>= K)
     const uint64_t* add;  // optional addend [np][3][2] (the pair form: out = C[i] + Q * D'), fields any u32
-    Lanes lanes;          // every pointer per query lane (each query folds with its own keys)
 };
+template <class L>
+struct FoldMacParamsT : FoldMacParamsCore {
+    using Core = FoldMacParamsCore;
+    using NoLanesT = FoldMacParamsT<NoLanes>;
+    L lanes;          // every pointer per query lane (each query folds with its own keys)
+};
+using FoldMacParams = FoldMacParamsT<Lanes>;
 // B ciphertexts per workgroup share every key word loaded (the key is common to all ciphertexts of a round)
-template <uint32_t B>
-__global__ __launch_bounds__(kTpb) void fold_mac_kernel(FoldMacParams p) {
+template <uint32_t B, class L>
+__global__ __launch_bounds__(kTpb) void fold_mac_kernel(FoldMacParamsT<L> p) {
     __shared__ uint64_t sh[3][64][12 * B];
     const uint32_t zz = threadIdx.x & 63u, kg = threadIdx.x >> 6, z = blockIdx.x * 64u + zz, i0 = blockIdx.y * B;
     {
@@ -161,7 +167,8 @@ __global__ __launch_bounds__(kTpb) void fold_mac_kernel(FoldMacParams p) {
 // whatever digits the round's loader produced).  This is the fallback form -- fold_root's first round, the stage API's fold() without transform-domain words,
 // option fold_pair = 0, gadgets without the pair identity -- so it is written for clarity: one thread per slot, one ciphertext per block row, no k-split.
 // d: the two-product operand layout D[i][(L | H) half][m2 rows][2 columns]; its words may be lazy ([0, 2m)): canonicalised on load.
-__global__ __launch_bounds__(kTpb) void fold_mac_two_kernel(FoldMacParams p, uint32_t ell, uint32_t bits) {
+template <class L>
+__global__ __launch_bounds__(kTpb) void fold_mac_two_kernel(FoldMacParamsT<L> p, uint32_t ell, uint32_t bits) {
     const uint32_t z = blockIdx.x * kTpb + threadIdx.x, i = blockIdx.y, m2 = p.K;
     {
         const int64_t lane = p.lanes.here();
@@ -204,17 +211,33 @@ __global__ __launch_bounds__(kTpb) void fold_mac_two_kernel(FoldMacParams p, uin
 }
 void launch_fold_mac_two(const uint64_t* q, const uint64_t* d, uint64_t* out, uint32_t m2, uint32_t ell, uint32_t bits, uint32_t np, hipStream_t s, const Lanes& lanes) {
     if (np == 0) return;
-    FoldMacParams p{q, d, out, m2, m2, nullptr, lanes};
-    hipLaunchKernelGGL(fold_mac_two_kernel, dim3(kBpp, np, lanes.n), dim3(kTpb), 0, s, p, ell, bits);
+    FoldMacParams p{};
+    static_cast<FoldMacParamsCore&>(p) = FoldMacParamsCore{q, d, out, m2, m2, nullptr};
+    p.lanes = lanes;
+    if (lanes.n > 1)
+        hipLaunchKernelGGL(fold_mac_two_kernel<Lanes>, dim3(kBpp, np, lanes.n), dim3(kTpb), 0, s, p, ell, bits);
+    else
+        hipLaunchKernelGGL(fold_mac_two_kernel<NoLanes>, dim3(kBpp, np, 1), dim3(kTpb), 0, s, no_lanes(p), ell, bits);
 }
 void launch_fold_mac(const uint64_t* key, const uint64_t* d, uint64_t* out, uint32_t K, uint32_t np, hipStream_t s, uint32_t key_stride, const uint64_t* addend,
                      const Lanes& lanes) {
     if (np == 0) return;
-    FoldMacParams p{key, d, out, K, key_stride ? key_stride : K, addend, lanes};
-    if (np * lanes.n >= 16 && np % 2 == 0)  // wide rounds (all query lanes together): 2 ciphertexts per workgroup
-        hipLaunchKernelGGL(fold_mac_kernel<2>, dim3(kN / 64, np / 2, lanes.n), dim3(kTpb), 0, s, p);
-    else
-        hipLaunchKernelGGL(fold_mac_kernel<1>, dim3(kN / 64, np, lanes.n), dim3(kTpb), 0, s, p);
+    FoldMacParams p{};
+    static_cast<FoldMacParamsCore&>(p) = FoldMacParamsCore{key, d, out, K, key_stride ? key_stride : K, addend};
+    p.lanes = lanes;
+    const bool two = np * lanes.n >= 16 && np % 2 == 0;  // wide rounds (all query lanes together): 2 ciphertexts per workgroup
+    const dim3 grid(kN / 64, two ? np / 2 : np, lanes.n);
+    if (lanes.n > 1) {  // (one query: the instantiations without lane arguments, kernels.h NoLanes)
+        if (two)
+            hipLaunchKernelGGL((fold_mac_kernel<2, Lanes>), grid, dim3(kTpb), 0, s, p);
+        else
+            hipLaunchKernelGGL((fold_mac_kernel<1, Lanes>), grid, dim3(kTpb), 0, s, p);
+    } else {
+        if (two)
+            hipLaunchKernelGGL((fold_mac_kernel<2, NoLanes>), grid, dim3(kTpb), 0, s, no_lanes(p));
+        else
+            hipLaunchKernelGGL((fold_mac_kernel<1, NoLanes>), grid, dim3(kTpb), 0, s, no_lanes(p));
+    }
 }
 
 // ---- add / mul_by_const (src/poly.cpp:138-155, 190-211) ----------------------------------------------
@@ -277,8 +300,9 @@ __global__ __launch_bounds__(kTpb) void rescale_kernel(const uint64_t* in, uint6
     if (i < n) out[i] = rescale_dev(in[i] % kQ, inp_mod, out_mod);
 }
 // the response switch in one launch: elements [0, n0) -> out_mod0 (row 0 -> q'), [n0, n) -> out_mod1 (the rest -> 4p)
+template <class L>
 __global__ __launch_bounds__(kTpb) void rescale2_kernel(const uint64_t* in, uint64_t* out, uint32_t n0, uint32_t n, uint64_t inp_mod, uint64_t out_mod0,
-                                                        uint64_t out_mod1, Lanes lanes) {
+                                                        uint64_t out_mod1, L lanes) {
     const uint32_t i = blockIdx.x * kTpb + threadIdx.x;
     lane_shift(in, lanes.here());
     lane_shift(out, lanes.here());
@@ -311,14 +335,19 @@ void launch_response_wire(const uint64_t* in, uint64_t* out, uint32_t n0, uint32
 }
 void launch_rescale2(const uint64_t* in, uint64_t* out, uint32_t n0, uint32_t n, uint64_t inp_mod, uint64_t out_mod0, uint64_t out_mod1, hipStream_t s,
                      const Lanes& lanes) {
-    if (n) hipLaunchKernelGGL(rescale2_kernel, dim3((n + kTpb - 1) / kTpb, 1, lanes.n), dim3(kTpb), 0, s, in, out, n0, n, inp_mod, out_mod0, out_mod1, lanes);
+    if (n == 0) return;
+    if (lanes.n > 1)
+        hipLaunchKernelGGL(rescale2_kernel<Lanes>, dim3((n + kTpb - 1) / kTpb, 1, lanes.n), dim3(kTpb), 0, s, in, out, n0, n, inp_mod, out_mod0, out_mod1, lanes);
+    else
+        hipLaunchKernelGGL(rescale2_kernel<NoLanes>, dim3((n + kTpb - 1) / kTpb, 1, 1), dim3(kTpb), 0, s, in, out, n0, n, inp_mod, out_mod0, out_mod1, NoLanes{});
 }
 void launch_rescale(const uint64_t* in, uint64_t* out, uint32_t n, uint64_t inp_mod, uint64_t out_mod, hipStream_t s) {
     if (n) hipLaunchKernelGGL(rescale_kernel, dim3((n + kTpb - 1) / kTpb), dim3(kTpb), 0, s, in, out, n, inp_mod, out_mod);
 }
 
 // ---- coefficient expansion (src/spiral.cpp:1664-1743) -------------------------------------------------------
-__device__ __forceinline__ void expand_mac_lane(ExpandMacParams& p) {  // query lane blockIdx.z: every query has its own ciphertexts, keys and scratch
+template <class P>
+__device__ __forceinline__ void expand_mac_lane(P& p) {  // query lane blockIdx.z: every query has its own ciphertexts, keys and scratch
     const int64_t lane = p.lanes.here();
     lane_shift(p.cv, lane);
     lane_shift(p.w_e, lane);
@@ -327,7 +356,8 @@ __device__ __forceinline__ void expand_mac_lane(ExpandMacParams& p) {  // query 
     lane_shift(p.a1, lane);
 }
 // whole-round MAC: 64 slots x 4 k-groups per workgroup, partial sums combined through LDS
-__global__ __launch_bounds__(kTpb) void expand_mac_round_kernel(ExpandMacParams p) {
+template <class L>
+__global__ __launch_bounds__(kTpb) void expand_mac_round_kernel(ExpandMacParamsT<L> p) {
     __shared__ uint64_t sh[3][64][4];
     expand_mac_lane(p);
     const uint32_t zz = threadIdx.x & 63u, kg = threadIdx.x >> 6, z = blockIdx.x * 64u + zz, a = blockIdx.y;
@@ -391,7 +421,8 @@ __global__ __launch_bounds__(kTpb) void expand_mac_round_kernel(ExpandMacParams 
 }
 // the same with two adjacent slots per thread (16-byte loads, 1 KiB per wave instruction) for the wide rounds
 typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
-__global__ __launch_bounds__(kTpb) void expand_mac_round_wide_kernel(ExpandMacParams p) {
+template <class L>
+__global__ __launch_bounds__(kTpb) void expand_mac_round_wide_kernel(ExpandMacParamsT<L> p) {
     __shared__ uint64_t sh[3][64][8];
     expand_mac_lane(p);
     const uint32_t zz = threadIdx.x & 63u, kg = threadIdx.x >> 6, z = (blockIdx.x * 64u + zz) * 2u, a = blockIdx.y;
@@ -467,8 +498,8 @@ __global__ __launch_bounds__(kTpb) void expand_mac_round_wide_kernel(ExpandMacPa
 // The widest rounds: CT ciphertexts of one parity per workgroup, so that a W word is fetched once for CT digit streams (the
 // single-ciphertext kernels above read 2 W words per digit word: two thirds of their L2 traffic).  Same split over 4
 // k-groups; wave c finishes ciphertext c from the other waves' partial sums (LDS [k-group][ct][word][lane]: conflict-free).
-template <int CT>
-__global__ __launch_bounds__(kTpb) void expand_mac_round_batch_kernel(ExpandMacParams p) {
+template <int CT, class L>
+__global__ __launch_bounds__(kTpb) void expand_mac_round_batch_kernel(ExpandMacParamsT<L> p) {
     __shared__ uint64_t sh[4][CT][8][64];
     expand_mac_lane(p);
     const uint32_t zz = threadIdx.x & 63u, kg = threadIdx.x >> 6, z = (blockIdx.x * 64u + zz) * 2u;
@@ -578,14 +609,27 @@ void launch_expand_mac_round(const ExpandMacParams& p, hipStream_t s) {
     // (the thresholds count the ciphertexts of all query lanes: what matters is how many workgroups the launch has; the groups of a batch kernel
     // still come from one lane -- they share that lane's W)
     const uint32_t eff = cnt * p.lanes.n;
-    if (eff >= ct4_min && cnt >= 8)
-        hipLaunchKernelGGL(expand_mac_round_batch_kernel<4>, dim3(kN / 128, (p.cnt_e + 3) / 4 + (p.cnt_o + 3) / 4, p.lanes.n), dim3(kTpb), 0, s, p);
-    else if (eff >= ct2_min && cnt >= 4)
-        hipLaunchKernelGGL(expand_mac_round_batch_kernel<2>, dim3(kN / 128, (p.cnt_e + 1) / 2 + (p.cnt_o + 1) / 2, p.lanes.n), dim3(kTpb), 0, s, p);
-    else if (eff >= wide_min)
-        hipLaunchKernelGGL(expand_mac_round_wide_kernel, dim3(kN / 128, cnt, p.lanes.n), dim3(kTpb), 0, s, p);
-    else
-        hipLaunchKernelGGL(expand_mac_round_kernel, dim3(kN / 64, cnt, p.lanes.n), dim3(kTpb), 0, s, p);
+// (one query: the instantiations without lane arguments, kernels.h NoLanes)
+    const bool one = p.lanes.n == 1;
+    const auto q = no_lanes(p);
+    const dim3 b(kTpb);
+    if (eff >= ct4_min && cnt >= 8) {
+        const dim3 g(kN / 128, (p.cnt_e + 3) / 4 + (p.cnt_o + 3) / 4, p.lanes.n);
+        if (one) hipLaunchKernelGGL((expand_mac_round_batch_kernel<4, NoLanes>), g, b, 0, s, q);
+        else hipLaunchKernelGGL((expand_mac_round_batch_kernel<4, Lanes>), g, b, 0, s, p);
+    } else if (eff >= ct2_min && cnt >= 4) {
+        const dim3 g(kN / 128, (p.cnt_e + 1) / 2 + (p.cnt_o + 1) / 2, p.lanes.n);
+        if (one) hipLaunchKernelGGL((expand_mac_round_batch_kernel<2, NoLanes>), g, b, 0, s, q);
+        else hipLaunchKernelGGL((expand_mac_round_batch_kernel<2, Lanes>), g, b, 0, s, p);
+    } else if (eff >= wide_min) {
+        const dim3 g(kN / 128, cnt, p.lanes.n);
+        if (one) hipLaunchKernelGGL(expand_mac_round_wide_kernel<NoLanes>, g, b, 0, s, q);
+        else hipLaunchKernelGGL(expand_mac_round_wide_kernel<Lanes>, g, b, 0, s, p);
+    } else {
+        const dim3 g(kN / 64, cnt, p.lanes.n);
+        if (one) hipLaunchKernelGGL(expand_mac_round_kernel<NoLanes>, g, b, 0, s, q);
+        else hipLaunchKernelGGL(expand_mac_round_kernel<Lanes>, g, b, 0, s, p);
+    }
 }
 
 // ---- scalToMat (src/spiral.cpp:1834-1885) ----------------------------------------------------------------------
@@ -663,7 +707,8 @@ __device__ __forceinline__ void scal2mat_slot(const uint64_t* w, const uint64_t*
             out[r][c] = v;
         }
 }
-__device__ __forceinline__ void scal2mat_lane(Scal2MatParams& p) {  // query lane blockIdx.z
+template <class P>
+__device__ __forceinline__ void scal2mat_lane(P& p) {  // query lane blockIdx.z
     const int64_t lane = p.lanes.here();
     lane_shift(p.w, lane);
     lane_shift(p.g, lane);
@@ -671,7 +716,8 @@ __device__ __forceinline__ void scal2mat_lane(Scal2MatParams& p) {  // query lan
     lane_shift(p.out, lane);
     lane_shift(p.qs, lane);  // (u32 records in a u64-word arena: the shift is in bytes)
 }
-__device__ __forceinline__ void gsw_lane(GswParams& p) {
+template <class P>
+__device__ __forceinline__ void gsw_lane(P& p) {
     const int64_t lane = p.lanes.here();
     lane_shift(p.w, lane);
     lane_shift(p.v, lane);
@@ -680,7 +726,8 @@ __device__ __forceinline__ void gsw_lane(GswParams& p) {
     lane_shift(p.gsw, lane);
     lane_shift(p.key, lane);
 }
-__global__ __launch_bounds__(kTpb) void scal2mat_kernel(Scal2MatParams p) {
+template <class L>
+__global__ __launch_bounds__(kTpb) void scal2mat_kernel(Scal2MatParamsT<L> p) {
     scal2mat_lane(p);
     const uint32_t z = blockIdx.x * kTpb + threadIdx.x, a = blockIdx.y;
     const uint64_t cv1 = p.cv[((size_t)p.cv_pos(a) * 2 + 1) * kN + z];
@@ -702,7 +749,7 @@ __global__ __launch_bounds__(kTpb) void scal2mat_kernel(Scal2MatParams p) {
 // the same product for 16 ciphertexts x 16 slots per workgroup, records only: the 48-byte sweep records of one slot and
 // consecutive j are adjacent in memory, so the workgroup transposes its results through LDS and writes 768-byte runs
 // (one thread per slot and ciphertext writes 16-byte pieces 12 KiB apart instead)
-__device__ __forceinline__ void scal2mat_rec_body(const Scal2MatParams& p, uint32_t bx, uint32_t by) {
+__device__ __forceinline__ void scal2mat_rec_body(const Scal2MatParamsCore& p, uint32_t bx, uint32_t by) {
     __shared__ uint4 sh[16][16][3];  // [slot][ct][piece]
     const uint32_t zl = threadIdx.x & 15u, al = threadIdx.x >> 4, z0 = bx * 16u, a0 = by * 16u;
     {
@@ -734,7 +781,7 @@ __device__ __forceinline__ void scal2mat_rec_body(const Scal2MatParams& p, uint3
 // Large t_conv (the SpiralStream sets: 56 digit polynomials per ciphertext, 1.9 GB of digits): 64 slots x 16 ciphertexts per
 // workgroup, a thread takes one slot of FOUR ciphertexts, so a W word is fetched once per four digit words (the 16 x 16 tile above
 // fetches six per digit word and ran at 1.8 TB/s of digits, bound by the L1/L2 request rate) and a wave reads 512 contiguous bytes.
-__device__ __forceinline__ void scal2mat_rec4_body(const Scal2MatParams& p, uint32_t bx, uint32_t by) {
+__device__ __forceinline__ void scal2mat_rec4_body(const Scal2MatParamsCore& p, uint32_t bx, uint32_t by) {
     __shared__ uint4 sh[64][16][3];  // [slot][ct][piece]
     const uint32_t zl = threadIdx.x & 63u, cg = threadIdx.x >> 6, z = bx * 64u + zl, a0 = by * 16u, tc = p.t_conv;
     Acc2 acc[4][3][2];
@@ -793,11 +840,13 @@ static uint32_t scal2mat_wide_min() {
     }();
     return v;
 }
-__global__ __launch_bounds__(kTpb) void scal2mat_rec4_kernel(Scal2MatParams p) {
+template <class L>
+__global__ __launch_bounds__(kTpb) void scal2mat_rec4_kernel(Scal2MatParamsT<L> p) {
     scal2mat_lane(p);
     scal2mat_rec4_body(p, blockIdx.x, blockIdx.y);
 }
-__global__ __launch_bounds__(kTpb) void scal2mat_rec_kernel(Scal2MatParams p) {
+template <class L>
+__global__ __launch_bounds__(kTpb) void scal2mat_rec_kernel(Scal2MatParamsT<L> p) {
     scal2mat_lane(p);
     scal2mat_rec_body(p, blockIdx.x, blockIdx.y);
 }
@@ -808,19 +857,24 @@ static bool scal2mat_rec_ok(const Scal2MatParams& p) { return p.count && p.count
 static bool scal2mat_wide(const Scal2MatParams& p) { return p.t_conv >= scal2mat_wide_min() || (kN / 64u) * (p.count / 16u) * p.lanes.n >= 2048u; }
 void launch_scal2mat(const Scal2MatParams& p, hipStream_t s) {
     if (scal2mat_rec_ok(p)) {
-        if (scal2mat_wide(p))
-            hipLaunchKernelGGL(scal2mat_rec4_kernel, dim3(kN / 64, p.count / 16, p.lanes.n), dim3(kTpb), 0, s, p);
-        else
-            hipLaunchKernelGGL(scal2mat_rec_kernel, dim3(kN / 16, p.count / 16, p.lanes.n), dim3(kTpb), 0, s, p);
+        if (scal2mat_wide(p)) {
+            if (p.lanes.n > 1) hipLaunchKernelGGL(scal2mat_rec4_kernel<Lanes>, dim3(kN / 64, p.count / 16, p.lanes.n), dim3(kTpb), 0, s, p);
+            else hipLaunchKernelGGL(scal2mat_rec4_kernel<NoLanes>, dim3(kN / 64, p.count / 16, 1), dim3(kTpb), 0, s, no_lanes(p));
+        } else {
+            if (p.lanes.n > 1) hipLaunchKernelGGL(scal2mat_rec_kernel<Lanes>, dim3(kN / 16, p.count / 16, p.lanes.n), dim3(kTpb), 0, s, p);
+            else hipLaunchKernelGGL(scal2mat_rec_kernel<NoLanes>, dim3(kN / 16, p.count / 16, 1), dim3(kTpb), 0, s, no_lanes(p));
+        }
         return;
     }
-    if (p.count) hipLaunchKernelGGL(scal2mat_kernel, dim3(kBpp, p.count, p.lanes.n), dim3(kTpb), 0, s, p);
+    if (p.count == 0) return;
+    if (p.lanes.n > 1) hipLaunchKernelGGL(scal2mat_kernel<Lanes>, dim3(kBpp, p.count, p.lanes.n), dim3(kTpb), 0, s, p);
+    else hipLaunchKernelGGL(scal2mat_kernel<NoLanes>, dim3(kBpp, p.count, 1), dim3(kTpb), 0, s, no_lanes(p));
 }
 
 // ---- regevToGSW (src/spiral.cpp:1985-2025) ------------------------------------------------------------------------
 // HOIST: the V product's operands requested up front (the conversion's own launch in a batch: 104 VGPRs); the merged single-query launch keeps the loop (78)
 template <bool HOIST>
-__device__ __forceinline__ void regev_to_gsw_body(const GswParams& p, uint32_t bx, uint32_t by) {
+__device__ __forceinline__ void regev_to_gsw_body(const GswParamsCore& p, uint32_t bx, uint32_t by) {
     const uint32_t z = bx * kTpb + threadIdx.x, di = by;  // di = d*ell + i
     const uint32_t d = di / p.ell, i = di - d * p.ell, tc = p.t_conv;
     const uint64_t* chat = p.chat + (size_t)di * 2 * tc * kN + z;
@@ -874,13 +928,14 @@ __device__ __forceinline__ void regev_to_gsw_body(const GswParams& p, uint32_t b
         }
     }
 }
-__global__ __launch_bounds__(kTpb) void regev_to_gsw_kernel(GswParams p) {
+template <class L>
+__global__ __launch_bounds__(kTpb) void regev_to_gsw_kernel(GswParamsT<L> p) {
     gsw_lane(p);
     regev_to_gsw_body<true>(p, blockIdx.x, blockIdx.y);
 }
 // the two conversion products are independent: one launch, the first n1 blocks ScalToMat, the rest Regev->GSW
-template <bool WIDE>
-__global__ __launch_bounds__(kTpb) void convert_products_kernel(Scal2MatParams sp, GswParams gp, uint32_t n1) {
+template <bool WIDE, class L>
+__global__ __launch_bounds__(kTpb) void convert_products_kernel(Scal2MatParamsT<L> sp, GswParamsT<L> gp, uint32_t n1) {
     scal2mat_lane(sp);
     gsw_lane(gp);
 #ifdef CONVERT_GSW_FIRST  // (variant: the latency-bound Regev->GSW workgroups dispatched first, the streaming ScalToMat ones fill in behind them)
@@ -902,17 +957,23 @@ void launch_convert_products(const Scal2MatParams& sp, const GswParams& gp, hipS
     if (scal2mat_rec_ok(sp) && gp.dims) {
         const bool wide = scal2mat_wide(sp);
         const uint32_t n1 = (kN / (wide ? 64u : 16u)) * (sp.count / 16u), n2 = kBpp * gp.dims * gp.ell;
-        if (wide)
-            hipLaunchKernelGGL(convert_products_kernel<true>, dim3(n1 + n2, 1, sp.lanes.n), dim3(kTpb), 0, s, sp, gp, n1);
-        else
-            hipLaunchKernelGGL(convert_products_kernel<false>, dim3(n1 + n2, 1, sp.lanes.n), dim3(kTpb), 0, s, sp, gp, n1);
+        const dim3 g(n1 + n2, 1, sp.lanes.n);
+        if (sp.lanes.n > 1) {
+            if (wide) hipLaunchKernelGGL((convert_products_kernel<true, Lanes>), g, dim3(kTpb), 0, s, sp, gp, n1);
+            else hipLaunchKernelGGL((convert_products_kernel<false, Lanes>), g, dim3(kTpb), 0, s, sp, gp, n1);
+        } else {  // one query: no lane arguments (kernels.h NoLanes)
+            if (wide) hipLaunchKernelGGL((convert_products_kernel<true, NoLanes>), g, dim3(kTpb), 0, s, no_lanes(sp), no_lanes(gp), n1);
+            else hipLaunchKernelGGL((convert_products_kernel<false, NoLanes>), g, dim3(kTpb), 0, s, no_lanes(sp), no_lanes(gp), n1);
+        }
     } else {
         launch_scal2mat(sp, s);
         launch_regev_to_gsw(gp, s);
     }
 }
 void launch_regev_to_gsw(const GswParams& p, hipStream_t s) {
-    if (p.dims) hipLaunchKernelGGL(regev_to_gsw_kernel, dim3(kBpp, p.dims * p.ell, p.lanes.n), dim3(kTpb), 0, s, p);
+    if (p.dims == 0) return;
+    if (p.lanes.n > 1) hipLaunchKernelGGL(regev_to_gsw_kernel<Lanes>, dim3(kBpp, p.dims * p.ell, p.lanes.n), dim3(kTpb), 0, s, p);
+    else hipLaunchKernelGGL(regev_to_gsw_kernel<NoLanes>, dim3(kBpp, p.dims * p.ell, 1), dim3(kTpb), 0, s, no_lanes(p));
 }
 
 // ---- fold key from the reference's reoriented matrices (the resident path writes its keys in regev_to_gsw_kernel) --------
