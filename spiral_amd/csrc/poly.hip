@@ -164,12 +164,15 @@ __global__ __launch_bounds__(kTpb) void fold_mac_kernel(FoldMacParamsT<L> p) {
 // The reference's two-product round from the matrices Q alone (the resident server keeps no Q_neg): with Q_neg = G2 - Q slot by slot (src/spiral.cpp:2361-2379)
 //     Q_neg D_L + Q D_H  =  G2 D_L + Q (D_H - D_L),      (G2 D_L)[r][c] = sum_k 2^(bits k) D_L[3 k + r][c]      (G2[r][3 k + r'] = 2^(bits k) iff r' == r)
 // in exact arithmetic mod p and mod b: the same canonical residues as the stored-Q_neg form, for any gadget dimension (no recomposition is assumed: D_L, D_H are
-// whatever digits the round's loader produced).  This is the fallback form -- fold_root's first round, the stage API's fold() without transform-domain words,
-// option fold_pair = 0, gadgets without the pair identity -- so it is written for clarity: one thread per slot, one ciphertext per block row, no k-split.
+// whatever digits the round's loader produced).  The fallback form -- fold_root's first round, the stage API's fold() without transform-domain words,
+// option fold_pair = 0, gadgets without the pair identity.
 // d: the two-product operand layout D[i][(L | H) half][m2 rows][2 columns]; its words may be lazy ([0, 2m)): canonicalised on load.
 template <class L>
 __global__ __launch_bounds__(kTpb) void fold_mac_two_kernel(FoldMacParamsT<L> p, uint32_t ell, uint32_t bits) {
-    const uint32_t z = blockIdx.x * kTpb + threadIdx.x, i = blockIdx.y, m2 = p.K;
+    // 64 slots x 4 k-groups per workgroup as fold_mac_kernel<1> -- these rounds are narrow (fold_root's first round holds G / 2 <= 8 ciphertexts) and
+    // latency-bound, so a k-group requests ALL its terms' operands before the first multiply (terms beyond m2 are clamped and skipped)
+    __shared__ uint64_t sh[3][64][12];
+    const uint32_t zz = threadIdx.x & 63u, kg = threadIdx.x >> 6, z = blockIdx.x * 64u + zz, i = blockIdx.y, m2 = p.K;
     {
         const int64_t lane = p.lanes.here();
         lane_shift(p.key, lane);
@@ -180,34 +183,68 @@ __global__ __launch_bounds__(kTpb) void fold_mac_two_kernel(FoldMacParamsT<L> p,
     const uint64_t* dh = dl + (size_t)m2 * 2 * kN;
     const uint64_t* kp = p.key + z;
     Acc2 acc[3][2];
-    for (uint32_t mm = 0; mm < m2; mm++) {
-        uint64_t kv[3], lv[2], df[2];
+    constexpr uint32_t U = 6;  // terms in flight per k-group: m2 = 3 ell <= 24 for ell <= 8 in one trip
+    for (uint32_t m0 = kg; m0 < m2; m0 += 4 * U) {
+        uint64_t kv[U][3], lw[U][2], hw[U][2];
 #pragma unroll
-        for (uint32_t r = 0; r < 3; r++) kv[r] = kp[((size_t)r * p.ks + mm) * kN];
+        for (uint32_t u = 0; u < U; u++) {
+            const uint32_t mm = min(m0 + 4 * u, m2 - 1);
 #pragma unroll
-        for (uint32_t c = 0; c < 2; c++) {
-            const uint64_t l = dl[((size_t)mm * 2 + c) * kN], h = dh[((size_t)mm * 2 + c) * kN];
-            const uint32_t lp = csub(lo32(l), kP), lb = csub(hi32(l), kB), hp = csub(lo32(h), kP), hb = csub(hi32(h), kB);
-            lv[c] = pack(lp, lb);
-            df[c] = pack(csub(hp + kP - lp, kP), csub(hb + kB - lb, kB));  // D_H - D_L, canonical
+            for (uint32_t r = 0; r < 3; r++) kv[u][r] = kp[((size_t)r * p.ks + mm) * kN];
+#pragma unroll
+            for (uint32_t c = 0; c < 2; c++) {
+                lw[u][c] = dl[((size_t)mm * 2 + c) * kN];
+                hw[u][c] = dh[((size_t)mm * 2 + c) * kN];
+            }
         }
 #pragma unroll
-        for (uint32_t r = 0; r < 3; r++) {
-            acc[r][0].mac(kv[r], df[0]);
-            acc[r][1].mac(kv[r], df[1]);
-        }
-        const uint32_t k = mm / 3u, r = mm - 3u * k, sh = bits * k;  // row 3 k + r of D_L is digit k of the ciphertext's row r
-        if (sh < 64u) {
-            const uint64_t g2 = pack(mod_p(1ull << sh), mod_b(1ull << sh));
-            acc[r][0].mac(g2, lv[0]);
-            acc[r][1].mac(g2, lv[1]);
+        for (uint32_t u = 0; u < U; u++) {
+            const uint32_t mm = m0 + 4 * u;
+            if (mm < m2) {
+                uint64_t lv[2], df[2];
+#pragma unroll
+                for (uint32_t c = 0; c < 2; c++) {
+                    const uint32_t lp = csub(lo32(lw[u][c]), kP), lb = csub(hi32(lw[u][c]), kB), hp = csub(lo32(hw[u][c]), kP), hb = csub(hi32(hw[u][c]), kB);
+                    lv[c] = pack(lp, lb);
+                    df[c] = pack(csub(hp + kP - lp, kP), csub(hb + kB - lb, kB));  // D_H - D_L, canonical
+                }
+#pragma unroll
+                for (uint32_t r = 0; r < 3; r++) {
+                    acc[r][0].mac(kv[u][r], df[0]);
+                    acc[r][1].mac(kv[u][r], df[1]);
+                }
+                const uint32_t k = mm / 3u, r = mm - 3u * k, sh_ = bits * k;  // row 3 k + r of D_L is digit k of the ciphertext's row r
+                const uint64_t g2 = sh_ < 64u ? pack(mod_p(1ull << (sh_ & 63u)), mod_b(1ull << (sh_ & 63u))) : 0ull;
+#pragma unroll
+                for (uint32_t rr = 0; rr < 3; rr++)  // (a select per row instead of a dynamically indexed accumulator)
+                    if (rr == r) {
+                        acc[rr][0].mac(g2, lv[0]);
+                        acc[rr][1].mac(g2, lv[1]);
+                    }
+            }
         }
     }
-    (void)ell;  // (m2 = 3 ell: at most 4 ell <= 112 canonical products per accumulator, far inside the u64 bound)
+    (void)ell;  // (m2 = 3 ell: at most 4 ell <= 112 canonical products per accumulator over the four k-groups, far inside the u64 bound)
+    if (kg > 0) {
 #pragma unroll
-    for (uint32_t r = 0; r < 3; r++)
+        for (uint32_t rc = 0; rc < 6; rc++) {
+            sh[kg - 1][zz][rc * 2] = acc[rc >> 1][rc & 1].lo;
+            sh[kg - 1][zz][rc * 2 + 1] = acc[rc >> 1][rc & 1].hi;
+        }
+    }
+    __syncthreads();
+    if (kg == 0) {
 #pragma unroll
-        for (uint32_t c = 0; c < 2; c++) p.out[((size_t)i * 6 + r * 2 + c) * kN + z] = acc[r][c].reduced();
+        for (uint32_t rc = 0; rc < 6; rc++) {
+            Acc2 a = acc[rc >> 1][rc & 1];
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                a.lo += sh[q][zz][rc * 2];
+                a.hi += sh[q][zz][rc * 2 + 1];
+            }
+            p.out[((size_t)i * 6 + rc) * kN + z] = a.reduced();
+        }
+    }
 }
 void launch_fold_mac_two(const uint64_t* q, const uint64_t* d, uint64_t* out, uint32_t m2, uint32_t ell, uint32_t bits, uint32_t np, hipStream_t s, const Lanes& lanes) {
     if (np == 0) return;
@@ -215,9 +252,9 @@ void launch_fold_mac_two(const uint64_t* q, const uint64_t* d, uint64_t* out, ui
     static_cast<FoldMacParamsCore&>(p) = FoldMacParamsCore{q, d, out, m2, m2, nullptr};
     p.lanes = lanes;
     if (lanes.n > 1)
-        hipLaunchKernelGGL(fold_mac_two_kernel<Lanes>, dim3(kBpp, np, lanes.n), dim3(kTpb), 0, s, p, ell, bits);
+        hipLaunchKernelGGL(fold_mac_two_kernel<Lanes>, dim3(kN / 64, np, lanes.n), dim3(kTpb), 0, s, p, ell, bits);
     else
-        hipLaunchKernelGGL(fold_mac_two_kernel<NoLanes>, dim3(kBpp, np, 1), dim3(kTpb), 0, s, no_lanes(p), ell, bits);
+        hipLaunchKernelGGL(fold_mac_two_kernel<NoLanes>, dim3(kN / 64, np, 1), dim3(kTpb), 0, s, no_lanes(p), ell, bits);
 }
 void launch_fold_mac(const uint64_t* key, const uint64_t* d, uint64_t* out, uint32_t K, uint32_t np, hipStream_t s, uint32_t key_stride, const uint64_t* addend,
                      const Lanes& lanes) {
