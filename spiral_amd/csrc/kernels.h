@@ -62,9 +62,9 @@ __device__ __forceinline__ void lane_shift(T*& p, int64_t words) {  // optional 
     if (p) p = reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + (intptr_t)words * 8);
 }
 #endif
-// ONE query's launches carry no lane machinery at all.  A query is ~50 dependent launch-bound launches, and each pays for every byte of its kernel
-// arguments and every instruction of its prologue: with the eight offsets (72 bytes + a select chain) in every launch one query took 748 us, without
-// them 725 (round 6, same box, alternating builds).  So every kernel that takes lanes is instantiated twice -- `Lanes` for batches, `NoLanes` (no
+// ONE query's launches carry no lane machinery at all.  A query is ~50 dependent launch-bound launches, and each pays for every instruction of its
+// prologue: with the eight offsets in every launch (eight scalar loads and a select chain before the first address is known) one query took 748 us,
+// without them 725 (round 6, same box, alternating builds; 64 bytes of UNUSED kernel arguments cost nothing measurable: it is the dependent prologue).  So every kernel that takes lanes is instantiated twice -- `Lanes` for batches, `NoLanes` (no
 // offsets, here() == 0, the shifts fold away) for n == 1 -- and every parameter struct is `XCore` (the fields) + `XT<L>` (the fields and an L); the
 // host fills an `X = XT<Lanes>` as before and the launcher picks the instantiation (no_lanes() copies the fields).
 struct NoLanes {
