@@ -324,14 +324,18 @@ template <bool CANONICAL = true>
 __device__ __forceinline__ void ntt_forward_block(uint32_t* lo, uint32_t* hi, uint64_t* sh, const uint4* tw, uint32_t tid) {
     const TwTable tb(tw);
     Tw7 wb = tw_load8(tb, 8 + (tid >> 5), 16 + 2 * (tid >> 5), 32 + 4 * (tid >> 5));
+#ifndef NTT_ABLATE_AB  // ablation (tools/build_variants.sh): the first six stages' butterflies off, exchanges kept -- the bound on moving them off the vector ALU
     ct_radix8(lo, hi, tw, 1, 2, 4);
+#endif
     NTT_PRIO_HI();
     lds_put<ix_a>(sh, tid, lo, hi);
     NTT_SYNC();
     lds_get<ix_b>(sh, tid, lo, hi);
     Tw7 wc = tw_load8(tb, 64 + (tid >> 2), 128 + 2 * (tid >> 2), 256 + 4 * (tid >> 2));
     NTT_PRIO_LO();
+#ifndef NTT_ABLATE_AB
     ct_radix8_pre(lo, hi, wb);
+#endif
     NTT_PRIO_HI();
     lds_put<ix_b>(sh, tid, lo, hi);
     NTT_SYNC();
@@ -405,19 +409,23 @@ __device__ __forceinline__ void ntt_forward_block2(uint32_t* lo0, uint32_t* hi0,
                                                    const uint4* tw, uint32_t tid) {
     const TwTable tb(tw);
     Tw7 wb = tw_load8(tb, 8 + (tid >> 5), 16 + 2 * (tid >> 5), 32 + 4 * (tid >> 5));
+#ifndef NTT_ABLATE_AB
     {
         const Tw7 wa = tw_load8(tw, 1, 2, 4);
         ct_radix8_pre(lo0, hi0, wa);
         ct_radix8_pre(lo1, hi1, wa);
     }
+#endif
     lds_put<ix_a>(sh0, tid, lo0, hi0);
     lds_put<ix_a>(sh1, tid, lo1, hi1);
     NTT_SYNC();
     lds_get<ix_b>(sh0, tid, lo0, hi0);
     lds_get<ix_b>(sh1, tid, lo1, hi1);
     Tw7 wc = tw_load8(tb, 64 + (tid >> 2), 128 + 2 * (tid >> 2), 256 + 4 * (tid >> 2));
+#ifndef NTT_ABLATE_AB
     ct_radix8_pre(lo0, hi0, wb);
     ct_radix8_pre(lo1, hi1, wb);
+#endif
     lds_put<ix_b>(sh0, tid, lo0, hi0);
     lds_put<ix_b>(sh1, tid, lo1, hi1);
     NTT_SYNC();
