@@ -1740,7 +1740,11 @@ int spiral_gpu_server_run_query_batch(spiral_gpu_server* const* servers, uint32_
     // right in front of it: dirty lines draining into the database stream cost the matrix-core sweep 30-70 us (profiles/r06_sweep_in_situ_batch.txt).
     const bool gsw_early = n >= 4 && !S->p.direct_upload && S->s.stopround > 0 && S->s.stopround + 1 < S->s.g && S->p.nu2 > 0;
     auto body = [&]() {
-        if (gsw_early) {
+        if (gsw_early && tuning_env("SPIRAL_GSW_ORDER") && atoi(tuning_env("SPIRAL_GSW_ORDER")) == 2) {  // (tuning builds only) ScalToMat first, the GSW side last
+            if (expand_lanes(S, lanes)) return -1;
+            if (convert_part(S, CONV_S2M, S->stream, false, lanes)) return -1;
+            if (convert_part(S, CONV_GSW, S->stream, false, lanes)) return -1;
+        } else if (gsw_early) {
             if (expand_lanes(S, lanes, 0, S->s.stopround + 1)) return -1;
             if (convert_part(S, CONV_GSW, S->stream, false, lanes)) return -1;
             if (expand_lanes(S, lanes, S->s.stopround + 1)) return -1;
