@@ -81,6 +81,13 @@ def answer_hash(np, final_ct, response):
     return h.hexdigest()
 
 
+def inject_fail(tag, rank):
+    """test hook: SPIRAL_BENCH_INJECT_FAIL=<tag>[:<rank>] raises at the point named <tag> (a schedule, "stream_item", "cpu_baseline"), on one rank or on all"""
+    want = os.environ.get("SPIRAL_BENCH_INJECT_FAIL", "")
+    if want and want in (tag, f"{tag}:{rank}"):
+        raise RuntimeError(f"SPIRAL_BENCH_INJECT_FAIL={want}: injected failure on rank {rank}")
+
+
 class Progress:
     """The line-so-far and a watchdog.  The first multi-GPU run may be the only one: after every schedule and every leg the line as it
     stands (same keys, "partial": true) goes to stderr and to bench_partial.json, and a watchdog thread per phase turns a hang (an RCCL
@@ -94,8 +101,37 @@ class Progress:
         self.lock = threading.Lock()
         self.wrap = lambda line: line  # the secondary leg nests its line under the primary's `also`
         self.on_hang = None  # optional: () -> dict merged into the hung line (the process-group set-up says which ranks never joined)
+        self.sig_r = None  # read end of the signal wake-up pipe (catch_sigterm)
+        self.done = False  # the final line is out: a later SIGTERM must not print a second one
         t = threading.Thread(target=self._watch, daemon=True)
         t.start()
+
+    def catch_sigterm(self):
+        """A launcher that loses one rank (an exception, an out-of-memory kill) sends SIGTERM to the others: rank 0 then still owes its line.  The main thread
+        may be inside a collective or a synchronize, where a Python-level handler never runs -- so the signal only writes to a wake-up pipe
+        (signal.set_wakeup_fd, done by the C-level handler at once) and the watchdog thread, which polls the pipe, prints the line-so-far and exits."""
+        import signal
+
+        try:
+            r, w = os.pipe()
+            os.set_blocking(r, False)
+            os.set_blocking(w, False)
+            signal.signal(signal.SIGTERM, lambda signum, frame: None)  # (keeps the default action -- immediate death -- from happening)
+            signal.set_wakeup_fd(w, warn_on_full_buffer=False)
+            self.sig_r = r
+        except (ValueError, OSError):  # not the main thread / no pipe: the run goes on without this net
+            self.sig_r = None
+
+    def give_up(self, code, **more):
+        """rank 0: the line-so-far on stdout with `more` (why), then a fresh exit; other ranks just exit"""
+        with self.lock:
+            line, done = self.line, self.done
+            self.done = True
+        if self.rank == 0 and not done:
+            out = dict(line or {"metric": "server ms/query + DB GB/s vs HBM roofline", "value": None}, partial=True, **more)
+            sys.stdout.write(json.dumps(out) + "\n")
+            sys.stdout.flush()
+        os._exit(code)
 
     def arm(self, where, factor=1.0, seconds=None):
         """seconds: this phase's own limit (the process-group set-up's is short); otherwise `factor` x the --watchdog seconds"""
@@ -124,6 +160,14 @@ class Progress:
     def _watch(self):
         while True:
             time.sleep(0.25)
+            if self.sig_r is not None:
+                try:
+                    got = os.read(self.sig_r, 64)
+                except (BlockingIOError, OSError):
+                    got = b""
+                if 15 in got:  # SIGTERM
+                    print(f"bench.py: rank {self.rank} received SIGTERM in '{self.where}' (another rank died and the launcher is tearing the job down?)", file=sys.stderr, flush=True)
+                    self.give_up(143, terminated_by="SIGTERM", terminated_in=self.where)
             with self.lock:
                 late = self.deadline is not None and time.monotonic() > self.deadline
                 line, where, limit, hook = self.line, self.where, self.limit, self.on_hang
@@ -395,6 +439,8 @@ def bench_stream(args, ctx, prog, steps=None, warmup=None):
     one hipGraph); value = wall ms per item query, max over ranks.  One GPU holds four instances (4 x 56 GiB + query state of 288 GiB): a rank that is assigned more
     instances than fit re-sweeps its resident images for the rest -- the timing of the sweep does not depend on the data -- and says so (instances_resident)."""
     import hashlib
+
+    inject_fail("stream_item", ctx.rank)
 
     import numpy as np
 
@@ -965,6 +1011,7 @@ def bench_base(args, ctx, workload, steps, warmup, primary, prog):
             if not args.no_graphs:  # priming, not a step of the run: each step flavour once, so that no hipGraph is captured in the timed region
                 if sch == "in-order": step(new_events())
                 step(None, ov, st)
+            inject_fail(sch, rank)
             if inject_hang in (sch, f"{workload}/{sch}"):
                 print(f"bench.py: SPIRAL_BENCH_INJECT_HANG={inject_hang}: rank {rank} stops here", file=sys.stderr, flush=True)
                 time.sleep(10 ** 6)
@@ -1214,6 +1261,37 @@ def main(argv=None):
     import numpy as np
 
     prog = Progress(int(os.environ.get("RANK", "0")), args.watchdog)
+    prog.catch_sigterm()
+    try:
+        return run(args, prog, np)
+    except BaseException as e:  # a rank that fails takes the job down (the launcher SIGTERMs the others): rank 0 prints what it has first
+        if isinstance(e, SystemExit) and not e.code:
+            raise
+        import traceback
+
+        traceback.print_exc()
+        prog.give_up(1, error=repr(e), failed_in=prog.where)
+
+
+def extra_leg(prog, name, fn):
+    """a leg beside the headline (replicas, the secondary geometry, the whole-item stream, the CPU baseline): its failure is recorded in the line, it does not cost the line"""
+    try:
+        return fn(), None
+    except Exception as e:
+        import traceback
+
+        traceback.print_exc()
+        print(f"bench.py: leg '{name}' failed on rank {prog.rank}: {e!r}; the line goes on without it", file=sys.stderr, flush=True)
+        try:
+            import torch
+
+            torch.cuda.empty_cache()
+        except Exception:
+            pass
+        return None, {"error": repr(e)[:400], "failed_in": prog.where}
+
+
+def run(args, prog, np):
     prog.arm("process group set-up", 3.0)
     ctx = Ctx(args, prog)
     prog.arm("set-up", 3.0)
@@ -1226,13 +1304,15 @@ def main(argv=None):
             import ctypes
 
             ctypes.CDLL(None).fflush(None)
+            prog.done = True
             print(json.dumps(out), flush=True)
         return
     if args.workload == "stream-instance":
         args.workload = "stream"
     out, params_kw = bench_base(args, ctx, args.workload, args.steps, args.warmup, True, prog)
     if ctx.world > 1 and "config2" in (args.workload, args.secondary) and not args.no_replicas and (args.nu1, args.nu2) == (None, None):
-        out["replicas"] = bench_replicas(args, ctx, prog)  # no collective on its data path: cannot hang where the j-shard schedules did not
+        rep, err = extra_leg(prog, "replicas", lambda: bench_replicas(args, ctx, prog))  # no collective on its data path: cannot hang where the j-shard schedules did not
+        out["replicas"] = rep if err is None else err
         prog.update(out)
     if args.secondary and not args.no_config3 and (args.nu1, args.nu2) == (None, None):
         # secondary leg, LAST.  Default: configs[2]'s geometry (where the sweep is ~75 % of the query and the j-shard scales) under `also.config3`, the
@@ -1251,14 +1331,16 @@ def main(argv=None):
             return line
 
         prog.wrap = nest
-        o3, _ = bench_base(args, ctx, sec, args.config3_steps if sec == "config3" else args.steps, min(args.warmup, 2) if sec == "config3" else args.warmup, False, prog)
+        o3, err = extra_leg(prog, "also." + sec, lambda: bench_base(args, ctx, sec, args.config3_steps if sec == "config3" else args.steps, min(args.warmup, 2) if sec == "config3" else args.warmup, False, prog)[0])
         prog.wrap = lambda line: line
-        out = nest(o3)
+        out = nest(o3) if err is None else dict(out, also={sec: err})
     if args.workload in ("config2", "config3") and not args.no_stream_item and not args.no_config3 and (args.nu1, args.nu2) == (None, None):  # (--no-config3 = no extra legs at all)
         # last leg: configs[3] WHOLE (bench_stream): one query against the 7 instances of a 100 KB item's database; rank r holds instances r, r + N, ...
         prog.update(out)
-        st = bench_stream(args, ctx, prog, steps=3, warmup=1)
-        if ctx.rank == 0:
+        st, err = extra_leg(prog, "also.stream_item", lambda: bench_stream(args, ctx, prog, steps=3, warmup=1))
+        if err is not None:
+            out = dict(out, also=dict(out.get("also", {}), stream_item=err))
+        elif ctx.rank == 0:
             out = dict(out, also=dict(out.get("also", {}), stream_item={k: st[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "item", "answer_sha256")}))
             out["also"]["stream_item"]["workload"] = st["config"]["workload"]
             out["also"]["stream_item"]["parallelism"] = st["config"]["parallelism"]
@@ -1270,11 +1352,13 @@ def main(argv=None):
     prog.disarm()
     if ctx.rank == 0:
         if ctx.world == 1 and not args.no_cpu_baseline and args.workload == "config2" and args.headline != "config3":  # (the larger workloads' 32 / 64 GiB host databases are not built for a baseline)
-            out["cpu_baseline"] = cpu_baseline(params_kw, np, args.workload)
+            cb, err = extra_leg(prog, "cpu_baseline", lambda: cpu_baseline(params_kw, np, args.workload))
+            out["cpu_baseline"] = cb if err is None else err
         import ctypes
 
         ctypes.CDLL(None).fflush(None)  # RCCL printf()s a banner into C stdio; get it out before the JSON
         sys.stdout.flush()
+        prog.done = True
         print(json.dumps(out), flush=True)  # the ONE JSON line, last thing on stdout
 
 

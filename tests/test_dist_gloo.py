@@ -354,3 +354,56 @@ def test_two_rank_factor_shard_gathers_every_instance():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got == {0: True, 1: True}
+
+
+def test_bench_prints_its_line_when_the_launcher_terminates_it(tmp_path):
+    """bench.py's last net (Progress.catch_sigterm): a launcher that loses one rank SIGTERMs the others while their main threads sit in a collective, where no
+    Python-level signal handler can run; the signal reaches the watchdog thread through a wake-up pipe and rank 0 prints the line-so-far before it exits"""
+    import json
+    import signal
+    import subprocess
+    import time
+
+    code = (
+        "import sys, ctypes\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import bench\n"
+        "prog = bench.Progress(0, 100)\n"
+        "prog.catch_sigterm()\n"
+        "prog.update({'metric': 'm', 'value': 1.5, 'schedules': {'ms_per_query': {'in-order': 1.5}}})\n"
+        "prog.arm('config2/comm-overlap', 1.0)\n"
+        "print('ready', file=sys.stderr, flush=True)\n"
+        "while True:\n"
+        "    ctypes.CDLL(None).sleep(60)  # a blocking C call on the main thread, restarted when interrupted: what a collective's wait does\n"
+    )
+    p = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, SPIRAL_BENCH_PARTIAL=str(tmp_path / "partial.json")))
+    while "ready" not in p.stderr.readline():
+        assert p.poll() is None
+    time.sleep(0.3)
+    p.send_signal(signal.SIGTERM)
+    out, _ = p.communicate(timeout=30)
+    assert p.returncode == 143
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line["partial"] is True and line["terminated_by"] == "SIGTERM" and line["terminated_in"] == "config2/comm-overlap" and line["value"] == 1.5
+
+
+def test_bench_failed_rank_prints_the_line_so_far_with_the_error():
+    """an exception on rank 0 itself (bench.main's outer net): the line-so-far goes to stdout with `error` and `failed_in`, exit code 1"""
+    import json
+    import subprocess
+
+    code = (
+        "import sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import bench\n"
+        "def boom(args, prog, np):\n"
+        "    prog.update({'metric': 'm', 'value': 2.5})\n"
+        "    prog.arm('config2/pipelined', 1.0)\n"
+        "    raise RuntimeError('device lost')\n"
+        "bench.run = boom\n"
+        "bench.main(['--no-cpu-baseline'])\n"
+    )
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=dict(os.environ, SPIRAL_BENCH_PARTIAL=os.devnull))
+    assert r.returncode == 1
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["partial"] is True and "device lost" in line["error"] and line["failed_in"] == "config2/pipelined" and line["value"] == 2.5

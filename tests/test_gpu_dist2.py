@@ -346,3 +346,39 @@ def test_bench_stream_item_factor_sharded_over_two_ranks():
         assert it["db_device_bytes_rank0"] == len(mine) * it["image_bytes_per_instance"] and o["value"] > 0 and o["roofline"]["achieved"] > 0
     assert o1["answer_sha256"] == o2["answer_sha256"] == o2["config"]["answer_sha256"] and len(o1["answer_sha256"]) == 64
     assert "no reduce" in o2["config"]["parallelism"] and o2["rccl"]["collective_smoke"]["ok"] is True
+
+
+def _bench_env(**extra):
+    return dict({k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}, **extra)
+
+
+def test_bench_failed_extra_leg_does_not_cost_the_line():
+    """a leg beside the headline that raises (an allocation failure in the whole-item leg, say) is recorded in the line -- `also.stream_item.error` -- and the
+    line is still printed, complete otherwise, with exit code 0"""
+    import json
+    import subprocess
+
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--prewarm", "2", "--lanes", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900, env=_bench_env(SPIRAL_BENCH_INJECT_FAIL="stream_item"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "partial" not in out and out["value"] > 0 and len(out["answer_sha256"]) == 64
+    assert "injected failure" in out["also"]["stream_item"]["error"]
+
+
+def test_bench_rank_failure_still_prints_rank0s_line(tmp_path):
+    """rank 1 raises in the second schedule and exits.  Rank 0 then either gets an error out of its collective (gloo: the peer closed the connection) -- bench.main's
+    outer net prints the line-so-far with `error` -- or sits in the collective until the launcher's SIGTERM, which its watchdog thread sees through the wake-up pipe
+    (`terminated_by`), or until the watchdog (`hung_in`): in every case the first schedule's timing reaches stdout"""
+    import json
+    import subprocess
+
+    env = _bench_env(SPIRAL_BENCH_INJECT_FAIL="comm-overlap:1", SPIRAL_BENCH_PARTIAL=str(tmp_path / "partial.json"))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--backend", "gloo", "--shared-device", "--prewarm", "2", "--nu1", "7", "--nu2", "6", "--no-config3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
+    assert r.returncode != 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines, r.stderr[-3000:]
+    out = json.loads(lines[-1])
+    assert out["partial"] is True and out["n_gpus"] == 2 and (out.get("terminated_by") == "SIGTERM" or "hung_in" in out or "error" in out)
+    assert set(out["schedules"]["ms_per_query"]) == {"in-order"} and out["value"] == out["schedules"]["ms_per_query"]["in-order"] > 0
