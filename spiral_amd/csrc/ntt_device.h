@@ -349,9 +349,11 @@ __device__ __forceinline__ void ntt_forward_block(uint32_t* lo, uint32_t* hi, ui
     }
     ct_radix8_pre(lo, hi, wc);
     NTT_PRIO_HI();
+#ifndef NTT_ABLATE_QUAD_EXCHANGE  // ablation: the one exchange that stays inside a quad of lanes (C <-> D) removed outright -- the bound on replacing it by DPP shuffles
     lds_put<ix_c>(sh, tid, lo, hi);
     NTT_SYNC();
     lds_get<ix_d>(sh, tid, lo, hi);
+#endif
     NTT_PRIO_LO();
     ct_radix4x2_pre(lo, hi, wd);
 #pragma unroll
@@ -377,9 +379,11 @@ __device__ __forceinline__ void ntt_inverse_block(uint32_t* lo, uint32_t* hi, ui
     Tw7 wc = tw_load8(tb, 64 + (tid >> 2), 128 + 2 * (tid >> 2), 256 + 4 * (tid >> 2));
     gs_radix4x2_pre(lo, hi, wd);
     NTT_PRIO_HI();
+#ifndef NTT_ABLATE_QUAD_EXCHANGE
     lds_put<ix_d>(sh, tid, lo, hi);
     __syncthreads();
     lds_get<ix_c>(sh, tid, lo, hi);
+#endif
     Tw7 wb = tw_load8(tb, 8 + (tid >> 5), 16 + 2 * (tid >> 5), 32 + 4 * (tid >> 5));
     NTT_PRIO_LO();
     gs_radix8_pre(lo, hi, wc);
@@ -441,11 +445,13 @@ __device__ __forceinline__ void ntt_forward_block2(uint32_t* lo0, uint32_t* hi0,
     }
     ct_radix8_pre(lo0, hi0, wc);
     ct_radix8_pre(lo1, hi1, wc);
+#ifndef NTT_ABLATE_QUAD_EXCHANGE
     lds_put<ix_c>(sh0, tid, lo0, hi0);
     lds_put<ix_c>(sh1, tid, lo1, hi1);
     NTT_SYNC();
     lds_get<ix_d>(sh0, tid, lo0, hi0);
     lds_get<ix_d>(sh1, tid, lo1, hi1);
+#endif
     ct_radix4x2_pre(lo0, hi0, wd);
     ct_radix4x2_pre(lo1, hi1, wd);
 #pragma unroll
