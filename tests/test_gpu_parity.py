@@ -529,6 +529,22 @@ def test_random_parameter_sets_batched(sa, oracle, nu1, nu2, kw):
             want = O.answer(po, q, pp[0], pp[1], pp[2], pp[3], db)
             assert_eq(srv.read(SV.BUF_FINAL), want, f"round {rnd} lane {b} of {n}: final ciphertext, params {nu1},{nu2},{kw}")
             assert_eq(srv.read(SV.BUF_RESPONSE), O.stage_rescale(po, want), f"round {rnd} lane {b} of {n}: response")
+    # one image per server: where the batch swept on the matrix cores it converted the owner's image in place; a single query then sweeps the limb planes
+    # (sweep_mfma_kernel<1>), and converting back restores the packed words exactly -- on this draw's geometry
+    fmt = owner.db_format()
+    want0 = O.answer(po, qs[0], *pps[0], db)
+    owner.run_query()
+    owner.sync()
+    assert_eq(owner.read(SV.BUF_FINAL), want0, f"single query on the image as the batch left it (format {fmt}), params {nu1},{nu2},{kw}")
+    item = (7 * nu1 + nu2) % total
+    before = owner.read_db_item(item)
+    if fmt == SV.DB_LIMBS:
+        owner.set_db_format(SV.DB_PACKED)
+        assert owner.db_format() == SV.DB_PACKED
+    assert_eq(owner.read_db_item(item), before, f"item {item} after converting the image back, params {nu1},{nu2},{kw}")
+    owner.run_query()
+    owner.sync()
+    assert_eq(owner.read(SV.BUF_FINAL), want0, f"single query after converting the image back, params {nu1},{nu2},{kw}")
     for srv in lanes[1:]:
         srv.close()
     owner.close()
