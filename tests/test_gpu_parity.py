@@ -460,6 +460,23 @@ def _random_parameter_sets(count, seed):
     return out
 
 
+def _with_matrix_core_geometries(sets):
+    """every third set of a draw moved to a geometry the matrix-core sweep covers (first dimension 64 or 128, at least 64 ciphertexts per slot), keeping its
+    drawn gadget dimensions, moduli and query form: the limb-plane image and sweep_mfma_kernel then meet the same variety the vector-ALU sweep does"""
+    out = []
+    for i, (nu1, nu2, kw) in enumerate(sets):
+        if i % 3 == 2:
+            nu1, nu2 = ((6, 6), (7, 6), (6, 6))[(i // 3) % 3]
+            if not kw["direct_upload"] and (1 << nu1) + kw["t_gsw"] * nu2 > 2048:
+                kw = dict(kw, t_gsw=8)
+        out.append((nu1, nu2, kw))
+    return out
+
+
+def _has_limb_form(nu1, nu2):
+    return 6 <= nu1 <= 11 and nu2 >= 6  # (sweep_mfma.hip sweep_mfma_ok: first dimension a power of two in [64, 2048], num_per >= 64)
+
+
 _N_FUZZ = int(__import__("os").environ.get("SPIRAL_FUZZ_SETS", "16"))  # a soak run sets it to hundreds
 
 
@@ -497,7 +514,7 @@ def test_random_parameter_sets_bit_exact(sa, oracle, nu1, nu2, kw):
 _N_FUZZ_BATCH = max(6, _N_FUZZ // 4)
 
 
-@pytest.mark.parametrize("nu1,nu2,kw", _random_parameter_sets(_N_FUZZ_BATCH, 515), ids=[f"set{i}" for i in range(_N_FUZZ_BATCH)])
+@pytest.mark.parametrize("nu1,nu2,kw", _with_matrix_core_geometries(_random_parameter_sets(_N_FUZZ_BATCH, 515)), ids=[f"set{i}" for i in range(_N_FUZZ_BATCH)])
 def test_random_parameter_sets_batched(sa, oracle, nu1, nu2, kw):
     """another seeded draw of parameter sets through run_query_batch with 2-8 lanes (each lane its own client): every lane's folded ciphertext and
     response == the oracle's for its inputs -- odd gadget dimensions, both query forms, expansions with and without a stop round, tiny geometries
@@ -532,6 +549,8 @@ def test_random_parameter_sets_batched(sa, oracle, nu1, nu2, kw):
     # one image per server: where the batch swept on the matrix cores it converted the owner's image in place; a single query then sweeps the limb planes
     # (sweep_mfma_kernel<1>), and converting back restores the packed words exactly -- on this draw's geometry
     fmt = owner.db_format()
+    if _has_limb_form(nu1, nu2) and n >= max(sa.get_option("sweep_mfma_min"), 1) and sa.get_option("sweep_mfma_min") and sa.get_option("one_image"):
+        assert fmt == SV.DB_LIMBS, f"a batch of {n} at ({nu1}, {nu2}) should have converted the image"
     want0 = O.answer(po, qs[0], *pps[0], db)
     owner.run_query()
     owner.sync()
@@ -970,6 +989,54 @@ def test_run_query_instances_factor_3_over_two_ranks(sa, oracle, nu1, nu2, kw, g
         qsrv.close()
         for sv in inst:
             sv.close()
+
+
+_N_FUZZ_INST = max(4, _N_FUZZ // 8)
+
+
+@pytest.mark.parametrize("nu1,nu2,kw", _with_matrix_core_geometries(_random_parameter_sets(_N_FUZZ_INST, 7117)), ids=[f"set{i}" for i in range(_N_FUZZ_INST)])
+def test_random_parameter_sets_instances(sa, oracle, nu1, nu2, kw):
+    """a third seeded draw through spiral_gpu_server_run_query_instances: one query against two database instances (factor 2; one of them in the limb-plane form
+    where the geometry has one), eagerly and as a replayed hipGraph, conversion inside the call and as its own step: every instance's folded ciphertext and
+    response == the oracle's answer against that instance's database"""
+    import torch
+
+    O = oracle
+    from spiral_amd import server as SV
+
+    po, pg = O.make_params(nu1, nu2, **kw), sa.make_params(nu1, nu2, **kw)
+    cl = O.Client(po, seed=3 + nu1 + 5 * nu2)
+    pp = cl.pub_params()
+    inst, dbs = [], []
+    for k in range(2):
+        sv = sa.Server(pg)
+        sv.gen_db(40 + k)
+        dbs.append(O.gen_db(po, 40 + k))
+        inst.append(sv)
+    if _has_limb_form(nu1, nu2):  # instance 1 answers from the limb planes through sweep_mfma_kernel<1>
+        inst[1].set_db_format(SV.DB_LIMBS)
+        assert inst[1].db_format() == SV.DB_LIMBS
+    inst[0].set_pub_params(*pp)  # the query lives on instance 0's server
+    words = 6 * N
+    resp = torch.zeros(2 * words, dtype=torch.int64, device="cuda")
+    fins = torch.zeros(2 * words, dtype=torch.int64, device="cuda")
+    total = 1 << (nu1 + nu2)
+    for rnd, idx in enumerate((1 % total, total - 1, total // 2, 0)):
+        q = cl.query(idx)
+        inst[0].use_graphs(rnd >= 1)
+        inst[0].set_query(q)
+        if rnd == 2:
+            inst[0].run_pre()
+        inst[0].run_query_instances(inst, resp.data_ptr(), fins.data_ptr(), pre=rnd != 2)
+        inst[0].sync()
+        for k in range(2):
+            want = O.answer(po, q, *pp, dbs[k])
+            got_f = fins[k * words:(k + 1) * words].cpu().numpy().view(np.uint64).reshape(3, 2, N)
+            got_r = resp[k * words:(k + 1) * words].cpu().numpy().view(np.uint64).reshape(3, 2, N)
+            assert_eq(got_f, want, f"round {rnd} instance {k}: folded ciphertext, params {nu1},{nu2},{kw}")
+            assert_eq(got_r, O.stage_rescale(po, want), f"round {rnd} instance {k}: response, params {nu1},{nu2},{kw}")
+    for sv in inst:
+        sv.close()
 
 
 def test_batch_without_the_matrix_core_image_and_after_a_reload(sa, oracle, opts):
