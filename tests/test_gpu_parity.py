@@ -1261,6 +1261,85 @@ def test_distributed_fold_emulated_on_one_gpu(sa, oracle, G, graphs):
         srv.close()
 
 
+_N_FUZZ_SHARD = max(6, _N_FUZZ // 8)
+
+
+def _shardable(sets):
+    return [(nu1, max(nu2, 1), kw) for nu1, nu2, kw in sets]  # (a fold over ranks needs at least two ciphertexts)
+
+
+@pytest.mark.parametrize("nu1,nu2,kw", _shardable(_random_parameter_sets(_N_FUZZ_SHARD, 909)), ids=[f"set{i}" for i in range(_N_FUZZ_SHARD)])
+def test_random_parameter_sets_sharded(sa, oracle, nu1, nu2, kw):
+    """the N > 1 answer path on a seeded draw of parameter sets: G emulated ranks (2 or 4, as the geometry allows) with j-shards of the database, the reduce-scatter and
+    the all-gather as torch sums / slices, local folds and the root fold as replayed hipGraphs (the call sequence of bench.py's in-order schedule) == the oracle's
+    single-device answer, bit for bit -- odd gadget dimensions, both query forms, shards of one first-dimension index"""
+    import torch
+    from spiral_amd import dist as sdist
+    from spiral_amd import server as SV
+
+    O = oracle
+    po, pg = O.make_params(nu1, nu2, **kw), sa.make_params(nu1, nu2, **kw)
+    s = O.shape_of(po)
+    G = 4 if (nu1 >= 2 and nu2 >= 2 and (nu1 + nu2) % 2 == 0) else 2
+    cl = O.Client(po, seed=17 + nu1)
+    wl, wr, w, v = cl.pub_params()
+    db = O.gen_db(po, 55)
+    dev = torch.device("cuda", 0)
+    words = s.num_per * 6 * N
+    L = words // G
+    srvs, accs, chunks, cts = [], [], [], []
+    for g in range(G):
+        srv = sa.Server(pg, 0, g * s.dim0 // G, (g + 1) * s.dim0 // G)
+        srv.gen_db(55)
+        srv.set_pub_params(wl, wr, w, v)
+        srv.set_fold_ranks(G)
+        accs.append(torch.zeros(words, dtype=torch.int64, device=dev))
+        chunks.append(torch.zeros(L, dtype=torch.int64, device=dev))
+        cts.append(torch.zeros(6 * N, dtype=torch.int64, device=dev))
+        srv.set_acc(accs[g].data_ptr())
+        srv.use_graphs(True)
+        srvs.append(srv)
+    gathered = torch.zeros(G * 6 * N, dtype=torch.int64, device=dev)
+    # where the query form allows it the expansion is sharded too (every rank its own subtree and every G-th GSW bit, the bits all-gathered): bench.py's default at N > 1
+    shard_expand = sdist.expand_shard_ok(sa.get_shape(pg), pg, G)
+    if shard_expand:
+        for g in range(G):
+            srvs[g].set_expand_shard(g, G)
+        bits = [torch.zeros(srvs[g].gsw_bits_words(), dtype=torch.int64, device=dev) for g in range(G)]
+        bits_all = torch.zeros(G * bits[0].numel(), dtype=torch.int64, device=dev)
+    total_items = 1 << (nu1 + nu2)
+    for idx in (total_items - 1, 0, total_items // 3):
+        q = cl.query(idx)
+        for g in range(G):
+            srvs[g].set_query(q)
+            if shard_expand:
+                srvs[g].run_expand_pack(bits[g].data_ptr())
+            else:
+                srvs[g].run_pre_sweep()
+            srvs[g].sync()
+        if shard_expand:
+            bits_all.copy_(torch.cat(bits))  # the all-gather of the GSW bits
+            torch.cuda.synchronize()
+            for g in range(G):
+                srvs[g].run_unpack_convert_sweep(bits_all.data_ptr())
+                srvs[g].sync()
+        total = torch.stack(accs).sum(0)
+        for g in range(G):
+            chunks[g].copy_(total[g * L:(g + 1) * L])
+            torch.cuda.synchronize()
+            srvs[g].fold_local(chunks[g].data_ptr(), cts[g].data_ptr())
+            srvs[g].sync()
+        gathered.copy_(torch.cat(cts))
+        torch.cuda.synchronize()
+        srvs[0].fold_root(gathered.data_ptr())
+        srvs[0].sync()
+        want = O.answer(po, q, wl, wr, w, v, db)
+        assert_eq(srvs[0].read(SV.BUF_FINAL), want, f"sharded over G={G} idx={idx}: folded ciphertext, params {nu1},{nu2},{kw}")
+        assert_eq(srvs[0].read(SV.BUF_RESPONSE), O.stage_rescale(po, want), f"sharded over G={G} idx={idx}: response")
+    for srv in srvs:
+        srv.close()
+
+
 @pytest.mark.parametrize("G,K,nu2", [(1, 2, 6), (2, 2, 6), (8, 2, 6), (2, 4, 7), (4, 4, 7)])
 def test_pipelined_sweep_stages_emulated_on_one_gpu(sa, oracle, G, K, nu2):
     """the pipelined sweep: G emulated ranks sweep their j-shards in K column-block stages (first_dim_stage) into accumulators laid out
