@@ -325,7 +325,7 @@ def test_bench_collective_smoke_and_headline_swap():
     assert out["config"]["value_no_prewarm"] == out["value_no_prewarm"]["value"] > 0
 
 
-def test_bench_stream_item_factor_sharded_over_two_ranks():
+def test_bench_stream_item_factor_sharded_over_two_and_eight_ranks():
     """bench.py --workload stream: a 100 KB item = 7 database instances; two ranks (one device, gloo) hold instances {0, 2, 4, 6} and {1, 3, 5}, every rank
     converts the one query, ONE all-gather of the seven responses, no reduce.  At a geometry small enough for all seven instances to be resident on the one
     device; the same answer hash as the one-rank run (which sweeps the seven instances one after the other)."""
@@ -346,6 +346,11 @@ def test_bench_stream_item_factor_sharded_over_two_ranks():
         assert it["db_device_bytes_rank0"] == len(mine) * it["image_bytes_per_instance"] and o["value"] > 0 and o["roofline"]["achieved"] > 0
     assert o1["answer_sha256"] == o2["answer_sha256"] == o2["config"]["answer_sha256"] and len(o1["answer_sha256"]) == 64
     assert "no reduce" in o2["config"]["parallelism"] and o2["rccl"]["collective_smoke"]["ok"] is True
+    # N = 8, what the driver's scaling run does: one instance per rank and rank 7 holds NONE (factor 7) -- it only takes part in the all-gather
+    r8 = subprocess.run(base + ["--gpus", "8", "--backend", "gloo", "--shared-device"], capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert r8.returncode == 0, r8.stdout[-2000:] + r8.stderr[-2000:]
+    o8 = json.loads([ln for ln in r8.stdout.splitlines() if ln.startswith("{")][-1])
+    assert o8["n_gpus"] == 8 and o8["item"]["instances_of_rank0"] == [0] and o8["answer_sha256"] == o1["answer_sha256"] and "partial" not in o8
 
 
 def _bench_env(**extra):
